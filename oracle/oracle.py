@@ -1,0 +1,230 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU checker.
+
+`oracle/libfpt_oracle.so` is the C restatement (oracle/fpt_oracle.c) and
+`oracle/_ref/libfpt_ref.so` (optional) is the reference's own native code
+compiled from /root/reference.  Only tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py may import this module; the product package
+(footprint_tools_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+WIN_OPS = {"sum": 0, "product": 1, "fishers_combined": 2, "stouffers_z": 3,
+           "weighted_stouffers_z": 4}
+MAP1 = {"gamma": 0, "lgam": 1, "ndtr": 2, "ndtri": 3, "log1p": 4, "erf": 5, "erfc": 6}
+
+# canonical synthetic dispersion model (DM-SYNTH-A)
+DM_SYNTH_A = dict(
+    mu=np.array([25, 50, 75, 0, 0.5, 1.0, 1.0, 0.98, 0.97], dtype=np.float64),
+    r=np.array([3, 7, 15, 25, 75, 0.05, 0.08, 0.115, 0.16, 0.185, 0.02, 0.01, 0.005, 0.002,
+                0.001], dtype=np.float64))
+
+
+def build(force=False):
+    """Compile the checker(s) with the committed Makefile."""
+    so = os.path.join(HERE, "libfpt_oracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(
+            os.path.join(HERE, "fpt_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_map1.argtypes = [C.c_int, f64p, C.c_int64, f64p]
+        L.orc_incbet_v.argtypes = [f64p, f64p, f64p, C.c_int64, f64p]
+        L.orc_chdtrc_v.argtypes = [f64p, f64p, C.c_int64, f64p]
+        L.orc_kmer_probs.argtypes = [u8p, C.c_int64, f64p, C.c_double, f64p, f64p, i32p, i32p]
+        L.orc_fast_predict.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p]
+        L.orc_fit_mu.argtypes = [f64p, C.c_double]
+        L.orc_fit_mu.restype = C.c_double
+        L.orc_fit_r.argtypes = [f64p, C.c_double, C.POINTER(C.c_double)]
+        L.orc_nb_values.argtypes = [C.c_int, f64p, f64p, f64p, f64p, C.c_int64, f64p]
+        for nm in ("orc_nb_cdf", "orc_nb_logpmf", "orc_nb_pmf"):
+            getattr(L, nm).argtypes = [C.c_int32, C.c_double, C.c_double]
+            getattr(L, nm).restype = C.c_double
+        L.orc_window.argtypes = [C.c_int, f64p, C.c_void_p, C.c_int, C.c_int, f64p]
+        L.orc_bisect.argtypes = [f64p, C.c_int, f64p, C.c_int, f64p]
+        L.orc_emperical_fdr.argtypes = [f64p, C.c_int64, f64p, C.c_int, f64p]
+        L.orc_segment.argtypes = [f64p, C.c_int, C.c_double, C.c_int, C.c_int, i32p, C.c_int]
+        L.orc_detect_batch.argtypes = [f64p, f64p, u8p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, f64p, C.c_double, f64p, f64p, i32p, C.c_int,
+                                       f64p, f64p, f64p, f64p, C.c_int]
+        L.orc_log_likelihood_row.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int, C.c_int, f64p]
+        L.orc_synth_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                                     C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own native sources (None when oracle/_ref was not built)."""
+    global _REF
+    if _REF is None:
+        so = os.path.join(HERE, "_ref", "libfpt_ref.so")
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        R.ref_fast_predict.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p]
+        R.ref_window.argtypes = [C.c_int, f64p, C.c_void_p, C.c_int, C.c_int, f64p]
+        R.ref_map1.argtypes = [C.c_int, f64p, C.c_long, f64p]
+        R.ref_incbet_v.argtypes = [f64p, f64p, f64p, C.c_long, f64p]
+        R.ref_chdtrc_v.argtypes = [f64p, f64p, C.c_long, f64p]
+        _REF = R
+    return _REF
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def map1(name, x, ref=False):
+    x = _f(x).ravel()
+    out = np.empty_like(x)
+    if ref:
+        ref_lib().ref_map1(MAP1[name], x, x.size, out)
+    else:
+        lib().orc_map1(MAP1[name], x, x.size, out)
+    return out
+
+
+def incbet(a, b, x, ref=False):
+    a, b, x = np.broadcast_arrays(_f(a), _f(b), _f(x))
+    a, b, x = _f(a).ravel(), _f(b).ravel(), _f(x).ravel()
+    out = np.empty_like(a)
+    (ref_lib().ref_incbet_v if ref else lib().orc_incbet_v)(a, b, x, a.size, out)
+    return out
+
+
+def chdtrc(df, x, ref=False):
+    df, x = np.broadcast_arrays(_f(df), _f(x))
+    df, x = _f(df).ravel(), _f(x).ravel()
+    out = np.empty_like(x)
+    (ref_lib().ref_chdtrc_v if ref else lib().orc_chdtrc_v)(df, x, x.size, out)
+    return out
+
+
+def seq_bytes(seq):
+    if isinstance(seq, str):
+        seq = seq.encode("ascii")
+    if isinstance(seq, (bytes, bytearray)):
+        return np.frombuffer(bytes(seq), dtype=np.uint8).copy()
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+def kmer_probs(seq, table, dflt=1e-6):
+    s = seq_bytes(seq)
+    l = max(s.size - 6, 0)
+    fwd, rev = np.empty(l), np.empty(l)
+    fi, ri = np.empty(l, np.int32), np.empty(l, np.int32)
+    lib().orc_kmer_probs(s, s.size, _f(table), dflt, fwd, rev, fi, ri)
+    return fwd, rev, fi, ri
+
+
+def fast_predict(obs, probs, hw, shw, clip, ref=False):
+    obs, probs = _f(obs), _f(probs)
+    l = obs.size
+    e, w = np.empty(l), np.empty(l)
+    (ref_lib().ref_fast_predict if ref else lib().orc_fast_predict)(obs, probs, l, hw, shw, clip, e, w)
+    return e, w
+
+
+def fit_mu(mu_par, x):
+    return lib().orc_fit_mu(_f(mu_par), float(x))
+
+
+def fit_r(r_par, x):
+    out = C.c_double()
+    if lib().orc_fit_r(_f(r_par), float(x), C.byref(out)):
+        raise ZeroDivisionError("float division")
+    return out.value
+
+
+def nb_values(what, mu_par, r_par, exp, obs):
+    exp, obs = _f(exp), _f(obs)
+    out = np.empty(exp.size)
+    code = {"cdf": 0, "logpmf": 1, "pmf": 2}[what]
+    if lib().orc_nb_values(code, _f(mu_par), _f(r_par), exp, obs, exp.size, out):
+        raise ZeroDivisionError("float division")
+    return out
+
+
+def window(op, x, hw, w=None, ref=False):
+    x = _f(x)
+    out = np.empty(x.size)
+    wp = None
+    if w is not None:
+        w = _f(w)
+        wp = w.ctypes.data
+    (ref_lib().ref_window if ref else lib().orc_window)(WIN_OPS[op], x, wp, x.size, hw, out)
+    return out
+
+
+def bisect(a, b):
+    a, b = _f(a), _f(b)
+    out = np.empty(b.size)
+    lib().orc_bisect(a, a.size, b, b.size, out)
+    return out
+
+
+def emperical_fdr(pvals_null, pvals):
+    nul, p = _f(pvals_null).ravel(), _f(pvals)
+    out = np.empty(p.size)
+    lib().orc_emperical_fdr(nul, nul.size, p, p.size, out)
+    return out
+
+
+def segment(x, threshold, w=1, decreasing=False):
+    x = _f(x)
+    seg = np.empty(2 * (x.size + 1), np.int32)
+    n = lib().orc_segment(x, x.size, threshold, w, int(bool(decreasing)), seg, x.size + 1)
+    return seg[:2 * n].reshape(n, 2).tolist()
+
+
+def detect_batch(counts_plus, counts_minus, seq, n_iv, L, hw, shw, clip, table, mu_par, r_par,
+                 scales, dflt=1e-6, n_threads=1):
+    """Equal-length batch; returns exp, obs, p (n_iv*L) and winp (S, n_iv*L)."""
+    scales = np.ascontiguousarray(scales, dtype=np.int32)
+    tot = n_iv * L
+    e, o, p = np.empty(tot), np.empty(tot), np.empty(tot)
+    wp = np.empty((scales.size, tot))
+    rc = lib().orc_detect_batch(_f(counts_plus).ravel(), _f(counts_minus).ravel(),
+                                seq_bytes(seq).ravel(), n_iv, L, hw, shw, clip, _f(table), dflt,
+                                _f(mu_par), _f(r_par), scales, scales.size, e, o, p, wp, n_threads)
+    if rc:
+        raise ZeroDivisionError("float division")
+    return e, o, p, wp
+
+
+def log_likelihood_row(mu_par, r_par, obs, exp, delta, w):
+    obs, exp = _f(obs), _f(exp)
+    delta = _f(np.broadcast_to(delta, obs.shape))
+    out = np.empty(obs.size)
+    if lib().orc_log_likelihood_row(_f(mu_par), _f(r_par), obs, exp, delta, obs.size, w, out):
+        raise ZeroDivisionError("float division")
+    return out
+
+
+def synth_counts(seed, pos0, n, stream):
+    out = np.empty(n)
+    lib().orc_synth_fill(seed, pos0, n, stream, out.ctypes.data, None)
+    return out
+
+
+def synth_bases(seed, pos0, n):
+    out = np.empty(n, np.uint8)
+    lib().orc_synth_fill(seed, pos0, n, 2, None, out.ctypes.data)
+    return out

@@ -1,0 +1,440 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz from the GENUINE reference.
+
+Runs only in the dev container (needs /root/reference):
+    python oracle/pyref/build_pyref.py      # cython+gcc on the reference's own sources -> /tmp
+    make -C oracle                          # also builds oracle/_ref/libfpt_ref.so
+    python tests/golden/make_golden.py
+
+Expected outputs come from
+  * the reference package itself (footprint_tools.modeling / .stats, imported through
+    oracle/pyref/ref_import.py), and
+  * the reference's native C (hcephes, predict.h, windowing.h) compiled where it lies into
+    oracle/_ref/libfpt_ref.so, for functions that have no Python entry point
+    (`cdef predict`, raw hcephes calls).
+No code of this repo's restatement or HIP path is used to produce an expected value.
+The reference has no tests or golden vectors of its own, so these files are
+what pins parity.
+"""
+import ctypes as C
+import hashlib
+import os
+import platform
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "pyref"))
+import ref_import  # noqa: E402
+
+ref_import.load()
+from footprint_tools.modeling import bias, dispersion, predict  # noqa: E402
+from footprint_tools.stats import fdr, posterior, utils, windowing  # noqa: E402
+from footprint_tools.stats.distributions import nbinom  # noqa: E402
+
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+REFC = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libfpt_ref.so"))
+REFC.ref_fast_predict.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p]
+REFC.ref_map1.argtypes = [C.c_int, f64p, C.c_long, f64p]
+REFC.ref_incbet_v.argtypes = [f64p, f64p, f64p, C.c_long, f64p]
+REFC.ref_chdtrc_v.argtypes = [f64p, f64p, C.c_long, f64p]
+
+PROVENANCE = np.array([
+    "reference=vierstralab/footprint-tools v1.3.7 (+hcephes 0.4.1) built from /root/reference",
+    "gcc -O2 -fwrapv; cython 3.x; " + platform.platform(),
+    "numpy " + np.__version__ + "; python " + platform.python_version(),
+])
+
+DMS = {
+    # SURVEY.md App. B canonical synthetic model
+    "A": ([25, 50, 75, 0, 0.5, 1.0, 1.0, 0.98, 0.97],
+          [3, 7, 15, 25, 75, 0.05, 0.08, 0.115, 0.16, 0.185, 0.02, 0.01, 0.005, 0.002, 0.001]),
+    # Poisson-like (r in the hundreds: a+b > MAXGAM -> lgam epilogue of incbet)
+    "B": ([10, 40, 80, 0.2, 0.1, 0.5, 0.95, 0.96, 0.955],
+          [5, 10, 20, 40, 80, 0.002, 0.002, 0.003, 0.004, 0.006,
+           0.0002, 0.0002, 0.0001, 0.00005, 0.00002]),
+    # heavy dispersion (r ~ 1..2.5), mu clamps to 0.1 near 0
+    "C": ([20, 60, 100, -0.5, 0.3, 1.5, 1.1, 1.05, 1.0],
+          [2, 6, 12, 30, 60, 0.4, 0.45, 0.5, 0.6, 0.7, 0.03, 0.02, 0.015, 0.01, 0.005]),
+    # first 1/r segment negative below x=2.5 (r clamps to 1e-6)
+    "D": ([25, 50, 75, 0, 0.5, 1.0, 1.0, 0.98, 0.97],
+          [3, 7, 15, 25, 75, -0.05, 0.08, 0.115, 0.16, 0.185, 0.02, 0.01, 0.005, 0.002, 0.001]),
+}
+
+
+def make_dm(key):
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = DMS[key]
+    return dm
+
+
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth(seed, pos0, n, stream):
+    """SURVEY.md 8(d) counter-hash generator (bench-defined): stream 0/1 counts, 2 bases."""
+    with np.errstate(over="ignore"):
+        key = splitmix64(np.array([seed + stream], dtype=np.uint64))[0]
+        h = splitmix64(key + np.arange(pos0, pos0 + n, dtype=np.uint64))
+    if stream < 2:
+        return ((h >> np.uint64(33)) % np.uint64(20)).astype(np.float64)
+    return np.frombuffer(b"ACGT", np.uint8)[((h >> np.uint64(13)) & np.uint64(3)).astype(np.int64)]
+
+
+def table_2bit(bm):
+    """4096-entry table in 2-bit order (A=0,C=1,G=2,T=3; first base most significant)."""
+    import itertools
+    return np.array([bm["".join(k)] for k in itertools.product("ACGT", repeat=6)])
+
+
+def ref_predict_c(obs, probs, hw, shw, clip):
+    obs = np.ascontiguousarray(obs, np.float64)
+    probs = np.ascontiguousarray(probs, np.float64)
+    e, w = np.empty(obs.size), np.empty(obs.size)
+    REFC.ref_fast_predict(obs, probs, obs.size, hw, shw, clip, e, w)
+    return e, w
+
+
+def ref_map1(op, x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    REFC.ref_map1(op, x, x.size, out)
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, provenance=PROVENANCE, **arrs)
+    print("%-20s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ---------------------------------------------------------------- G1: 6-mer lookup (A1)
+def g1():
+    bm = bias.kmer_model(os.path.join(ref_import.REF, "data", "vierstra_et_al.6mer-model.txt"))
+    rs = np.random.RandomState(11)
+    out = {"table": table_2bit(bm)}
+    seqs = []
+    s0 = "".join(rs.choice(list("ACGT"), 3000))
+    seqs.append(s0)
+    s1 = list("".join(rs.choice(list("ACGT"), 2000)))
+    for i in rs.choice(2000, 20, replace=False):
+        s1[i] = "N"
+    s1[0:8] = list("NNNNNNNN")
+    s1[500:503] = list("RYK")  # other IUPAC codes are unknown k-mers too
+    seqs.append("".join(s1))
+    s2 = "".join(rs.choice(list("ACGTacgtn"), 1500))
+    seqs.append(s2)
+    seqs.append("ACGTAC")  # len 6 -> empty output
+    seqs.append("ACGTACG")  # one output
+    for i, s in enumerate(seqs):
+        up = s.upper()  # predict.pyx:140
+        fwd = bm.probs(up)
+        rev = bm.probs(predict.reverse_complement(up))[::-1]
+        out["seq%d" % i] = np.frombuffer(s.encode(), np.uint8)
+        out["fwd%d" % i] = np.asarray(fwd, np.float64)
+        out["rev%d" % i] = np.asarray(rev, np.float64)
+    out["n_seq"] = np.array(len(seqs))
+    save("kmer_probs.npz", **out)
+    return bm, out["table"]
+
+
+# ---------------------------------------------------------------- G2: fast_predict (A2-A4)
+def g2():
+    rs = np.random.RandomState(22)
+    params = [(5, 0, .01), (5, 50, .01), (3, 10, .01), (5, 50, .05), (5, 25, 0.0), (1, 1, .4),
+              (5, 50, .2), (2, 7, .1)]
+    kinds = ["u20", "pois", "zero", "five", "two", "float", "ramp"]
+    lens = [11, 111, 611, 1111]
+    out, meta = {}, []
+    c = 0
+    for (hw, shw, clip) in params:
+        for kind in kinds:
+            for l in lens:
+                if l == 1111 and kind not in ("u20", "pois"):
+                    continue
+                if kind == "u20":
+                    obs = rs.randint(0, 20, l).astype(float)
+                elif kind == "pois":
+                    obs = rs.poisson(0.3, l).astype(float)
+                elif kind == "zero":
+                    obs = np.zeros(l)
+                elif kind == "five":
+                    obs = np.full(l, 5.0)
+                elif kind == "two":
+                    obs = rs.choice([0.0, 7.0], l, p=[.9, .1])
+                elif kind == "float":
+                    obs = rs.gamma(2.0, 1.7, l)
+                else:
+                    obs = np.arange(l, dtype=float) % 37
+                probs = rs.uniform(3e-4, 0.22, l)
+                e, w = ref_predict_c(obs, probs, hw, shw, clip)
+                out["obs%d" % c], out["probs%d" % c] = obs, probs
+                out["exp%d" % c], out["win%d" % c] = e, w
+                meta.append((hw, shw, clip, l))
+                c += 1
+    # degenerate lengths: l <= 2*hw, l <= 2*shw, l == 0/1
+    for (hw, shw, clip, l) in [(5, 50, .01, 10), (5, 50, .01, 100), (5, 50, .01, 101),
+                               (5, 50, .01, 102), (5, 0, .01, 1), (5, 3, .3, 8), (0, 2, .25, 9)]:
+        obs = rs.randint(0, 20, l).astype(float)
+        probs = rs.uniform(3e-4, 0.22, l)
+        e, w = ref_predict_c(obs, probs, hw, shw, clip)
+        out["obs%d" % c], out["probs%d" % c] = obs, probs
+        out["exp%d" % c], out["win%d" % c] = e, w
+        meta.append((hw, shw, clip, l))
+        c += 1
+    out["meta"] = np.array(meta, dtype=np.float64)
+    save("predict.npz", **out)
+
+
+# ---------------------------------------------------------------- G3: NB lattice (A5-A7) + hcephes grids
+def g3():
+    out = {}
+    ne, no = 120, 80
+    E, O = np.meshgrid(np.arange(ne, dtype=float), np.arange(no, dtype=float), indexing="ij")
+    e, o = E.ravel().copy(), O.ravel().copy()
+    out["lat_exp"], out["lat_obs"] = e, o
+    xs = np.concatenate([np.arange(0, 260, dtype=float), np.array([0.5, 2.49, 2.5, 24.999, 1e3, 1e6])])
+    out["fit_x"] = xs
+    for key in DMS:
+        dm = make_dm(key)
+        out["mu_%s" % key], out["r_%s" % key] = np.asarray(dm.mu_params, float), np.asarray(dm.r_params, float)
+        out["fit_mu_%s" % key] = np.array([dm.fit_mu(x) for x in xs])
+        fr, zd = [], []
+        for x in xs:  # fit_r raises ZeroDivisionError when the piecewise value is exactly 0
+            try:
+                fr.append(dm.fit_r(x))
+                zd.append(0)
+            except ZeroDivisionError:
+                fr.append(np.nan)
+                zd.append(1)
+        out["fit_r_%s" % key], out["fit_r_zerodiv_%s" % key] = np.array(fr), np.array(zd)
+        out["cdf_%s" % key] = np.asarray(dm.p_values(e, o)).copy()
+        out["logpmf_%s" % key] = np.asarray(dm.log_pmf_values(e, o)).copy()
+        out["pmf_%s" % key] = np.asarray(dm.pmf_values(e, o)).copy()
+    # heavier tails / non-integer obs (C truncation), large counts
+    rs = np.random.RandomState(33)
+    e2 = np.round(rs.gamma(2.0, 30.0, 4000))
+    o2 = np.floor(rs.gamma(1.5, 40.0, 4000)) + rs.choice([0.0, 0.25, 0.999], 4000)
+    out["tail_exp"], out["tail_obs"] = e2, o2
+    for key in ("A", "B", "C"):
+        dm = make_dm(key)
+        out["tail_cdf_%s" % key] = np.asarray(dm.p_values(e2, o2)).copy()
+        out["tail_logpmf_%s" % key] = np.asarray(dm.log_pmf_values(e2, o2)).copy()
+    # nbinom scalars (nbinom.pyx:82-138)
+    ks = np.array([0, 1, 2, 5, 17, 40, 300, -1, -5], dtype=np.int32)
+    ps = np.array([0.01, 0.3, 0.5, 0.9, 0.999])
+    rr = np.array([1e-6, 0.5, 3.0, 20.0, 180.0, 2000.0])
+    K, P, R = [a.ravel() for a in np.meshgrid(ks, ps, rr, indexing="ij")]
+    out["sc_k"], out["sc_p"], out["sc_r"] = K.astype(np.int32), P, R
+    out["sc_cdf"] = np.array([nbinom.cdf(int(k), p, r) for k, p, r in zip(K, P, R)])
+    out["sc_logpmf"] = np.array([nbinom.logpmf(int(k), p, r) for k, p, r in zip(K, P, R)])
+    out["sc_pmf"] = np.array([nbinom.pmf(int(k), p, r) for k, p, r in zip(K, P, R)])
+
+    # raw hcephes grids incl. branch boundaries (incbet.c, gamma.c, unity.c)
+    a = np.concatenate([np.logspace(-6, 3, 28), [1.0, 2.0, 33.0, 85.8, 170.0, 171.0, 172.0]])
+    b = np.concatenate([np.logspace(-2, 3, 18), [1.0, 2.0, 11.0, 85.82, 171.7]])
+    x = np.concatenate([np.logspace(-8, -0.01, 24), [0.5, 0.9, 0.95, 0.9500001, 0.99, 1 - 1e-9,
+                                                     0.0, 1.0, -0.1, 1.5]])
+    A, B, X = [v.ravel().copy() for v in np.meshgrid(a, b, x, indexing="ij")]
+    ib = np.empty_like(A)
+    REFC.ref_incbet_v(A, B, X, A.size, ib)
+    out["ib_a"], out["ib_b"], out["ib_x"], out["ib_val"] = A, B, X, ib
+    gx = np.concatenate([np.linspace(-40.5, 40.5, 163), np.logspace(-12, 2.3, 60),
+                         [33.0, 33.0000001, 143.01608, 143.02, 171.6, 171.7, 172.0, 1e-9, -1e-10,
+                          0.0, 2.0, 3.0, 1.0, -1.0, -2.5, 12.999, 13.0, 999.9, 1000.0, 1e8, 1.1e8,
+                          1e300, 3e305, -34.5, -35.0, -100.25, np.inf, -np.inf, np.nan]])
+    out["g_x"] = gx
+    out["g_gamma"], out["g_lgam"] = ref_map1(0, gx), ref_map1(1, gx)
+    lx = np.concatenate([np.linspace(-0.999, 1.5, 120), np.logspace(-18, -1, 40), -np.logspace(-18, -1, 40),
+                         [0.0, -1.0, -1.5, 0.41421356237309503, 0.41421356237309515, -0.2928932188134524,
+                          -0.29289321881345254]])
+    out["l1p_x"], out["l1p_val"] = lx, ref_map1(4, lx)
+    save("nb_lattice.npz", **out)
+
+
+# ---------------------------------------------------------------- G4: windows (A8-A9) + ndtr/ndtri grids
+def g4():
+    rs = np.random.RandomState(44)
+    out = {}
+    arrays = {}
+    arrays["unif"] = rs.uniform(0, 1, 300)
+    sm = rs.uniform(0, 1, 200) ** 6
+    arrays["small"] = sm
+    pl = rs.uniform(0, 1, 260)
+    pl[[7, 50, 51, 120, 200, 201, 255]] = [1e-18, 1e-15, 0.0, 1.0, np.nan, 5e-17, 6e-17]
+    pl[[30, 31]] = [1.0 - 1e-16, 2.0]
+    arrays["planted"] = pl
+    arrays["short5"] = rs.uniform(0, 1, 5)
+    arrays["one"] = np.array([0.3])
+    arrays["empty"] = np.zeros(0)
+    hws = [0, 1, 2, 3, 5, 10, 20, 40]
+    fns = {"sum": windowing.sum, "product": windowing.product,
+           "fishers_combined": windowing.fishers_combined, "stouffers_z": windowing.stouffers_z}
+    names = []
+    for nm, x in arrays.items():
+        out["x_" + nm] = x
+        names.append(nm)
+        wts = rs.uniform(0.1, 3.0, x.size)
+        out["w_" + nm] = wts
+        for hw in hws:
+            for fn, f in fns.items():
+                out["%s_%s_%d" % (fn, nm, hw)] = np.asarray(f(np.ascontiguousarray(x), hw)) if x.size else np.ones(0)
+            out["weighted_stouffers_z_%s_%d" % (nm, hw)] = (
+                np.asarray(windowing.weighted_stouffers_z(np.ascontiguousarray(x), wts, hw)) if x.size else np.ones(0))
+    out["names"] = np.array(names)
+    out["hws"] = np.array(hws)
+    # ndtri / ndtr / erf / erfc grids incl. boundaries (ndtri.c:48-88, ndtr.c:34-132)
+    e2 = 0.13533528323661269189
+    y = np.concatenate([np.linspace(0, 1, 401), np.logspace(-320, -1, 200), 1 - np.logspace(-16.5, -1, 100),
+                        [e2, np.nextafter(e2, 1), np.nextafter(e2, 0), 1 - e2, np.nextafter(1 - e2, 1),
+                         np.exp(-32.0), 1.2664165549e-14, 1.27e-14, 1.0, 0.0, -0.5, 1.5, 1 - 2 ** -53,
+                         np.nan]])
+    out["ndtri_y"], out["ndtri_val"] = y, ref_map1(3, y)
+    a = np.concatenate([np.linspace(-40, 40, 801), [1.4142135623730951, -1.4142135623730951, 11.313708498984761,
+                                                    -11.3137085, 37.5, -37.5, 37.6, -37.6, -38.5, 1e-300, np.inf,
+                                                    -np.inf, np.nan], rs.normal(0, 3, 300)])
+    out["ndtr_a"], out["ndtr_val"] = a, ref_map1(2, a)
+    out["erf_val"], out["erfc_val"] = ref_map1(5, a), ref_map1(6, a)
+    df = np.array([1.0, 2.0, 6.0, 14.0, 22.0, 42.0, 82.0, 162.0, 0.5])
+    xx = np.concatenate([np.logspace(-3, 3.2, 60), [0.0, -1.0, 1.0]])
+    D, XX = [v.ravel().copy() for v in np.meshgrid(df, xx, indexing="ij")]
+    ch = np.empty_like(D)
+    REFC.ref_chdtrc_v(D, XX, D.size, ch)
+    out["ch_df"], out["ch_x"], out["ch_val"] = D, XX, ch
+    save("window.npz", **out)
+
+
+# ---------------------------------------------------------------- G5: config 1 end to end
+class _Reads(object):
+    def __init__(self, plus, minus):
+        self.p, self.m = plus, minus
+
+    def __getitem__(self, iv):
+        return {"+": self.p, "-": self.m}
+
+
+class _Fasta(object):
+    def __init__(self, seq):
+        self.seq = seq
+
+    def fetch(self, chrom, start, end):
+        assert end - start == len(self.seq)
+        return self.seq
+
+
+def g5(bm):
+    n_iv, L, hw, shw, clip = 1000, 500, 5, 50, 0.01
+    scales = (3, 5, 10, 20, 40)
+    n_full = 16
+    pad = hw + shw
+    l = L + 2 * pad + 1
+    dm = make_dm("A")
+    full = {k: [] for k in ("exp", "obs", "p")}
+    full_w = []
+    sums = np.zeros((n_iv, 3 + len(scales)))
+    nans = np.zeros((n_iv, 1 + len(scales)), np.int32)
+    sha = hashlib.sha256()
+    sha_p = hashlib.sha256()
+    for i in range(n_iv):
+        cp = synth(1, i * l, l, 0)
+        cm = synth(1, i * l, l, 1)
+        sq = synth(1, i * (l + 6), l + 6, 2).tobytes().decode()
+        pr = predict.prediction(_Reads(cp, cm), _Fasta(sq), bm, half_win_width=hw,
+                                smoothing_half_win_width=shw, smoothing_clip=clip)
+        iv = ref_import.genomic_interval("chr1", 1000, 1000 + L)
+        obs, exp, _ = pr.compute(iv)
+        obs = obs["+"][1:] + obs["-"][:-1]  # cli/detect.py:121-122
+        exp = exp["+"][1:] + exp["-"][:-1]
+        p = np.asarray(dm.p_values(exp, obs)).copy()
+        wps = [windowing.stouffers_z(np.ascontiguousarray(p), s) for s in scales]
+        sha.update(np.ascontiguousarray(exp).tobytes())
+        sha.update(np.ascontiguousarray(obs).tobytes())
+        sha_p.update(p.tobytes())
+        for wp in wps:
+            sha_p.update(np.ascontiguousarray(wp).tobytes())
+        sums[i, 0], sums[i, 1], sums[i, 2] = exp.sum(), obs.sum(), np.nansum(p)
+        nans[i, 0] = np.isnan(p).sum()
+        for s, wp in enumerate(wps):
+            sums[i, 3 + s] = np.nansum(wp)
+            nans[i, 1 + s] = np.isnan(wp).sum()
+        if i < n_full:
+            full["exp"].append(exp)
+            full["obs"].append(obs)
+            full["p"].append(p)
+            full_w.append(np.stack(wps))
+    save("e2e_cfg1.npz", n_iv=np.array(n_iv), L=np.array(L), hw=np.array(hw), shw=np.array(shw),
+         clip=np.array(clip), scales=np.array(scales), seed=np.array(1), dm_key=np.array("A"),
+         exp=np.stack(full["exp"]), obs=np.stack(full["obs"]), p=np.stack(full["p"]),
+         winp=np.stack(full_w), sums=sums, nan_counts=nans,
+         sha256_exp_obs=np.array(sha.hexdigest()), sha256_p_winp=np.array(sha_p.hexdigest()))
+
+
+# ---------------------------------------------------------------- G6: FDR helpers (A10)
+def g6():
+    rs = np.random.RandomState(66)
+    out = {}
+    nul = rs.uniform(0, 1, (500, 100)) ** 2
+    pv = rs.uniform(0, 1, 500) ** 3
+    pv[[3, 77]] = np.nan
+    pv[[10, 11]] = pv[12]
+    nul[5, 5] = np.nan
+    out["null"], out["pvals"], out["efdr"] = nul, pv, fdr.emperical_fdr(nul, pv)
+    a = np.sort(rs.uniform(0, 1, 300))
+    b = np.sort(rs.uniform(-0.1, 1.1, 120))
+    out["bis_a"], out["bis_b"], out["bis_out"] = a, b, utils.bisect(a, b)
+    x = rs.uniform(0, 1, 400)
+    x[100:120] = 0.001
+    x[121:125] = 0.002
+    x[395:] = 0.0001
+    x[0:2] = 0.0
+    segs = []
+    for k, (thr, w, dec) in enumerate([(0.01, 3, True), (0.5, 1, False), (0.01, 1, True), (0.9, 5, False)]):
+        s = utils.segment(x, thr, w, dec)
+        out["seg%d" % k] = np.array(s, dtype=np.int64).reshape(-1, 2)
+        segs.append((thr, w, int(dec)))
+    out["seg_x"], out["seg_params"] = x, np.array(segs)
+    save("fdr.npz", **out)
+
+
+# ---------------------------------------------------------------- G7: posterior (A11)
+def g7():
+    rs = np.random.RandomState(77)
+    nd, n = 4, 200
+    exp = np.round(rs.gamma(2.0, 10.0, (nd, n)))
+    obs = rs.poisson(np.maximum(exp * rs.uniform(0.2, 1.2, (nd, n)), 0.05)).astype(float)
+    fdrv = rs.uniform(0, 1, (nd, n)) ** 3
+    w = (rs.uniform(0, 1, (nd, n)) > 0.2).astype(float)
+    betas = rs.uniform(0.5, 4.0, (nd, 2))
+    keys = ["A", "B", "C", "A"]
+    dms = [make_dm(k) for k in keys]
+    prior = posterior.compute_prior_weighted(fdrv, w, cutoff=0.05)
+    delta = posterior.compute_delta_prior(obs, exp, fdrv, betas, cutoff=0.05)
+    ll_on = posterior.log_likelihood(obs, exp, dms, delta=delta, w=3)
+    ll_off = posterior.log_likelihood(obs, exp, dms, w=3)
+    post = posterior.posterior(prior, ll_on, ll_off)
+    save("posterior.npz", obs=obs, exp=exp, fdr=fdrv, w=w, betas=betas, dm_keys=np.array(keys),
+         prior=prior, delta=delta, ll_on=ll_on, ll_off=ll_off, post=post)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7"]
+    bm, table = g1() if ("1" in which or "5" in which) else (None, None)
+    if "2" in which:
+        g2()
+    if "3" in which:
+        g3()
+    if "4" in which:
+        g4()
+    if "5" in which:
+        g5(bm)
+    if "6" in which:
+        g6()
+    if "7" in which:
+        g7()
