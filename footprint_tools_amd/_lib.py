@@ -1,0 +1,203 @@
+"""ctypes binding of libfpt_hip.so (C ABI: include/fpt.h).  No PyTorch, no cffi."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfpt_hip.so")
+
+FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
+NB_CDF, NB_LOGPMF, NB_PMF = range(3)
+FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8)
+MAX_SCALES = 8
+MAX_DM = 64
+
+EXPORTS = [
+    "fpt_last_error", "fpt_version", "fpt_device_count", "fpt_ctx_create", "fpt_ctx_destroy",
+    "fpt_ctx_set_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
+    "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
+    "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
+    "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms",
+]
+
+
+class ScanDesc(C.Structure):
+    """struct fpt_scan_desc of include/fpt.h"""
+    _fields_ = [
+        ("n_intervals", C.c_int64),
+        ("interval_len", C.c_int32),
+        ("interval_off", C.c_void_p),
+        ("interval_off_host", C.c_void_p),
+        ("half_win_width", C.c_int32),
+        ("smoothing_half_win_width", C.c_int32),
+        ("smoothing_clip", C.c_double),
+        ("n_scales", C.c_int32),
+        ("scales", C.c_int32 * MAX_SCALES),
+        ("dm_id", C.c_int32),
+        ("counts_plus", C.c_void_p),
+        ("counts_minus", C.c_void_p),
+        ("seq", C.c_void_p),
+        ("exp_out", C.c_void_p),
+        ("obs_out", C.c_void_p),
+        ("pval_out", C.c_void_p),
+        ("winp_out", C.c_void_p),
+        ("status_out", C.c_void_p),
+    ]
+
+
+_lib = None
+_lock = threading.RLock()
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "footprint_tools_amd: %s is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C footprint_tools_amd/csrc` (needs hipcc; target gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+        L.fpt_last_error.restype = C.c_char_p
+        L.fpt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.fpt_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.fpt_ctx_destroy.argtypes = [vp]
+        L.fpt_ctx_set_stream.argtypes = [vp, vp]
+        L.fpt_ctx_synchronize.argtypes = [vp]
+        L.fpt_set_bias_table.argtypes = [vp, vp, dbl]
+        L.fpt_set_dispersion.argtypes = [vp, i32, vp, vp]
+        L.fpt_kmer_probs.argtypes = [vp, vp, i64, vp, vp]
+        L.fpt_predict.argtypes = [vp, vp, vp, i64, i32, i32, i32, dbl, vp, vp]
+        L.fpt_nb_values.argtypes = [vp, i32, i32, vp, vp, i64, vp]
+        L.fpt_nb_scalar.argtypes = [vp, i32, vp, vp, vp, i64, vp]
+        L.fpt_window.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp]
+        L.fpt_special.argtypes = [vp, i32, vp, vp, vp, i64, vp]
+        L.fpt_scan_dev.argtypes = [vp, C.POINTER(ScanDesc)]
+        L.fpt_synth_dev.argtypes = [vp, C.c_uint64, i64, i64, vp, vp, i64, i64, vp]
+        L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
+        L.fpt_dev_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+        L.fpt_dev_free.argtypes = [vp, vp]
+        L.fpt_memcpy_h2d.argtypes = [vp, vp, vp, i64]
+        L.fpt_memcpy_d2h.argtypes = [vp, vp, vp, i64]
+        L.fpt_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+class FptError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == FPT_OK:
+        return
+    msg = load().fpt_last_error().decode("utf-8", "replace")
+    if rc == FPT_ERR_ZERODIV:
+        raise ZeroDivisionError(msg or "float division")
+    if rc == FPT_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == FPT_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise FptError("libfpt_hip error %d: %s" % (rc, msg))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context(object):
+    """One per (process, GPU): stream, bias table, dispersion-model slots, workspace."""
+
+    def __init__(self, device=None):
+        L = load()
+        if device is None:
+            device = int(os.environ.get("FPT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = C.c_int(0)
+            L.fpt_device_count(C.byref(n))
+            if n.value > 0:
+                device %= n.value
+        h = C.c_void_p()
+        check(L.fpt_ctx_create(int(device), C.byref(h)))
+        self.L, self.h, self.device = L, h, int(device)
+        self._table_key = None
+        self._dm_slots = {}
+        self._dm_next = 0
+        self._lock = threading.RLock()
+
+    def close(self):
+        if self.h:
+            self.L.fpt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model state -----------------------------------------------------------------
+    def set_bias_table(self, table, dflt=1e-6):
+        table = f64(table)
+        if table.shape != (4096,):
+            raise ValueError("bias table must have 4096 entries")
+        key = (table.tobytes(), float(dflt))
+        with self._lock:
+            if key != self._table_key:
+                check(self.L.fpt_set_bias_table(self.h, ptr(table), float(dflt)))
+                self._table_key = key
+
+    def dispersion_slot(self, mu_params, r_params):
+        """Slot id holding this (mu_params, r_params); uploads on first use (LRU of 64 slots)."""
+        mu, r = f64(mu_params).ravel(), f64(r_params).ravel()
+        if mu.size != 9 or r.size != 15:
+            raise ValueError("mu_params needs 9 and r_params 15 values")
+        key = (mu.tobytes(), r.tobytes())
+        with self._lock:
+            slot = self._dm_slots.get(key)
+            if slot is None:
+                slot = self._dm_next % MAX_DM
+                self._dm_next += 1
+                for k in [k for k, v in self._dm_slots.items() if v == slot]:
+                    del self._dm_slots[k]
+                check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
+                self._dm_slots[key] = slot
+            return slot
+
+    def synchronize(self):
+        check(self.L.fpt_ctx_synchronize(self.h))
+
+
+_default = None
+
+
+def get_ctx():
+    """Process-wide default context (created on first use)."""
+    global _default
+    if _default is None:
+        with _lock:
+            if _default is None:
+                _default = Context()
+    return _default
+
+
+def gpu_available():
+    try:
+        n = C.c_int(0)
+        load().fpt_device_count(C.byref(n))
+        return n.value > 0
+    except (ImportError, OSError):
+        return False

@@ -1,0 +1,584 @@
+// fpt_capi.cpp -- the C ABI of include/fpt.h on top of the HIP kernels.
+// Host-side only: argument checking, device workspace, H2D/D2H staging for the
+// host-buffer entry points, tile tables and launch geometry for the fused scan.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fpt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(FPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+constexpr int kSlots = 10;
+constexpr int kModelDoubles = 24;
+
+}  // namespace
+
+struct fpt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    double *d_table = nullptr;   // 4097 doubles (slot 4096 = default)
+    double *d_models = nullptr;  // FPT_MAX_DISPERSION_MODELS * 24
+    int *d_flags = nullptr;      // error flags
+    unsigned long long *d_sum = nullptr;
+    bool have_table = false;
+    bool have_model[FPT_MAX_DISPERSION_MODELS] = {};
+    void *ws[kSlots] = {};
+    size_t ws_bytes[kSlots] = {};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int n_cu = 0;
+};
+
+namespace {
+
+int ws_get(fpt_ctx *c, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (c->ws_bytes[slot] < bytes) {
+        if (c->ws[slot]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipFree(c->ws[slot]));
+            c->ws[slot] = nullptr;
+            c->ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&c->ws[slot], want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&c->ws[slot], want);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FPT_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+        }
+        c->ws_bytes[slot] = want;
+    }
+    *out = c->ws[slot];
+    return FPT_OK;
+}
+
+int check_ctx(fpt_ctx *c) {
+    if (!c) return fail(FPT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return FPT_OK;
+}
+
+int launch_ok(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FPT_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return FPT_OK;
+}
+
+// `(int)((double)w * clip)` of smoothing.h:112
+int trim_k(int shw, double clip) {
+    int w = shw * 2 + 1;
+    return (int)((double)w * clip);
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *fpt_last_error(void) { return g_err.c_str(); }
+
+int fpt_version(void) { return 100; }
+
+int fpt_device_count(int *n_out) {
+    if (!n_out) return fail(FPT_ERR_INVALID, "null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *n_out = n;
+    return FPT_OK;
+}
+
+int fpt_ctx_create(int device_id, fpt_ctx **out) {
+    if (!out) return fail(FPT_ERR_INVALID, "null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(FPT_ERR_NODEVICE,
+                    "no HIP device visible: libfpt_hip has no CPU fallback (needs an MI355X / gfx950)");
+    }
+    if (device_id < 0 || device_id >= n)
+        return fail(FPT_ERR_INVALID, "device %d out of range (%d visible)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FPT_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    fpt_ctx *c = new fpt_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc(&c->d_table, (FPT_KMER_TABLE + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_models, FPT_MAX_DISPERSION_MODELS * kModelDoubles * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_flags, 16 * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->d_sum, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_flags, 0, 16 * sizeof(int)));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return FPT_OK;
+}
+
+int fpt_ctx_destroy(fpt_ctx *c) {
+    if (!c) return FPT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < kSlots; ++i)
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_models) (void)hipFree(c->d_models);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_sum) (void)hipFree(c->d_sum);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return FPT_OK;
+}
+
+int fpt_ctx_set_stream(fpt_ctx *c, void *hip_stream) {
+    if (int rc = check_ctx(c)) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return FPT_OK;
+}
+
+int fpt_ctx_synchronize(fpt_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_set_bias_table(fpt_ctx *c, const double *table4096, double dflt) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!table4096) return fail(FPT_ERR_INVALID, "null table");
+    std::vector<double> t(FPT_KMER_TABLE + 1);
+    std::memcpy(t.data(), table4096, FPT_KMER_TABLE * sizeof(double));
+    t[FPT_KMER_TABLE] = dflt;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_table, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->have_table = true;
+    return FPT_OK;
+}
+
+int fpt_set_dispersion(fpt_ctx *c, int dm_id, const double *mu9, const double *r15) {
+    if (int rc = check_ctx(c)) return rc;
+    if (dm_id < 0 || dm_id >= FPT_MAX_DISPERSION_MODELS)
+        return fail(FPT_ERR_INVALID, "dm_id %d out of range", dm_id);
+    if (!mu9 || !r15) return fail(FPT_ERR_INVALID, "null parameters");
+    double m[kModelDoubles];
+    std::memcpy(m, mu9, 9 * sizeof(double));
+    std::memcpy(m + 9, r15, 15 * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_models + (size_t)dm_id * kModelDoubles, m, sizeof m, hipMemcpyHostToDevice));
+    c->have_model[dm_id] = true;
+    return FPT_OK;
+}
+
+// ---------------------------------------------------------------- host-buffer entry points
+
+int fpt_kmer_probs(fpt_ctx *c, const uint8_t *seq, int64_t seq_len, double *fwd, double *rev) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->have_table) return fail(FPT_ERR_INVALID, "bias table not set");
+    if (seq_len < 0 || (!seq && seq_len > 0)) return fail(FPT_ERR_INVALID, "bad sequence");
+    int64_t n = seq_len - 6;
+    if (n <= 0) return FPT_OK;
+    void *d_seq, *d_f, *d_r;
+    if (int rc = ws_get(c, 0, (size_t)seq_len, &d_seq)) return rc;
+    if (int rc = ws_get(c, 1, (size_t)n * 8, &d_f)) return rc;
+    if (int rc = ws_get(c, 2, (size_t)n * 8, &d_r)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_seq, seq, (size_t)seq_len, hipMemcpyHostToDevice, c->stream));
+    fptk::launch_kmer_probs(c->stream, (const uint8_t *)d_seq, n, c->d_table, (double *)d_f,
+                            (double *)d_r);
+    if (int rc = launch_ok("k_kmer_probs")) return rc;
+    if (fwd) HIP_TRY(hipMemcpyAsync(fwd, d_f, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (rev) HIP_TRY(hipMemcpyAsync(rev, d_r, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_predict(fpt_ctx *c, const double *obs, const double *probs, int64_t n_rows, int l, int hw,
+                int shw, double clip, double *exp_out, double *win_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_rows < 0 || l < 0 || hw < 0 || shw < 0)
+        return fail(FPT_ERR_INVALID, "negative size / window");
+    if (shw > 4096) return fail(FPT_ERR_INVALID, "smoothing_half_win_width %d too large", shw);
+    size_t n = (size_t)n_rows * (size_t)l;
+    if (n == 0) return FPT_OK;
+    if (!obs || !probs || !exp_out || !win_out) return fail(FPT_ERR_INVALID, "null buffer");
+    int k = trim_k(shw, clip);
+    if (shw > 0 && (k < 0 || 2 * k >= 2 * shw + 1))
+        return fail(FPT_ERR_INVALID, "smoothing_clip %g trims the whole window", clip);
+    void *d_o, *d_p, *d_e, *d_w;
+    if (int rc = ws_get(c, 0, n * 8, &d_o)) return rc;
+    if (int rc = ws_get(c, 1, n * 8, &d_p)) return rc;
+    if (int rc = ws_get(c, 2, n * 8, &d_e)) return rc;
+    if (int rc = ws_get(c, 3, n * 8, &d_w)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_o, obs, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p, probs, n * 8, hipMemcpyHostToDevice, c->stream));
+    fptk::launch_predict_rows(c->stream, (const double *)d_o, (const double *)d_p, n_rows, l, hw, shw,
+                              k, (double *)d_e, (double *)d_w);
+    if (int rc = launch_ok("k_predict_rows")) return rc;
+    HIP_TRY(hipMemcpyAsync(exp_out, d_e, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(win_out, d_w, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_nb_values(fpt_ctx *c, int what, int dm_id, const double *ex, const double *ob, int64_t n,
+                  double *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (what < 0 || what > 2) return fail(FPT_ERR_INVALID, "bad `what` %d", what);
+    if (dm_id < 0 || dm_id >= FPT_MAX_DISPERSION_MODELS || !c->have_model[dm_id])
+        return fail(FPT_ERR_INVALID, "dispersion model %d not set", dm_id);
+    if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
+    if (n == 0) return FPT_OK;
+    if (!ex || !ob || !out) return fail(FPT_ERR_INVALID, "null buffer");
+    void *d_e, *d_o, *d_r;
+    if (int rc = ws_get(c, 0, (size_t)n * 8, &d_e)) return rc;
+    if (int rc = ws_get(c, 1, (size_t)n * 8, &d_o)) return rc;
+    if (int rc = ws_get(c, 2, (size_t)n * 8, &d_r)) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemcpyAsync(d_e, ex, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_o, ob, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    fptk::launch_nb_values(c->stream, what, c->d_models + (size_t)dm_id * kModelDoubles,
+                           (const double *)d_e, (const double *)d_o, n, (double *)d_r, c->d_flags);
+    if (int rc = launch_ok("k_nb_values")) return rc;
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(out, d_r, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag & 1) return fail(FPT_ERR_ZERODIV, "float division by zero in fit_r");
+    return FPT_OK;
+}
+
+int fpt_nb_scalar(fpt_ctx *c, int what, const int32_t *k, const double *p, const double *r, int64_t n,
+                  double *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (what < 0 || what > 2) return fail(FPT_ERR_INVALID, "bad `what` %d", what);
+    if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
+    if (n == 0) return FPT_OK;
+    if (!k || !p || !r || !out) return fail(FPT_ERR_INVALID, "null buffer");
+    void *d_k, *d_p, *d_r, *d_o;
+    if (int rc = ws_get(c, 0, (size_t)n * 4, &d_k)) return rc;
+    if (int rc = ws_get(c, 1, (size_t)n * 8, &d_p)) return rc;
+    if (int rc = ws_get(c, 2, (size_t)n * 8, &d_r)) return rc;
+    if (int rc = ws_get(c, 3, (size_t)n * 8, &d_o)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_k, k, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p, p, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_r, r, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    fptk::launch_nb_scalar(c->stream, what, (const int32_t *)d_k, (const double *)d_p,
+                           (const double *)d_r, n, (double *)d_o);
+    if (int rc = launch_ok("k_nb_scalar")) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_window(fpt_ctx *c, int op, const double *x, const double *w, int64_t n_rows, int n, int hw,
+               double *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (op < 0 || op > 4) return fail(FPT_ERR_INVALID, "bad window op %d", op);
+    if (n_rows < 0 || n < 0 || hw < 0) return fail(FPT_ERR_INVALID, "negative size / window");
+    if (hw > 2048) return fail(FPT_ERR_INVALID, "half window %d too large", hw);
+    size_t tot = (size_t)n_rows * (size_t)n;
+    if (tot == 0) return FPT_OK;
+    if (!x || !out || (op == FPT_WIN_WSTOUFFER && !w)) return fail(FPT_ERR_INVALID, "null buffer");
+    void *d_x, *d_w = nullptr, *d_o;
+    if (int rc = ws_get(c, 0, tot * 8, &d_x)) return rc;
+    if (int rc = ws_get(c, 1, tot * 8, &d_o)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_x, x, tot * 8, hipMemcpyHostToDevice, c->stream));
+    if (op == FPT_WIN_WSTOUFFER) {
+        if (int rc = ws_get(c, 2, tot * 8, &d_w)) return rc;
+        HIP_TRY(hipMemcpyAsync(d_w, w, tot * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    fptk::launch_window_rows(c->stream, op, (const double *)d_x, (const double *)d_w, n_rows, n, hw,
+                             (double *)d_o);
+    if (int rc = launch_ok("k_window_rows")) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_o, tot * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_special(fpt_ctx *c, int fn, const double *a, const double *b, const double *x, int64_t n,
+                double *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (fn < 0 || fn > 8) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
+    if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
+    if (n == 0) return FPT_OK;
+    if (!a || !out) return fail(FPT_ERR_INVALID, "null buffer");
+    if (fn == FPT_FN_INCBET && (!b || !x)) return fail(FPT_ERR_INVALID, "incbet needs a, b, x");
+    if (fn == FPT_FN_CHDTRC && !x) return fail(FPT_ERR_INVALID, "chdtrc needs df (a) and x");
+    void *d_a, *d_b, *d_x, *d_o;
+    if (int rc = ws_get(c, 0, (size_t)n * 8, &d_a)) return rc;
+    if (int rc = ws_get(c, 1, (size_t)n * 8, &d_b)) return rc;
+    if (int rc = ws_get(c, 2, (size_t)n * 8, &d_x)) return rc;
+    if (int rc = ws_get(c, 3, (size_t)n * 8, &d_o)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_a, a, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(d_b, b, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (x) HIP_TRY(hipMemcpyAsync(d_x, x, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    fptk::launch_special(c->stream, fn, (const double *)d_a, (const double *)d_b, (const double *)d_x, n,
+                         (double *)d_o);
+    if (int rc = launch_ok("k_special")) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+// ---------------------------------------------------------------- fused scan
+
+int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
+    if (!c->have_table) return fail(FPT_ERR_INVALID, "bias table not set");
+    if (d->dm_id < 0 || d->dm_id >= FPT_MAX_DISPERSION_MODELS || !c->have_model[d->dm_id])
+        return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id);
+    if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
+    if (d->n_intervals == 0) return FPT_OK;
+    const int hw = d->half_win_width, shw = d->smoothing_half_win_width;
+    if (hw < 0 || shw < 0 || hw > 64 || shw > 1024)
+        return fail(FPT_ERR_INVALID, "window widths out of range (hw=%d shw=%d)", hw, shw);
+    if (d->n_scales < 0 || d->n_scales > FPT_MAX_SCALES)
+        return fail(FPT_ERR_INVALID, "n_scales %d out of range", d->n_scales);
+    int H = 0;
+    for (int i = 0; i < d->n_scales; ++i) {
+        if (d->scales[i] < 0 || d->scales[i] > 200)
+            return fail(FPT_ERR_INVALID, "scale %d out of range", d->scales[i]);
+        H = std::max(H, d->scales[i]);
+    }
+    if (!d->counts_plus || !d->counts_minus || !d->seq) return fail(FPT_ERR_INVALID, "null input");
+    if (d->n_scales > 0 && !d->winp_out) return fail(FPT_ERR_INVALID, "winp_out is null");
+    const int k = trim_k(shw, d->smoothing_clip);
+    if (shw > 0 && (k < 0 || 2 * k >= 2 * shw + 1))
+        return fail(FPT_ERR_INVALID, "smoothing_clip %g trims the whole window", d->smoothing_clip);
+    const int pad = hw + shw;
+    const int split_len = 1024 - 2 * H;  // tile length inside intervals longer than a workgroup
+
+    fptk::scan_launch sl{};
+    sl.n_intervals = d->n_intervals;
+    sl.hw = hw;
+    sl.shw = shw;
+    sl.k_trim = k;
+    sl.n_scales = d->n_scales;
+    for (int i = 0; i < d->n_scales; ++i) sl.scales[i] = d->scales[i];
+    sl.counts_plus = d->counts_plus;
+    sl.counts_minus = d->counts_minus;
+    sl.seq = d->seq;
+    sl.table = c->d_table;
+    sl.model = c->d_models + (size_t)d->dm_id * kModelDoubles;
+    sl.exp_out = d->exp_out;
+    sl.obs_out = d->obs_out;
+    sl.pval_out = d->pval_out;
+    sl.winp_out = d->winp_out;
+    sl.status_out = d->status_out;
+
+    struct launch_t {
+        int nt;
+        int64_t first, count;
+        int tile_len;
+    };
+    std::vector<launch_t> launches;
+
+    auto nt_class = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : 1024); };
+
+    if (!d->interval_off) {
+        const int L = d->interval_len;
+        if (L <= 0) return fail(FPT_ERR_INVALID, "interval_len must be positive");
+        sl.interval_len = L;
+        sl.total_bases = d->n_intervals * (int64_t)L;
+        int tile_len = L <= 1024 ? L : split_len;
+        int tpi = (L + tile_len - 1) / tile_len;
+        sl.tiles_per_interval = tpi;
+        int nt_needed = tpi == 1 ? L : std::min(L, tile_len + 2 * H);
+        launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len});
+    } else {
+        // ragged batch: tile table binned by workgroup size
+        std::vector<int64_t> off_host;
+        const int64_t *off = d->interval_off_host;
+        if (!off) {
+            off_host.resize(d->n_intervals + 1);
+            HIP_TRY(hipMemcpyAsync(off_host.data(), d->interval_off,
+                                   (size_t)(d->n_intervals + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            off = off_host.data();
+        }
+        if (d->n_intervals > 0x7fffffff) return fail(FPT_ERR_INVALID, "too many intervals");
+        std::vector<int32_t> tiv[3], tt0[3], ttl[3];
+        for (int64_t i = 0; i < d->n_intervals; ++i) {
+            int64_t L64 = off[i + 1] - off[i];
+            if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
+            int L = (int)L64;
+            if (L == 0) continue;
+            if (L <= 1024) {
+                int cls = L <= 256 ? 0 : (L <= 512 ? 1 : 2);
+                tiv[cls].push_back((int32_t)i);
+                tt0[cls].push_back(0);
+                ttl[cls].push_back(L);
+            } else {
+                for (int t0 = 0; t0 < L; t0 += split_len) {
+                    int tl = std::min(split_len, L - t0);
+                    int ta = std::max(0, t0 - H), tb = std::min(L, t0 + tl + H);
+                    int n = tb - ta;
+                    int cls = n <= 256 ? 0 : (n <= 512 ? 1 : 2);
+                    tiv[cls].push_back((int32_t)i);
+                    tt0[cls].push_back(t0);
+                    ttl[cls].push_back(tl);
+                }
+            }
+        }
+        sl.total_bases = off[d->n_intervals];
+        sl.interval_off = d->interval_off;
+        std::vector<int32_t> flat;
+        int64_t n_tiles = (int64_t)(tiv[0].size() + tiv[1].size() + tiv[2].size());
+        flat.reserve((size_t)n_tiles * 3);
+        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
+        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
+        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
+        void *d_tiles;
+        if (int rc = ws_get(c, 9, flat.size() * 4, &d_tiles)) return rc;
+        if (!flat.empty())
+            HIP_TRY(hipMemcpyAsync(d_tiles, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
+        sl.tile_iv = (const int32_t *)d_tiles;
+        sl.tile_t0 = sl.tile_iv + n_tiles;
+        sl.tile_tl = sl.tile_t0 + n_tiles;
+        int64_t first = 0;
+        const int cls_nt[3] = {256, 512, 1024};
+        for (int cls = 0; cls < 3; ++cls) {
+            if (!tiv[cls].empty())
+                launches.push_back({cls_nt[cls], first, (int64_t)tiv[cls].size(), split_len});
+            first += (int64_t)tiv[cls].size();
+        }
+    }
+
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (const launch_t &ln : launches) {
+        fptk::scan_launch s2 = sl;
+        s2.tile_len = ln.tile_len;
+        s2.nc_max = ln.nt + 2 * pad + 1;
+        s2.tile_first = ln.first;
+        size_t lds = fptk::scan_lds_bytes(s2.nc_max);
+        if (lds > 160 * 1024)
+            return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
+        HIP_TRY(fptk::scan_set_lds(ln.nt, lds));
+        for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
+            int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
+            s2.tile_first = ln.first + done;
+            fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2);
+            if (int rc = launch_ok("k_scan_fused")) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return FPT_OK;
+}
+
+int fpt_last_scan_ms(fpt_ctx *c, float *ms_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!ms_out) return fail(FPT_ERR_INVALID, "null output");
+    if (!c->timed) return fail(FPT_ERR_INVALID, "no scan has been launched");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
+    return FPT_OK;
+}
+
+int fpt_synth_dev(fpt_ctx *c, uint64_t seed, int64_t pos0_counts, int64_t n_counts, double *cp,
+                  double *cm, int64_t pos0_seq, int64_t n_seq, uint8_t *seq) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_counts < 0 || n_seq < 0) return fail(FPT_ERR_INVALID, "negative length");
+    fptk::launch_synth(c->stream, seed, pos0_counts, n_counts, cp, cm, pos0_seq, n_seq, seq);
+    return launch_ok("k_synth");
+}
+
+int fpt_checksum_dev(fpt_ctx *c, const double *dev, int64_t n, uint64_t *host_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!host_out || n < 0 || (!dev && n > 0)) return fail(FPT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipMemsetAsync(c->d_sum, 0, sizeof(unsigned long long), c->stream));
+    fptk::launch_checksum(c->stream, dev, n, c->d_sum);
+    if (int rc = launch_ok("k_checksum")) return rc;
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->d_sum, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *host_out = (uint64_t)v;
+    return FPT_OK;
+}
+
+int fpt_dev_alloc(fpt_ctx *c, int64_t bytes, void **dev_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!dev_out || bytes < 0) return fail(FPT_ERR_INVALID, "bad arguments");
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes > 0 ? (size_t)bytes : 16);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FPT_ERR_NOMEM, "device allocation of %lld bytes failed", (long long)bytes);
+    }
+    *dev_out = p;
+    return FPT_OK;
+}
+
+int fpt_dev_free(fpt_ctx *c, void *dev) {
+    if (int rc = check_ctx(c)) return rc;
+    if (dev) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(dev));
+    }
+    return FPT_OK;
+}
+
+int fpt_memcpy_h2d(fpt_ctx *c, void *dev, const void *host, int64_t bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (bytes < 0 || ((!dev || !host) && bytes > 0)) return fail(FPT_ERR_INVALID, "bad arguments");
+    if (bytes == 0) return FPT_OK;
+    HIP_TRY(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+int fpt_memcpy_d2h(fpt_ctx *c, void *host, const void *dev, int64_t bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (bytes < 0 || ((!dev || !host) && bytes > 0)) return fail(FPT_ERR_INVALID, "bad arguments");
+    if (bytes == 0) return FPT_OK;
+    HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

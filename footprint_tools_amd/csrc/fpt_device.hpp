@@ -1,0 +1,155 @@
+// fpt_device.hpp -- device-side building blocks shared by the standalone kernels
+// and the fused scan kernel (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fpt_math.hpp"
+
+namespace fptd {
+
+constexpr int kWave = 64;
+constexpr int kTable = 4096;  // 6-mer table entries; slot kTable holds the default value
+
+// ---- 6-mer index (reference: modeling/bias.py:101-111, modeling/predict.pyx:47-61,150-153)
+
+// 2-bit code of an ASCII base, case-insensitive like str.upper() (predict.pyx:140); 4 = other.
+__device__ __forceinline__ int base_code(uint8_t ch) {
+    int u = ch & 0xDF;
+    return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+}
+
+// codes[0..6] are the codes of seq[j..j+6].  fwd = index of seq[j..j+5]; rev = index of
+// revcomp(seq[j+1..j+6]); an index of kTable means "unknown k-mer" (table slot with the default).
+__device__ __forceinline__ void kmer_indices(const uint8_t *codes, int &fwd, int &rev) {
+    int f = 0, r = 0, badf = 0, badr = 0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        int c = codes[m];
+        int d = codes[6 - m];
+        badf |= c >> 2;
+        badr |= d >> 2;
+        f = f * 4 + (c & 3);
+        r = r * 4 + (3 - (d & 3));
+    }
+    fwd = badf ? kTable : f;
+    rev = badr ? kTable : r;
+}
+
+// ---- trimmed mean of one smoothing window (reference: modeling/smoothing.h:59-104)
+//
+// The reference selects OS1 = sorted[k], OS2 = sorted[n-k-1] with quickselect and adds up
+// Beliakov-weighted elements; the value depends only on the multiset, so it is computed here
+// from order statistics and class sums.  `x` points at the n window values (LDS or global).
+
+struct trim_result {
+    double value;
+};
+
+// k == 1 (w=101, clip=0.01: the `detect` default): two smallest / two largest in one pass.
+__device__ __forceinline__ double trimmed_mean_k1(const double *x, int n) {
+#pragma clang fp contract(off)
+    double lo1 = fptm::kInf, lo2 = fptm::kInf, hi1 = -fptm::kInf, hi2 = -fptm::kInf, s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        s += v;
+        double a = fmin(lo1, v);
+        lo2 = fmin(lo2, fmax(lo1, v));
+        lo1 = a;
+        double b = fmax(hi1, v);
+        hi2 = fmax(hi2, fmin(hi1, v));
+        hi1 = b;
+    }
+    double t;
+    if (lo2 < hi2) {
+        // OS1 < OS2: sum of sorted[1 .. n-2]
+        t = (s - lo1) - hi1;
+    } else {
+        // OS1 == OS2 == c: only the OS1 weight is applied (smoothing.h:61-69), giving
+        // (b + bm - k) * c with b = #{== c}, bm = #{< c}
+        double c = lo2;
+        double cnt = (double)(n - 1) - ((hi1 > c) ? 1.0 : 0.0);
+        t = cnt * c;
+    }
+    return t / (double)(n - 2);
+}
+
+// general k >= 0: order statistics by walking distinct values from each end, then one
+// class-sum pass.  O(n * (k+1)) reads; only used for non-default clip values.
+__device__ __noinline__ double trimmed_mean_general(const double *x, int n, int k) {
+#pragma clang fp contract(off)
+    double os1 = 0.0, os2 = 0.0;
+    {
+        double cur = -fptm::kInf;
+        int cum = 0;
+        bool first = true;
+        for (;;) {
+            double m = fptm::kInf;
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) {
+                double v = x[i];
+                if (first || v > cur) {
+                    if (v < m) { m = v; cnt = 1; }
+                    else if (v == m) ++cnt;
+                }
+            }
+            first = false;
+            if (cnt == 0 || cum + cnt > k) { os1 = m; break; }
+            cum += cnt;
+            cur = m;
+        }
+    }
+    {
+        double cur = fptm::kInf;
+        int cum = 0;
+        bool first = true;
+        for (;;) {
+            double m = -fptm::kInf;
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) {
+                double v = x[i];
+                if (first || v < cur) {
+                    if (v > m) { m = v; cnt = 1; }
+                    else if (v == m) ++cnt;
+                }
+            }
+            first = false;
+            if (cnt == 0 || cum + cnt > k) { os2 = m; break; }
+            cum += cnt;
+            cur = m;
+        }
+    }
+    double b = 0, bm = 0, d = 0, dm = 0, mid = 0;
+    for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        if (v < os1) bm += 1; else if (v == os1) b += 1;
+        if (v < os2) dm += 1; else if (v == os2) d += 1;
+        if (v < os2 && v > os1) mid += v;
+    }
+    double w1 = (b + bm - (double)k) / b;
+    double w2 = ((double)(n - k) - dm) / d;
+    double t = mid + b * (w1 * os1);
+    if (os1 < os2) t += d * (w2 * os2);
+    return t / (double)(n - 2 * k);
+}
+
+__device__ __forceinline__ double trimmed_mean(const double *x, int n, int k) {
+    if (k == 1) return trimmed_mean_k1(x, n);
+    return trimmed_mean_general(x, n, k);
+}
+
+// ---- wave64 inclusive prefix sum (double + int) with __shfl_up
+__device__ __forceinline__ void wave_scan(double &v, int &c, int lane) {
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        double pv = __shfl_up(v, d, kWave);
+        int pc = __shfl_up(c, d, kWave);
+        if (lane >= d) {
+            v += pv;
+            c += pc;
+        }
+    }
+}
+
+}  // namespace fptd

@@ -1,0 +1,636 @@
+// fpt_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) of the footprint scan.
+//
+// Kernels
+//   k_kmer_probs      6-mer bias lookup, table staged in LDS            (bias.py / predict.pyx)
+//   k_predict_rows    window sums + trimmed-mean smoothing + expected   (predict.h / smoothing.h)
+//   k_nb_values       per-base NB cdf / logpmf / pmf                    (dispersion.pyx / nbinom.pyx)
+//   k_nb_scalar       nbinom.{cdf,logpmf,pmf}(k,p,r)
+//   k_window_rows     sliding-window reducers                           (windowing.h)
+//   k_special         element-wise special functions (diagnostics)
+//   k_scan_fused<NT>  the whole per-interval path in one pass           (cli/detect.py:120-130)
+//   k_synth, k_checksum  synthetic workload + parity checksum
+//
+// Reference citations are paths under vierstralab/footprint-tools v1.3.7.
+#include "fpt_kernels.hpp"
+
+#include "fpt_device.hpp"
+
+using namespace fptd;
+
+// ===========================================================================
+// k_kmer_probs
+// ===========================================================================
+__global__ void __launch_bounds__(256) k_kmer_probs(const uint8_t *__restrict__ seq, int64_t n_out,
+                                                    const double *__restrict__ table,
+                                                    double *__restrict__ fwd,
+                                                    double *__restrict__ rev) {
+    __shared__ double tbl[kTable + 1];
+    for (int i = threadIdx.x; i <= kTable; i += blockDim.x) tbl[i] = table[i];
+    __syncthreads();
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += stride) {
+        uint8_t codes[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) codes[m] = (uint8_t)base_code(seq[j + m]);
+        int fi, ri;
+        kmer_indices(codes, fi, ri);
+        if (fwd) fwd[j] = tbl[fi];
+        if (rev) rev[j] = tbl[ri];
+    }
+}
+
+// ===========================================================================
+// k_predict_rows: one block = one tile of TL output positions of one row.
+//   W[u]  = sum_{j=-hw}^{hw-1} obs[u+j]   u in [hw, l-hw), else 0       predict.h:41-48
+//   W'[u] = trimmed mean of W[u-shw..u+shw], u in [shw, l-shw), else 0  smoothing.h:107-133
+//   E[u]  = round(probs[u]/Q[u] * W'[u]),   u in [hw, l-hw), else 0     predict.h:60-63
+// ===========================================================================
+__global__ void __launch_bounds__(256) k_predict_rows(const double *__restrict__ obs,
+                                                      const double *__restrict__ probs, int l,
+                                                      int hw, int shw, int k_trim, int tile_len,
+                                                      double *__restrict__ exp_out,
+                                                      double *__restrict__ win_out) {
+    extern __shared__ double s_w[];  // tile_len + 2*shw window sums
+    const int64_t row = blockIdx.y;
+    const double *o = obs + row * (int64_t)l;
+    const double *p = probs + row * (int64_t)l;
+    const int i0 = blockIdx.x * tile_len;
+    const int nw = tile_len + 2 * shw;
+    for (int v = threadIdx.x; v < nw; v += blockDim.x) {
+        int u = i0 - shw + v;
+        double acc = 0.0;
+        if (u >= hw && u < l - hw)
+            for (int j = -hw; j < hw; ++j) acc += o[u + j];
+        s_w[v] = acc;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < tile_len; v += blockDim.x) {
+        int u = i0 + v;
+        if (u >= l) break;
+        double ws;
+        if (shw > 0)
+            ws = (u >= shw && u < l - shw) ? trimmed_mean(&s_w[v], 2 * shw + 1, k_trim) : 0.0;
+        else
+            ws = s_w[v];
+        double e = 0.0;
+        if (u >= hw && u < l - hw) {
+            double q = 0.0;
+            for (int j = -hw; j < hw; ++j) q += p[u + j];
+            e = round((p[u] / q) * ws);
+        }
+        exp_out[row * (int64_t)l + u] = e;
+        win_out[row * (int64_t)l + u] = ws;
+    }
+}
+
+// ===========================================================================
+// k_nb_values / k_nb_scalar / k_special
+// ===========================================================================
+__global__ void __launch_bounds__(256, 4) k_nb_values(int what, const double *__restrict__ model,
+                                                   const double *__restrict__ ex,
+                                                   const double *__restrict__ ob, int64_t n,
+                                                   double *__restrict__ out, int *__restrict__ flags) {
+    __shared__ double par[24];
+    if (threadIdx.x < 24) par[threadIdx.x] = model[threadIdx.x];
+    __syncthreads();
+    // one element per thread: a grid-stride loop around incbet makes LICM hoist every
+    // polynomial coefficient into registers (VGPRs 118 -> 200+)
+    bool zd = false;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double e = ex[i];
+        double r = fptm::fit_r(par + 9, e, &zd);
+        double mu = fptm::fit_mu(par, e);
+        int32_t k = fptm::c_int(ob[i]);
+        double pp = r / (r + mu);
+        double v;
+        if (what == 0) v = fptm::nb_cdf(k, pp, r);
+        else {
+            v = fptm::nb_logpmf(k, pp, r);
+            if (what == 2) v = exp(v);
+        }
+        out[i] = v;
+    }
+    if (zd) atomicOr(flags, 1);
+}
+
+__global__ void __launch_bounds__(256, 4) k_nb_scalar(int what, const int32_t *__restrict__ k,
+                                                   const double *__restrict__ p,
+                                                   const double *__restrict__ r, int64_t n,
+                                                   double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double v;
+        if (what == 0) v = fptm::nb_cdf(k[i], p[i], r[i]);
+        else {
+            v = fptm::nb_logpmf(k[i], p[i], r[i]);
+            if (what == 2) v = exp(v);
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_special(int fn, const double *__restrict__ a,
+                                                 const double *__restrict__ b,
+                                                 const double *__restrict__ x, int64_t n,
+                                                 double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double v = a[i], res;
+        switch (fn) {
+        case 0: res = fptm::gamma_fn(v); break;
+        case 1: res = fptm::lgam(v); break;
+        case 2: res = fptm::ndtr(v); break;
+        case 3: res = fptm::ndtri(v); break;
+        case 4: res = fptm::log1p_fn(v); break;
+        case 5: res = fptm::erf_fn(v); break;
+        case 6: res = fptm::erfc_fn(v); break;
+        case 7: res = fptm::incbet(v, b[i], x[i]); break;
+        default: res = fptm::chdtrc(v, x[i]); break;
+        }
+        out[i] = res;
+    }
+}
+
+// ===========================================================================
+// k_window_rows: out[i] = f(x[i-hw..i+hw]), i in [hw, n-hw); 1.0 elsewhere.
+// The per-element transform (ndtri(1-x), log x) is evaluated once per element into LDS
+// (the reference re-evaluates it for every window), then each output sums its window
+// left to right like windowing.h:11-67 does.
+// ===========================================================================
+__global__ void __launch_bounds__(256) k_window_rows(int op, const double *__restrict__ x,
+                                                     const double *__restrict__ w, int n, int hw,
+                                                     int tile_len, double *__restrict__ out) {
+    extern __shared__ double s_t[];  // [tile_len + 2*hw] (+ same again for weights^2)
+    const int64_t row = blockIdx.y;
+    const double *xr = x + row * (int64_t)n;
+    const double *wr = w ? w + row * (int64_t)n : nullptr;
+    const int i0 = blockIdx.x * tile_len;
+    const int nt = tile_len + 2 * hw;
+    double *s_w2 = s_t + nt;
+    for (int v = threadIdx.x; v < nt; v += blockDim.x) {
+        int i = i0 - hw + v;
+        double t = 0.0, w2 = 0.0;
+        if (i >= 0 && i < n) {
+            double xv = xr[i];
+            switch (op) {
+            case 0: case 1: t = xv; break;
+            case 2: t = log(xv); break;
+            case 3: t = fptm::ndtri(1.0 - xv); break;
+            default: {
+                double wv = wr[i];
+                t = wv * fptm::ndtri(1.0 - xv);
+                w2 = wv * wv;
+            }
+            }
+        }
+        s_t[v] = t;
+        if (op == 4) s_w2[v] = w2;
+    }
+    __syncthreads();
+    const int k = 2 * hw + 1;
+    for (int v = threadIdx.x; v < tile_len; v += blockDim.x) {
+        int i = i0 + v;
+        if (i >= n) break;
+        double res = 1.0;
+        if (i >= hw && i < n - hw) {
+            const double *win = &s_t[v];
+            if (op == 1) {
+                double pr = 1.0;
+                for (int j = 0; j < k; ++j) pr *= win[j];
+                res = pr;
+            } else {
+                double s = 0.0;
+                for (int j = 0; j < k; ++j) s += win[j];
+                if (op == 0) res = s;
+                else if (op == 2) res = fptm::chdtrc(2.0 * (double)k, s * -2.0);
+                else if (op == 3) res = fptm::ndtr(-(s / sqrt((double)k)));
+                else {
+                    double sw = 0.0;
+                    for (int j = 0; j < k; ++j) sw += s_w2[v + j];
+                    res = fptm::ndtr(-(s / sqrt(sw)));
+                }
+            }
+        }
+        out[row * (int64_t)n + i] = res;
+    }
+}
+
+// ===========================================================================
+// k_scan_fused: the whole path for one tile of one interval per workgroup.
+//
+// A tile is `tl` consecutive output bases [t0, t0+tl) of interval iv.  With
+// pad = hw+shw and H = the largest Stouffer half-width, the block stages into LDS
+//   counts +/-            padded positions u in [ta, tb+2*pad+1)        (ta = max(0,t0-H),
+//   sequence codes        u in [ta, tb+2*pad+7)                          tb = min(L,t0+tl+H))
+// and runs, separated by workgroup barriers,
+//   B  6-mer lookup from the LDS table, 2*hw-wide window sums of the counts, strand-merged obs
+//   C  trimmed-mean smoothing, window sum of the propensities, expected = round(P/Q*W')
+//   D  strand merge, NB lower-tail p-value, z = ndtri(1-p)      (one base per thread)
+//   E  block-wide prefix scan of z (wave64 __shfl_up + LDS carries) and per-scale
+//      Stouffer windows from prefix differences
+// One tile per workgroup and one base per thread in D on purpose: any loop around the
+// incbet body makes the compiler hoist its ~150 fp64 coefficients into registers.
+// The hardware workgroup dispatcher balances ragged tiles.
+//
+// LDS (doubles unless noted): table[4098] par[24] carry[64] | cE+[nc] cE-[nc] P+[nc] P-[nc]
+//   W+[nc] W-[nc] obs[nc] | codes u8[nc+8];  expected counts overwrite the counts (dead after
+//   B), z / non-finite prefix arrays overwrite the window sums (dead after C).
+// ===========================================================================
+struct scan_args {
+    int64_t n_intervals;
+    int32_t interval_len;        // uniform mode when interval_off == nullptr
+    const int64_t *interval_off; // ragged: output offsets
+    const int32_t *tile_iv;      // ragged: tile table
+    const int32_t *tile_t0;
+    const int32_t *tile_tl;
+    int64_t tile_first;          // first tile of this launch
+    int32_t tiles_per_interval;  // uniform mode
+    int32_t tile_len;
+    int32_t hw, shw, k_trim;
+    int32_t n_scales;
+    int32_t scales[FPT_MAX_SCALES];
+    double scale_sqrt[FPT_MAX_SCALES];
+    int32_t max_scale;
+    int32_t nc_max;              // LDS capacity per array (padded positions)
+    int64_t total_bases;
+    const double *counts_plus;
+    const double *counts_minus;
+    const uint8_t *seq;
+    const double *table;         // kTable + 1
+    const double *model;         // 24 doubles
+    double *exp_out, *obs_out, *pval_out, *winp_out;
+    int32_t *status_out;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_scan_fused(const scan_args a) {
+    extern __shared__ double smem[];
+    double *tbl = smem;                       // kTable + 1 (+1 pad to keep 16-B alignment)
+    double *par = tbl + (kTable + 2);         // 24
+    double *wsum = par + 24;                  // wave totals / carries of the scan
+    double *cP = wsum + 64;                   // counts '+', later expected '+'
+    double *cM = cP + a.nc_max;
+    double *pP = cM + a.nc_max;
+    double *pM = pP + a.nc_max;
+    double *wP = pM + a.nc_max;               // window sums, later z prefix
+    double *wM = wP + a.nc_max;               // window sums, later non-finite prefix (int)
+    double *obsm = wM + a.nc_max;             // strand-merged observed counts
+    uint8_t *sq = reinterpret_cast<uint8_t *>(obsm + a.nc_max);  // nc_max + 8 bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    constexpr int NW = NT / kWave;
+
+    const int hw = a.hw, shw = a.shw, pad = hw + shw;
+    const int H = a.max_scale;
+    const int64_t tile = a.tile_first + blockIdx.x;
+
+    int64_t iv;
+    int t0, L, tl;
+    int64_t out_off;
+    if (a.interval_off) {
+        iv = a.tile_iv[tile];
+        t0 = a.tile_t0[tile];
+        tl = a.tile_tl[tile];
+        out_off = a.interval_off[iv];
+        L = (int)(a.interval_off[iv + 1] - out_off);
+    } else {
+        iv = tile / a.tiles_per_interval;
+        t0 = (int)(tile % a.tiles_per_interval) * a.tile_len;
+        L = a.interval_len;
+        out_off = iv * (int64_t)L;
+        tl = min(a.tile_len, L - t0);
+    }
+    const int ta = max(0, t0 - H);
+    const int tb = min(L, t0 + tl + H);
+    const int nt = tb - ta;              // positions needing p / z   (<= NT by construction)
+    const int nc = nt + 2 * pad + 1;     // padded positions staged   (<= nc_max)
+    const int64_t cbase = out_off + iv * (int64_t)(2 * pad + 1) + ta;
+    const int64_t sbase = out_off + iv * (int64_t)(2 * pad + 7) + ta;
+
+    // ---- A: stage table, model, counts and sequence codes
+    for (int i = tid; i <= kTable; i += NT) tbl[i] = a.table[i];
+    if (tid < 24) par[tid] = a.model[tid];
+    for (int v = tid; v < nc; v += NT) {
+        cP[v] = a.counts_plus[cbase + v];
+        cM[v] = a.counts_minus[cbase + v];
+    }
+    for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
+    __syncthreads();
+
+    // ---- B: bias lookup (bias.py:101-111), count window sums (predict.h:41-48),
+    //         strand merge of the observed counts (detect.py:121)
+    for (int v = tid; v < nc; v += NT) {
+        int fi, ri;
+        kmer_indices(sq + v, fi, ri);
+        pP[v] = tbl[fi];
+        pM[v] = tbl[ri];
+        double sp = 0.0, sm = 0.0;
+        if (v >= hw && v < nc - hw) {
+            for (int j = -hw; j < hw; ++j) {
+                sp += cP[v + j];
+                sm += cM[v + j];
+            }
+        }
+        wP[v] = sp;
+        wM[v] = sm;
+        if (v < nt) obsm[v] = cP[pad + 1 + v] + cM[pad + v];
+    }
+    __syncthreads();
+
+    // ---- C: smoothing (smoothing.h:107-133) + expected counts (predict.h:60-63);
+    //         E overwrites the counts, which nobody reads any more
+    {
+        const int ne = nt + 1;  // padded positions [pad, nc-pad) per strand
+        for (int idx = tid; idx < 2 * ne; idx += NT) {
+            const bool minus = idx >= ne;
+            const int v = pad + (minus ? idx - ne : idx);
+            const double *ws = minus ? wM : wP;
+            const double *ps = minus ? pM : pP;
+            double wsm = (shw > 0) ? trimmed_mean(ws + v - shw, 2 * shw + 1, a.k_trim) : ws[v];
+            double q = 0.0;
+            for (int j = -hw; j < hw; ++j) q += ps[v + j];
+            double e = round((ps[v] / q) * wsm);
+            (minus ? cM : cP)[v] = e;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: expected merge (detect.py:122), p-value (dispersion.pyx:311-314), z = ndtri(1-p)
+    double *zb = wP;  // window sums are dead now
+    int *nf = reinterpret_cast<int *>(wM);
+    double zv = 0.0;
+    int zc = 0;
+    if (tid < nt) {
+        const int tp = tid;
+        bool zd = false;
+        double ob = obsm[tp];
+        double ex = cP[pad + 1 + tp] + cM[pad + tp];
+        double r = fptm::fit_r(par + 9, ex, &zd);
+        double mu = fptm::fit_mu(par, ex);
+        double pv = fptm::nb_cdf(fptm::c_int(ob), r / (r + mu), r);
+        double z = fptm::ndtri(1.0 - pv);
+        bool fin = isfinite(z);
+        zv = fin ? z : 0.0;
+        zc = fin ? 0 : 1;
+        int t = ta + tp;
+        if (t >= t0 && t < t0 + tl) {
+            int64_t g = out_off + t;
+            if (a.exp_out) a.exp_out[g] = ex;
+            if (a.obs_out) a.obs_out[g] = ob;
+            if (a.pval_out) a.pval_out[g] = pv;
+        }
+        if (zd && a.status_out) atomicOr(&a.status_out[iv], 1);
+    }
+    if (a.n_scales == 0) return;
+
+    // ---- E: inclusive prefix scan of (z, non-finite count) over [0, nt), nt <= NT
+    wave_scan(zv, zc, lane);
+    __syncthreads();  // everyone is done reading W before the prefix arrays overwrite it
+    if (lane == kWave - 1) {
+        wsum[wave] = zv;
+        wsum[32 + wave] = (double)zc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double tv = (lane < NW) ? wsum[lane] : 0.0;
+        int tc = (lane < NW) ? (int)wsum[32 + lane] : 0;
+        wave_scan(tv, tc, lane);
+        if (lane < NW) {
+            wsum[lane] = tv;
+            wsum[32 + lane] = (double)tc;
+        }
+    }
+    __syncthreads();
+    if (tid < nt) {
+        zb[tid] = zv + (wave > 0 ? wsum[wave - 1] : 0.0);
+        nf[tid] = zc + (wave > 0 ? (int)wsum[32 + wave - 1] : 0);
+    }
+    __syncthreads();
+
+    // ---- Stouffer windows (windowing.h:53-84; edges 1.0: windowing.pyx:51)
+    for (int s = 0; s < a.n_scales; ++s) {
+        const int hs = a.scales[s];
+        const double rk = a.scale_sqrt[s];
+        double *dst = a.winp_out + (int64_t)s * a.total_bases + out_off;
+        for (int v = tid; v < tl; v += NT) {
+            int t = t0 + v;
+            double res = 1.0;
+            if (t >= hs && t < L - hs) {
+                int hi = t - ta + hs;
+                int lo = t - ta - hs - 1;
+                double sv = zb[hi];
+                int sc = nf[hi];
+                if (lo >= 0) {
+                    sv -= zb[lo];
+                    sc -= nf[lo];
+                }
+                res = (sc > 0) ? NAN : fptm::ndtr(-(sv / rk));
+            }
+            dst[t] = res;
+        }
+    }
+}
+
+template __global__ void k_scan_fused<256>(const scan_args);
+template __global__ void k_scan_fused<512>(const scan_args);
+template __global__ void k_scan_fused<1024>(const scan_args);
+
+// ===========================================================================
+// synthetic workload + checksum
+// ===========================================================================
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_synth_counts(uint64_t key, int64_t pos0, int64_t n,
+                                                      double *__restrict__ out) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = splitmix64(key + (uint64_t)(pos0 + i));
+        out[i] = (double)((h >> 33) % 20u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_synth_bases(uint64_t key, int64_t pos0, int64_t n,
+                                                     uint8_t *__restrict__ out) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = splitmix64(key + (uint64_t)(pos0 + i));
+        const uint32_t acgt = 0x54474341u;  // "ACGT" little endian
+        out[i] = (uint8_t)(acgt >> (8 * ((h >> 13) & 3u)));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_checksum(const double *__restrict__ x, int64_t n,
+                                                  unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        acc += (unsigned long long)__double_as_longlong(x[i]);
+    for (int d = kWave / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, acc);
+}
+
+// ===========================================================================
+// launchers (called from fpt_capi.cpp through fpt_kernels.hpp)
+// ===========================================================================
+namespace fptk {
+
+static inline int grid_for(int64_t n, int block, int cap) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
+                       double *fwd, double *rev) {
+    if (n_out <= 0) return;
+    hipLaunchKernelGGL(k_kmer_probs, dim3(grid_for(n_out, 256, 2048)), dim3(256), 0, st, seq, n_out,
+                       table, fwd, rev);
+}
+
+void launch_predict_rows(hipStream_t st, const double *obs, const double *probs, int64_t n_rows,
+                         int l, int hw, int shw, int k_trim, double *exp_out, double *win_out) {
+    if (n_rows <= 0 || l <= 0) return;
+    const int tile_len = 1024;
+    int tiles = (l + tile_len - 1) / tile_len;
+    size_t lds = (size_t)(tile_len + 2 * shw) * sizeof(double);
+    // grid.y is limited to 65535: loop over row chunks
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+        int64_t nr = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+        hipLaunchKernelGGL(k_predict_rows, dim3(tiles, (unsigned)nr), dim3(256), lds, st,
+                           obs + r0 * l, probs + r0 * l, l, hw, shw, k_trim, tile_len,
+                           exp_out + r0 * l, win_out + r0 * l);
+    }
+}
+
+void launch_nb_values(hipStream_t st, int what, const double *model, const double *ex,
+                      const double *ob, int64_t n, double *out, int *flags) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_nb_values, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, what, model,
+                       ex, ob, n, out, flags);
+}
+
+void launch_nb_scalar(hipStream_t st, int what, const int32_t *k, const double *p, const double *r,
+                      int64_t n, double *out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_nb_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, what, k, p,
+                       r, n, out);
+}
+
+void launch_special(hipStream_t st, int fn, const double *a, const double *b, const double *x,
+                    int64_t n, double *out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, x,
+                       n, out);
+}
+
+void launch_window_rows(hipStream_t st, int op, const double *x, const double *w, int64_t n_rows,
+                        int n, int hw, double *out) {
+    if (n_rows <= 0 || n <= 0) return;
+    const int tile_len = 1024;
+    int tiles = (n + tile_len - 1) / tile_len;
+    size_t lds = (size_t)(tile_len + 2 * hw) * sizeof(double) * (op == 4 ? 2 : 1);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+        int64_t nr = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+        hipLaunchKernelGGL(k_window_rows, dim3(tiles, (unsigned)nr), dim3(256), lds, st, op,
+                           x + r0 * n, w ? w + r0 * n : nullptr, n, hw, tile_len, out + r0 * n);
+    }
+}
+
+size_t scan_lds_bytes(int nc_max) {
+    return (size_t)(kTable + 2 + 24 + 64 + 7 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
+}
+
+hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu) {
+    switch (nt) {
+    case 256: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<256>, 256, lds);
+    case 512: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<512>, 512, lds);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<1024>, 1024, lds);
+    }
+}
+
+hipError_t scan_set_lds(int nt, size_t lds) {
+    switch (nt) {
+    case 256: return hipFuncSetAttribute((const void *)k_scan_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    case 512: return hipFuncSetAttribute((const void *)k_scan_fused<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    default: return hipFuncSetAttribute((const void *)k_scan_fused<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+}
+
+void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl) {
+    scan_args a;
+    a.n_intervals = sl.n_intervals;
+    a.interval_len = sl.interval_len;
+    a.interval_off = sl.interval_off;
+    a.tile_iv = sl.tile_iv;
+    a.tile_t0 = sl.tile_t0;
+    a.tile_tl = sl.tile_tl;
+    a.tile_first = sl.tile_first;
+    a.tiles_per_interval = sl.tiles_per_interval;
+    a.tile_len = sl.tile_len;
+    a.hw = sl.hw;
+    a.shw = sl.shw;
+    a.k_trim = sl.k_trim;
+    a.n_scales = sl.n_scales;
+    a.max_scale = 0;
+    for (int i = 0; i < FPT_MAX_SCALES; ++i) {
+        a.scales[i] = i < sl.n_scales ? sl.scales[i] : 0;
+        a.scale_sqrt[i] = i < sl.n_scales ? sqrt((double)(2 * sl.scales[i] + 1)) : 1.0;
+        if (i < sl.n_scales && sl.scales[i] > a.max_scale) a.max_scale = sl.scales[i];
+    }
+    a.nc_max = sl.nc_max;
+    a.total_bases = sl.total_bases;
+    a.counts_plus = sl.counts_plus;
+    a.counts_minus = sl.counts_minus;
+    a.seq = sl.seq;
+    a.table = sl.table;
+    a.model = sl.model;
+    a.exp_out = sl.exp_out;
+    a.obs_out = sl.obs_out;
+    a.pval_out = sl.pval_out;
+    a.winp_out = sl.winp_out;
+    a.status_out = sl.status_out;
+    switch (nt) {
+    case 256: hipLaunchKernelGGL(k_scan_fused<256>, dim3(grid), dim3(256), lds, st, a); break;
+    case 512: hipLaunchKernelGGL(k_scan_fused<512>, dim3(grid), dim3(512), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_scan_fused<1024>, dim3(grid), dim3(1024), lds, st, a); break;
+    }
+}
+
+void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
+                  double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
+                  uint8_t *seq) {
+    // host-side splitmix64 of (seed + stream) gives the per-stream key
+    auto mix = [](uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    if (counts_plus && n_counts > 0)
+        hipLaunchKernelGGL(k_synth_counts, dim3(grid_for(n_counts, 256, 4096)), dim3(256), 0, st,
+                           mix(seed + 0), pos0_counts, n_counts, counts_plus);
+    if (counts_minus && n_counts > 0)
+        hipLaunchKernelGGL(k_synth_counts, dim3(grid_for(n_counts, 256, 4096)), dim3(256), 0, st,
+                           mix(seed + 1), pos0_counts, n_counts, counts_minus);
+    if (seq && n_seq > 0)
+        hipLaunchKernelGGL(k_synth_bases, dim3(grid_for(n_seq, 256, 4096)), dim3(256), 0, st,
+                           mix(seed + 2), pos0_seq, n_seq, seq);
+}
+
+void launch_checksum(hipStream_t st, const double *x, int64_t n, unsigned long long *out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_checksum, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, x, n, out);
+}
+
+}  // namespace fptk

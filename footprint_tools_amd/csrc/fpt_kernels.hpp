@@ -1,0 +1,55 @@
+// fpt_kernels.hpp -- host-visible launch interface of fpt_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fpt.h"
+
+namespace fptk {
+
+struct scan_launch {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    const int32_t *tile_iv;
+    const int32_t *tile_t0;
+    const int32_t *tile_tl;
+    int64_t tile_first;
+    int32_t tiles_per_interval;
+    int32_t tile_len;
+    int32_t hw, shw, k_trim;
+    int32_t n_scales;
+    int32_t scales[FPT_MAX_SCALES];
+    int32_t nc_max;
+    int64_t total_bases;
+    const double *counts_plus, *counts_minus;
+    const uint8_t *seq;
+    const double *table;
+    const double *model;
+    double *exp_out, *obs_out, *pval_out, *winp_out;
+    int32_t *status_out;
+};
+
+void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
+                       double *fwd, double *rev);
+void launch_predict_rows(hipStream_t st, const double *obs, const double *probs, int64_t n_rows,
+                         int l, int hw, int shw, int k_trim, double *exp_out, double *win_out);
+void launch_nb_values(hipStream_t st, int what, const double *model, const double *ex,
+                      const double *ob, int64_t n, double *out, int *flags);
+void launch_nb_scalar(hipStream_t st, int what, const int32_t *k, const double *p, const double *r,
+                      int64_t n, double *out);
+void launch_special(hipStream_t st, int fn, const double *a, const double *b, const double *x,
+                    int64_t n, double *out);
+void launch_window_rows(hipStream_t st, int op, const double *x, const double *w, int64_t n_rows,
+                        int n, int hw, double *out);
+size_t scan_lds_bytes(int nc_max);
+hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu);
+hipError_t scan_set_lds(int nt, size_t lds);
+void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl);
+void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
+                  double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
+                  uint8_t *seq);
+void launch_checksum(hipStream_t st, const double *x, int64_t n, unsigned long long *out);
+
+}  // namespace fptk

@@ -1,0 +1,125 @@
+"""Sequence-bias models.  Mirrors footprint_tools/modeling/bias.py (v1.3.7); the per-base
+lookup runs on the GPU from a 4096-entry table staged in LDS."""
+import itertools
+import random
+
+import numpy as np
+
+from .. import _lib
+
+_ACGT = "ACGT"
+_CODE = {c: i for i, c in enumerate(_ACGT)}
+
+
+def kmer_index(kmer):
+    """2-bit index of an ACGT 6-mer (first base most significant); None if not indexable."""
+    if len(kmer) != 6:
+        return None
+    idx = 0
+    for ch in kmer:
+        c = _CODE.get(ch)
+        if c is None:
+            return None
+        idx = idx * 4 + c
+    return idx
+
+
+class bias_model(object):
+    """reference: bias.py:9-58"""
+
+    default = 1e-6  # bias.py:17
+
+    def __init__(self):
+        self.model = {}
+        self.k = 6
+        self.mid = 3
+
+    def __getitem__(self, key):
+        return self.model.get(key, self.default)
+
+    def __setitem__(self, key, value):
+        self.model[key] = value
+
+    def offset(self):
+        return max(self.k - self.mid, self.mid)
+
+    def shuffle(self):
+        """Randomly shuffle the bias model (bias.py:25-43)"""
+        ret = bias_model()
+        ret.model = {
+            x: y
+            for (x, y) in zip(list(self.model.keys()),
+                              sorted(list(self.model.values()), key=lambda k: random.random()))
+        }
+        ret.offset = self.offset
+        return ret
+
+    def predict(self, probs, n=100):
+        return np.around(probs / np.sum(probs) * n)
+
+    # ---- device table ------------------------------------------------------------------
+    def table(self):
+        """4096 propensities in 2-bit order; k-mers absent from the model get the default."""
+        t = np.full(4096, self.default, dtype=np.float64)
+        for kmer, val in self.model.items():
+            idx = kmer_index(kmer)
+            if idx is not None:
+                t[idx] = val
+        return t
+
+    def probs_both(self, seq, ctx=None):
+        """(forward, reverse) propensities as prediction.compute uses them
+        (predict.pyx:150-153): fwd[j] = model[seq[j:j+6]], rev[j] = model[revcomp(seq[j+1:j+7])]."""
+        ctx = ctx or _lib.get_ctx()
+        ctx.set_bias_table(self.table(), self.default)
+        if isinstance(seq, str):
+            seq = seq.encode("ascii", "replace")
+        s = np.frombuffer(bytes(seq), dtype=np.uint8)
+        n = max(s.size - 6, 0)
+        fwd, rev = np.empty(n), np.empty(n)
+        _lib.check(ctx.L.fpt_kmer_probs(ctx.h, _lib.ptr(s), s.size, _lib.ptr(fwd), _lib.ptr(rev)))
+        return fwd, rev
+
+    def probs(self, seq):
+        """Cleavage preference array from a DNA sequence (bias.py:88-111): len(seq)-6 values."""
+        return self.probs_both(seq)[0]
+
+
+class kmer_model(bias_model):
+    """reference: bias.py:58-111"""
+
+    def __init__(self, filepath):
+        bias_model.__init__(self)
+        self.read_model(filepath)
+
+    def read_model(self, filepath):
+        import urllib.request as request
+
+        try:
+            if filepath.startswith("http"):
+                file = request.urlopen(filepath)
+            else:
+                file = open(filepath, "r")
+            for line in file:
+                if isinstance(line, bytes):
+                    line = line.decode()
+                (seq, prob) = line.strip().split("\t")
+                self.model[seq.upper()] = float(prob)
+        except IOError:
+            raise IOError("Cannot open file: %s" % filepath)
+
+
+class uniform_model(bias_model):
+    """reference: bias.py:114-122 (probs returns len(seq) ones, not len(seq)-6)"""
+
+    def __init__(self):
+        bias_model.__init__(self)
+        for seq in itertools.product("ATCG", repeat=self.k):
+            self.model["".join(seq)] = 1.0
+
+    def probs(self, seq):
+        return np.ones(len(seq))
+
+    def probs_both(self, seq, ctx=None):
+        n = len(seq)
+        return np.ones(n), np.ones(n)

@@ -1,0 +1,194 @@
+"""Batched, HBM-resident footprint scan: many intervals per launch.
+
+The reference runs `prediction.compute -> strand merge -> dm.p_values -> stouffers_z` one
+interval at a time (cli/detect.py:120-130).  `FootprintScanner` runs the same sequence for a
+whole batch of intervals in one fused HIP kernel (fpt_scan_dev of include/fpt.h) and keeps
+inputs and output tracks resident in HBM.
+
+Layout (pad = half_win_width + smoothing_half_win_width), interval i of length L_i, output
+offset off_i = sum_{j<i} L_j:
+    counts_plus / counts_minus : float64, interval i at [off_i + i*(2*pad+1), +L_i+2*pad+1)
+    seq                        : uint8 ASCII, interval i at [off_i + i*(2*pad+7), +L_i+2*pad+7)
+    exp, obs, pval             : float64 tracks of sum(L_i)
+    winp                       : (n_scales, sum(L_i)) float64
+which is what prediction.compute fetches per interval (predict.pyx:132-140), back to back.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray(object):
+    """A device allocation made through the C ABI (for hosts without their own allocator)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _lib.check(ctx.L.fpt_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        _lib.check(self.ctx.L.fpt_memcpy_h2d(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
+        return self
+
+    def download(self, dtype, count, offset_bytes=0):
+        out = np.empty(count, dtype=dtype)
+        _lib.check(self.ctx.L.fpt_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset_bytes,
+                                             out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.fpt_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def shard_intervals(lengths, world_size, pad):
+    """Contiguous interval ranges per rank, balanced by cumulative padded bases
+    sum(L_i + 2*pad + 1).  `lengths` is an int (uniform count is then given by
+    `lengths=(n, L)`) or an array of interval lengths.  Returns a list of (first, last)."""
+    if isinstance(lengths, tuple):
+        n, L = lengths
+        cost = np.full(int(n), int(L) + 2 * pad + 1, dtype=np.int64)
+    else:
+        cost = np.asarray(lengths, dtype=np.int64) + 2 * pad + 1
+    n = cost.size
+    cum = np.concatenate([[0], np.cumsum(cost)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r // world_size
+        i = int(np.searchsorted(cum, target, side="left"))
+        bounds.append(min(max(i, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+class FootprintScanner(object):
+    def __init__(self, bias_table, dispersion, half_win_width=5, smoothing_half_win_width=50,
+                 smoothing_clip=0.01, scales=(3,), default_propensity=1e-6, ctx=None):
+        """bias_table: 4096 propensities in 2-bit order (bias_model.table());
+        dispersion: object with mu_params / r_params (modeling.dispersion.dispersion_model)."""
+        self.ctx = ctx or _lib.get_ctx()
+        self.table = _lib.f64(bias_table)
+        self.dflt = float(default_propensity)
+        self.mu = _lib.f64(dispersion.mu_params).ravel()
+        self.r = _lib.f64(dispersion.r_params).ravel()
+        self.hw, self.shw, self.clip = int(half_win_width), int(smoothing_half_win_width), float(smoothing_clip)
+        self.scales = tuple(int(s) for s in scales)
+        if len(self.scales) > _lib.MAX_SCALES:
+            raise ValueError("at most %d scales" % _lib.MAX_SCALES)
+        self.pad = self.hw + self.shw
+
+    # ---- geometry ------------------------------------------------------------------------
+    def padded_len(self, L):
+        return int(L) + 2 * self.pad + 1
+
+    def input_sizes(self, n_intervals, total_bases):
+        """(#count elements per strand, #sequence bytes) for a batch."""
+        return (total_bases + n_intervals * (2 * self.pad + 1),
+                total_bases + n_intervals * (2 * self.pad + 7))
+
+    # ---- device-pointer level ----------------------------------------------------------
+    def scan_dev(self, n_intervals, counts_plus, counts_minus, seq, exp_out=None, obs_out=None,
+                 pval_out=None, winp_out=None, interval_len=None, interval_off_dev=None,
+                 interval_off_host=None, status_out=None):
+        """Enqueue the fused scan on device pointers (ints); does not synchronise."""
+        ctx = self.ctx
+        ctx.set_bias_table(self.table, self.dflt)
+        d = _lib.ScanDesc()
+        d.n_intervals = int(n_intervals)
+        d.interval_len = int(interval_len or 0)
+        d.interval_off = interval_off_dev
+        self._keep = None
+        if interval_off_host is not None:
+            self._keep = np.ascontiguousarray(interval_off_host, dtype=np.int64)
+            d.interval_off_host = self._keep.ctypes.data
+        d.half_win_width, d.smoothing_half_win_width = self.hw, self.shw
+        d.smoothing_clip = self.clip
+        d.n_scales = len(self.scales)
+        for i, s in enumerate(self.scales):
+            d.scales[i] = s
+        d.dm_id = ctx.dispersion_slot(self.mu, self.r)
+        d.counts_plus, d.counts_minus, d.seq = counts_plus, counts_minus, seq
+        d.exp_out, d.obs_out, d.pval_out, d.winp_out = exp_out, obs_out, pval_out, winp_out
+        d.status_out = status_out
+        _lib.check(ctx.L.fpt_scan_dev(ctx.h, C.byref(d)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _lib.check(self.ctx.L.fpt_last_scan_ms(self.ctx.h, C.byref(ms)))
+        return ms.value
+
+    # ---- numpy level ---------------------------------------------------------------------
+    def scan(self, counts_plus, counts_minus, seq, interval_len=None, interval_off=None):
+        """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status)."""
+        ctx = self.ctx
+        cp, cm = _lib.f64(counts_plus).ravel(), _lib.f64(counts_minus).ravel()
+        if isinstance(seq, str):
+            seq = seq.encode("ascii", "replace")
+        sq = (np.frombuffer(bytes(seq), dtype=np.uint8) if isinstance(seq, (bytes, bytearray))
+              else np.ascontiguousarray(seq, dtype=np.uint8).ravel())
+        if interval_off is not None:
+            off = np.ascontiguousarray(interval_off, dtype=np.int64)
+            n_iv, total = off.size - 1, int(off[-1])
+        else:
+            lp = self.padded_len(interval_len)
+            if cp.size % lp:
+                raise ValueError("counts length is not a multiple of the padded interval length")
+            n_iv = cp.size // lp
+            total = n_iv * int(interval_len)
+            off = None
+        n_c, n_s = self.input_sizes(n_iv, total)
+        if cp.size != n_c or cm.size != n_c or sq.size != n_s:
+            raise ValueError("input sizes do not match the batch layout (counts %d/%d, seq %d/%d)"
+                             % (cp.size, n_c, sq.size, n_s))
+        S = len(self.scales)
+        bufs = []
+        try:
+            d_cp = DeviceArray(ctx, max(cp.nbytes, 16)).upload(cp); bufs.append(d_cp)
+            d_cm = DeviceArray(ctx, max(cm.nbytes, 16)).upload(cm); bufs.append(d_cm)
+            d_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq); bufs.append(d_sq)
+            d_out = DeviceArray(ctx, max((3 + S) * total * 8, 16)); bufs.append(d_out)
+            d_st = DeviceArray(ctx, max(n_iv * 4, 16)).upload(np.zeros(max(n_iv, 1), np.int32)); bufs.append(d_st)
+            d_off = None
+            if off is not None:
+                d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
+            t8 = total * 8
+            self.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, exp_out=d_out.ptr, obs_out=d_out.ptr + t8,
+                          pval_out=d_out.ptr + 2 * t8, winp_out=(d_out.ptr + 3 * t8) if S else None,
+                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
+                          interval_off_host=off, status_out=d_st.ptr)
+            ctx.synchronize()
+            flat = d_out.download(np.float64, (3 + S) * total)
+            status = d_st.download(np.int32, n_iv)
+        finally:
+            for b in bufs:
+                b.free()
+        return dict(exp=flat[:total], obs=flat[total:2 * total], pval=flat[2 * total:3 * total],
+                    winp=flat[3 * total:].reshape(S, total), status=status)
+
+    # ---- synthetic workload (BASELINE.json configs 1-3) ---------------------------------
+    def synth_dev(self, seed, n_intervals, interval_len, counts_plus, counts_minus, seq,
+                  first_interval=0):
+        """Fill device buffers with the counter-hash workload for intervals
+        [first_interval, first_interval + n_intervals) of a uniform batch."""
+        lp = self.padded_len(interval_len)
+        _lib.check(self.ctx.L.fpt_synth_dev(self.ctx.h, int(seed), first_interval * lp, n_intervals * lp,
+                                            counts_plus, counts_minus, first_interval * (lp + 6),
+                                            n_intervals * (lp + 6), seq))
+
+    def checksum_dev(self, ptr, n):
+        out = C.c_uint64()
+        _lib.check(self.ctx.L.fpt_checksum_dev(self.ctx.h, ptr, int(n), C.byref(out)))
+        return out.value

@@ -1,0 +1,186 @@
+/*
+ * fpt.h -- C ABI of libfpt_hip.so: the MI355X (gfx950) implementation of the
+ * footprint-tools per-nucleotide expected-cleavage / deviation-statistics scan.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no framework types.
+ * Each entry point names the reference interface it replaces (paths under the
+ * reference repo vierstralab/footprint-tools v1.3.7).  The reference-side
+ * bindings are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (FPT_OK) or a negative fpt_status; the message
+ *     of the last failure on the calling thread is fpt_last_error().
+ *   - "host" entry points take caller-owned HOST buffers (numpy arrays) and do
+ *     the H2D/D2H copies themselves: they mirror the one-interval-at-a-time
+ *     reference calls.  "_dev" entry points take DEVICE pointers, enqueue on
+ *     the context's stream and return without synchronising: they are the
+ *     batched, HBM-resident path.
+ *   - all floating-point data is float64, C-contiguous, like the reference's
+ *     typed memoryviews; lengths that the reference types as C int stay int.
+ *   - there is no CPU fallback: without a HIP device fpt_ctx_create fails.
+ */
+#ifndef FPT_H
+#define FPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpt_ctx fpt_ctx;
+
+enum fpt_status {
+    FPT_OK = 0,
+    FPT_ERR_INVALID = -1,  /* bad argument */
+    FPT_ERR_HIP = -2,      /* HIP runtime error (message has the hipError string) */
+    FPT_ERR_NODEVICE = -3, /* no usable gfx950 device */
+    FPT_ERR_ZERODIV = -4,  /* reference would raise ZeroDivisionError (dispersion.pyx:160-161) */
+    FPT_ERR_NOMEM = -5
+};
+
+/* reducers of stats/windowing.pyx:60-178 */
+enum fpt_window_op {
+    FPT_WIN_SUM = 0,      /* windowing.sum               -> windowing.h:11-22  */
+    FPT_WIN_PRODUCT = 1,  /* windowing.product           -> windowing.h:24-35  */
+    FPT_WIN_FISHER = 2,   /* windowing.fishers_combined  -> windowing.h:38-51  */
+    FPT_WIN_STOUFFER = 3, /* windowing.stouffers_z       -> windowing.h:53-67  */
+    FPT_WIN_WSTOUFFER = 4 /* windowing.weighted_stouffers_z -> windowing.h:86-102 */
+};
+
+/* per-base NB quantities of modeling/dispersion.pyx */
+enum fpt_nb_what {
+    FPT_NB_CDF = 0,    /* dispersion_model.p_values        dispersion.pyx:291-316 */
+    FPT_NB_LOGPMF = 1, /* dispersion_model.log_pmf_values  dispersion.pyx:170-196 (+ _0 :228-258) */
+    FPT_NB_PMF = 2     /* dispersion_model.pmf_values      dispersion.pyx:199-225 (+ _0 :260-289) */
+};
+
+/* hcephes entry points reachable from the path (unit-test / diagnostics hook) */
+enum fpt_special_fn {
+    FPT_FN_GAMMA = 0, FPT_FN_LGAM = 1, FPT_FN_NDTR = 2, FPT_FN_NDTRI = 3, FPT_FN_LOG1P = 4,
+    FPT_FN_ERF = 5, FPT_FN_ERFC = 6, FPT_FN_INCBET = 7, /* (a,b,x) */
+    FPT_FN_CHDTRC = 8 /* (df = a, x) */
+};
+
+#define FPT_MAX_DISPERSION_MODELS 64
+#define FPT_MAX_SCALES 8
+#define FPT_KMER_TABLE 4096
+
+const char *fpt_last_error(void);
+int fpt_version(void);
+int fpt_device_count(int *n_out);
+
+/* ---- context: one per (process, GPU); owns a stream, the bias table, the
+ * dispersion-model table and a grow-only device workspace. */
+int fpt_ctx_create(int device_id, fpt_ctx **out);
+int fpt_ctx_destroy(fpt_ctx *ctx);
+/* run on a caller-provided hipStream_t (e.g. the framework's current stream); NULL = own stream */
+int fpt_ctx_set_stream(fpt_ctx *ctx, void *hip_stream);
+int fpt_ctx_synchronize(fpt_ctx *ctx);
+
+/* bias_model.__getitem__ / kmer_model.read_model (modeling/bias.py:16-17, 63-86):
+ * 4096 propensities indexed by sum code(s_m)*4^(5-m), A=0 C=1 G=2 T=3; `dflt` is the
+ * value for k-mers that are missing or contain a non-ACGT letter (1e-6 in the reference). */
+int fpt_set_bias_table(fpt_ctx *ctx, const double *table4096, double dflt);
+
+/* dispersion_model.mu_params / .r_params (modeling/dispersion.pyx:113-124): 9 and 15 doubles,
+ * (breaks, intercepts, slopes).  dm_id selects one of FPT_MAX_DISPERSION_MODELS slots
+ * (the reference has one model per dataset: cli/detect.py:334-336, stats/posterior.py:119). */
+int fpt_set_dispersion(fpt_ctx *ctx, int dm_id, const double *mu_params9, const double *r_params15);
+
+/* ---- host-buffer entry points (one reference call each) ----------------- */
+
+/* kmer_model.probs on both strands as prediction.compute uses it
+ * (modeling/bias.py:88-111; modeling/predict.pyx:47-61, 150-153):
+ * fwd[j] = T[seq[j..j+5]], rev[j] = T[revcomp(seq[j+1..j+6])], j in [0, seq_len-6).
+ * Letters are matched case-insensitively (predict.pyx:140 upper-cases first). */
+int fpt_kmer_probs(fpt_ctx *ctx, const uint8_t *seq, int64_t seq_len, double *fwd, double *rev);
+
+/* fast_predict (modeling/predict.h:23-74, smoothing.h:107-133) for n_rows independent rows of
+ * length l laid out back to back: the `cdef predict()` of modeling/predict.pyx:23-45 is the
+ * n_rows == 1 case.  exp_out / win_out: n_rows*l doubles. */
+int fpt_predict(fpt_ctx *ctx, const double *obs, const double *probs, int64_t n_rows, int l,
+                int half_win_width, int smoothing_half_win_width, double smoothing_clip,
+                double *exp_out, double *win_out);
+
+/* dispersion_model.{p_values, log_pmf_values, pmf_values}(exp, obs) with the model in slot dm_id.
+ * FPT_ERR_ZERODIV when fit_r's piecewise value is exactly 0 for some element. */
+int fpt_nb_values(fpt_ctx *ctx, int what, int dm_id, const double *exp, const double *obs,
+                  int64_t n, double *out);
+
+/* nbinom.{cdf,logpmf,pmf}(k, p, r) element-wise (stats/distributions/nbinom.pyx:82-138) */
+int fpt_nb_scalar(fpt_ctx *ctx, int what, const int32_t *k, const double *p, const double *r,
+                  int64_t n, double *out);
+
+/* windowing.<op>(x, hw) (stats/windowing.pyx:34-58,132-158; windowing.h:69-122) applied to
+ * n_rows independent rows of length n: out[i] = f(x[i-hw..i+hw]) for i in [hw, n-hw), 1.0
+ * elsewhere.  w (weights) only for FPT_WIN_WSTOUFFER, else NULL. */
+int fpt_window(fpt_ctx *ctx, int op, const double *x, const double *w, int64_t n_rows, int n,
+               int hw, double *out);
+
+/* element-wise hcephes functions (see fpt_special_fn); b/x may be NULL for 1-argument functions */
+int fpt_special(fpt_ctx *ctx, int fn, const double *a, const double *b, const double *x,
+                int64_t n, double *out);
+
+/* ---- batched, HBM-resident scan (cli/detect.py:120-130 for many intervals) */
+
+typedef struct fpt_scan_desc {
+    int64_t n_intervals;
+    /* uniform batches: every interval has `interval_len` bases and interval_off == NULL.
+     * ragged batches: interval_off (DEVICE, n_intervals+1 int64) are offsets into the output
+     * tracks, interval_off_host the same array on the HOST (used to build the tile table). */
+    int32_t interval_len;
+    const int64_t *interval_off;
+    const int64_t *interval_off_host;
+    int32_t half_win_width;           /* prediction(half_win_width=5)             predict.pyx:85 */
+    int32_t smoothing_half_win_width; /* prediction(smoothing_half_win_width=..)  predict.pyx:85 */
+    double smoothing_clip;            /* prediction(smoothing_clip=0.01)          predict.pyx:85 */
+    int32_t n_scales;                 /* number of Stouffer windows (detect uses one, hw=3) */
+    int32_t scales[FPT_MAX_SCALES];   /* half window widths                       detect.py:84   */
+    int32_t dm_id;                    /* dispersion model slot */
+    /* inputs (DEVICE).  With pad = hw + shw, interval i of length L_i owns
+     *   counts_*[ off_i + i*(2*pad+1) .. +L_i+2*pad+1 )   padded cut counts, genomic order
+     *   seq     [ off_i + i*(2*pad+7) .. +L_i+2*pad+7 )   ASCII bases, 3 extra on each side
+     * exactly the arrays prediction.compute fetches (predict.pyx:132-140). */
+    const double *counts_plus;
+    const double *counts_minus;
+    const uint8_t *seq;
+    /* outputs (DEVICE), tracks of sum(L_i) doubles; any may be NULL to skip the store.
+     * winp holds n_scales tracks back to back. */
+    double *exp_out;
+    double *obs_out;
+    double *pval_out;
+    double *winp_out;
+    /* optional per-interval status (DEVICE int32[n_intervals]): bit 0 = ZeroDivisionError */
+    int32_t *status_out;
+} fpt_scan_desc;
+
+/* Enqueue the fused scan on the context's stream (no synchronisation). */
+int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
+
+/* Fill device buffers with the synthetic workload of BASELINE.json configs 1-3:
+ * counter-hash generator, element at global position p of stream s is
+ * mix(mix(seed+s)+p); counts = U{0..19} as float64, bases uniform ACGT.
+ * Any pointer may be NULL. */
+int fpt_synth_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
+                  double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
+                  uint8_t *seq);
+
+/* 64-bit order-independent checksum (sum of value bit patterns mod 2^64) of a device track,
+ * written to *host_out after synchronising; for size-independent parity checks. */
+int fpt_checksum_dev(fpt_ctx *ctx, const double *dev, int64_t n, uint64_t *host_out);
+
+/* device memory helpers for hosts that have no allocator of their own (ctypes callers) */
+int fpt_dev_alloc(fpt_ctx *ctx, int64_t bytes, void **dev_out);
+int fpt_dev_free(fpt_ctx *ctx, void *dev);
+int fpt_memcpy_h2d(fpt_ctx *ctx, void *dev, const void *host, int64_t bytes);
+int fpt_memcpy_d2h(fpt_ctx *ctx, void *host, const void *dev, int64_t bytes);
+
+/* timing of the most recent fpt_scan_dev launch sequence measured with HIP events on the
+ * context's stream (valid after fpt_ctx_synchronize): milliseconds of the fused kernel. */
+int fpt_last_scan_ms(fpt_ctx *ctx, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPT_H */

@@ -18,11 +18,19 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-@pytest.fixture(scope="session")
-def orc():
-    """The CPU checker (test infrastructure, never the product path)."""
+@pytest.fixture(scope="session", autouse=True)
+def _load_checker_first():
+    """Load (and if needed build) the CPU checker before any test initialises the GPU: a
+    process that has touched the GPU must not fork/exec on the GPU pool."""
     from oracle import oracle
     oracle.lib()
+    oracle.ref_lib()
+
+
+@pytest.fixture(scope="session")
+def orc(_load_checker_first):
+    """The CPU checker (test infrastructure, never the product path)."""
+    from oracle import oracle
     return oracle
 
 

@@ -1,0 +1,438 @@
+"""Parity tests proper: the HIP path (through the C ABI / the Python mirror of the reference
+API) against the golden vectors of the genuine reference and against the CPU oracle.
+
+Bars (BASELINE.json north_star): 6-mer indices, window extents, obs and the integer-valued
+expected counts bit-exact; p-values / window p-values within 1e-6 relative, NaN masks identical."""
+import numpy as np
+import pytest
+
+from .conftest import golden, has_gpu, rel_err
+
+pytestmark = pytest.mark.gpu
+
+P_TOL = 1e-6   # the contract
+TIGHT = 1e-9   # what the kernels are expected to reach (device libm, FMA contraction)
+
+
+@pytest.fixture(scope="module")
+def fpt():
+    if not has_gpu():
+        pytest.fail("GPU tests need an MI355X")
+    from footprint_tools_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(fpt):
+    return fpt.get_ctx()
+
+
+def special(fpt, ctx, name, a, b=None, x=None):
+    a = fpt.f64(a).ravel()
+    out = np.empty_like(a)
+    b = None if b is None else fpt.f64(b).ravel()
+    x = None if x is None else fpt.f64(x).ravel()
+    fpt.check(ctx.L.fpt_special(ctx.h, fpt.FN[name], fpt.ptr(a), fpt.ptr(b), fpt.ptr(x), a.size,
+                                fpt.ptr(out)))
+    return out
+
+
+# ---------------------------------------------------------------- special functions (hcephes subset)
+def test_special_functions(fpt, ctx):
+    g, w = golden("nb_lattice.npz"), golden("window.npz")
+    errs = {}
+    errs["gamma"] = rel_err(special(fpt, ctx, "gamma", g["g_x"]), g["g_gamma"])
+    errs["lgam"] = rel_err(special(fpt, ctx, "lgam", g["g_x"]), g["g_lgam"])
+    errs["log1p"] = rel_err(special(fpt, ctx, "log1p", g["l1p_x"]), g["l1p_val"])
+    errs["ndtri"] = rel_err(special(fpt, ctx, "ndtri", w["ndtri_y"]), w["ndtri_val"])
+    errs["ndtr"] = rel_err(special(fpt, ctx, "ndtr", w["ndtr_a"]), w["ndtr_val"])
+    errs["erf"] = rel_err(special(fpt, ctx, "erf", w["ndtr_a"]), w["erf_val"])
+    errs["erfc"] = rel_err(special(fpt, ctx, "erfc", w["ndtr_a"]), w["erfc_val"])
+    errs["chdtrc"] = rel_err(special(fpt, ctx, "chdtrc", w["ch_df"], x=w["ch_x"]), w["ch_val"])
+    errs["incbet"] = rel_err(special(fpt, ctx, "incbet", g["ib_a"], g["ib_b"], g["ib_x"]), g["ib_val"])
+    print("max rel err:", {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < P_TOL, (k, v)
+
+
+# ---------------------------------------------------------------- A1: 6-mer lookup, bit-exact
+def test_kmer_probs(fpt, ctx):
+    g = golden("kmer_probs.npz")
+    ctx.set_bias_table(g["table"], 1e-6)
+    for i in range(int(g["n_seq"])):
+        s = np.ascontiguousarray(g["seq%d" % i])
+        n = max(s.size - 6, 0)
+        fwd, rev = np.empty(n), np.empty(n)
+        fpt.check(ctx.L.fpt_kmer_probs(ctx.h, fpt.ptr(s), s.size, fpt.ptr(fwd), fpt.ptr(rev)))
+        assert np.array_equal(fwd, g["fwd%d" % i]) and np.array_equal(rev, g["rev%d" % i]), i
+
+
+def test_kmer_model_api(fpt, tmp_path):
+    """kmer_model(path).probs(seq) like the reference class (bias.py:58-111)."""
+    import itertools
+    from footprint_tools_amd.modeling import bias
+    g = golden("kmer_probs.npz")
+    path = tmp_path / "model.txt"
+    rs = np.random.RandomState(0)
+    kmers = ["".join(k) for k in itertools.product("ACGT", repeat=6)]
+    order = rs.permutation(4096)  # file order is arbitrary (the published file is sorted by value)
+    with open(path, "w") as fh:
+        for j in order:
+            fh.write("%s\t%r\n" % (kmers[j].lower() if j % 7 == 0 else kmers[j], float(g["table"][j])))
+    bm = bias.kmer_model(str(path))
+    assert bm.offset() == 3 and bm.k == 6 and bm["ACGTNN"] == 1e-6
+    assert np.array_equal(bm.table(), g["table"])
+    for i in (0, 1, 2):
+        up = bytes(g["seq%d" % i]).decode().upper()
+        assert np.array_equal(bm.probs(up), g["fwd%d" % i])
+    assert np.array_equal(bias.uniform_model().probs("ACGTAC"), np.ones(6))
+
+
+# ---------------------------------------------------------------- A2-A4: fast_predict
+def test_predict_golden(fpt):
+    from footprint_tools_amd.modeling import predict
+    g = golden("predict.npz")
+    worst = 0.0
+    for c, (hw, shw, clip, l) in enumerate(g["meta"]):
+        e, w = predict.predict(g["obs%d" % c], g["probs%d" % c], int(hw), int(shw), float(clip))
+        assert np.array_equal(e, g["exp%d" % c]), "exp case %d %s" % (c, g["meta"][c])
+        if g["win%d" % c].size:
+            err = float(np.max(np.abs(w - g["win%d" % c]) / np.maximum(np.abs(g["win%d" % c]), 1e-300)))
+            worst = max(worst, err)
+            assert err < 1e-12, "win case %d %s err %g" % (c, g["meta"][c], err)
+    print("predict: exp bit-exact on %d cases, max win rel err %.2e" % (len(g["meta"]), worst))
+
+
+def test_predict_rows_and_long(fpt, orc):
+    """batched rows + a row longer than one tile (tiling with halos)."""
+    from footprint_tools_amd.modeling import predict
+    rs = np.random.RandomState(9)
+    obs = rs.poisson(2.0, (3, 5000)).astype(float)
+    probs = rs.uniform(1e-3, .2, (3, 5000))
+    for (hw, shw, clip) in [(5, 50, .01), (5, 50, .05), (3, 0, .01), (4, 100, 0.0)]:
+        e, w = predict.predict(obs, probs, hw, shw, clip)
+        for r in range(3):
+            e0, w0 = orc.fast_predict(obs[r], probs[r], hw, shw, clip)
+            assert np.array_equal(e[r], e0)
+            assert np.allclose(w[r], w0, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- A5-A7: NB values
+def test_nb_lattice(fpt):
+    from footprint_tools_amd.modeling import dispersion
+    g = golden("nb_lattice.npz")
+    worst = {}
+    for key in "ABCD":
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = g["mu_" + key], g["r_" + key]
+        xs = g["fit_x"]
+        assert np.array_equal([dm.fit_mu(x) for x in xs], g["fit_mu_" + key])
+        for x, zd, want in zip(xs, g["fit_r_zerodiv_" + key], g["fit_r_" + key]):
+            if zd:
+                with pytest.raises(ZeroDivisionError):
+                    dm.fit_r(x)
+            else:
+                assert dm.fit_r(x) == want
+        for fn, name in ((dm.p_values, "cdf"), (dm.log_pmf_values, "logpmf"), (dm.pmf_values, "pmf")):
+            err = rel_err(fn(g["lat_exp"], g["lat_obs"]), g["%s_%s" % (name, key)])
+            worst[name] = max(worst.get(name, 0), err)
+            assert err < P_TOL, (key, name, err)
+        if key in "ABC":
+            assert rel_err(dm.p_values(g["tail_exp"], g["tail_obs"]), g["tail_cdf_" + key]) < P_TOL
+            assert rel_err(dm.log_pmf_values(g["tail_exp"], g["tail_obs"]), g["tail_logpmf_" + key]) < P_TOL
+    print("nb lattice max rel err:", {k: "%.2e" % v for k, v in worst.items()})
+    res = np.full(g["lat_exp"].shape, 7.0)
+    assert dm.pmf_values_0(g["lat_exp"], g["lat_obs"], res) is res and res[0] != 7.0
+    with pytest.raises(ZeroDivisionError):
+        dm.p_values(np.array([1.0, 2.5, 3.0]), np.ones(3))
+
+
+def test_nbinom_scalars(fpt):
+    from footprint_tools_amd.stats.distributions import nbinom
+    g = golden("nb_lattice.npz")
+    assert rel_err(nbinom.cdf(g["sc_k"], g["sc_p"], g["sc_r"]), g["sc_cdf"]) < P_TOL
+    assert rel_err(nbinom.logpmf(g["sc_k"], g["sc_p"], g["sc_r"]), g["sc_logpmf"]) < P_TOL
+    assert rel_err(nbinom.pmf(g["sc_k"], g["sc_p"], g["sc_r"]), g["sc_pmf"]) < P_TOL
+    assert abs(nbinom.cdf(3, 0.3, 5.0) - g["sc_cdf"][0]) >= 0  # scalar call returns a float
+    assert isinstance(nbinom.cdf(3, 0.3, 5.0), float)
+
+
+# ---------------------------------------------------------------- A8-A9: windows
+def test_windows_golden(fpt):
+    from footprint_tools_amd.stats import windowing
+    g = golden("window.npz")
+    worst = 0.0
+    for nm in g["names"]:
+        x, w = g["x_" + nm], g["w_" + nm]
+        for hw in g["hws"]:
+            for fn in ("sum", "product", "fishers_combined", "stouffers_z"):
+                got = getattr(windowing, fn)(x, int(hw))
+                err = rel_err(got, g["%s_%s_%d" % (fn, nm, hw)])
+                worst = max(worst, err)
+                assert err < P_TOL, (fn, nm, hw, err)
+            got = windowing.weighted_stouffers_z(x, w, int(hw))
+            assert rel_err(got, g["weighted_stouffers_z_%s_%d" % (nm, hw)]) < P_TOL, (nm, hw)
+    print("windows max rel err %.2e" % worst)
+
+
+# ---------------------------------------------------------------- whole path
+def _cfg1(orc):
+    g = golden("e2e_cfg1.npz")
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    n_iv, L, hw, shw = int(g["n_iv"]), int(g["L"]), int(g["hw"]), int(g["shw"])
+    l = L + 2 * (hw + shw) + 1
+    cp = orc.synth_counts(1, 0, n_iv * l, 0)
+    cm = orc.synth_counts(1, 0, n_iv * l, 1)
+    sq = orc.synth_bases(1, 0, n_iv * (l + 6))
+    return g, lat, table, n_iv, L, hw, shw, cp, cm, sq
+
+
+class _DM(object):
+    def __init__(self, mu, r):
+        self.mu_params, self.r_params = mu, r
+
+
+def test_fused_scan_config1_golden(fpt, orc):
+    """BASELINE config 1 (1,000 x 500 bp, 5 scales) through the fused kernel vs the golden
+    vectors of the reference (first intervals in full, all intervals by per-interval sums)."""
+    from footprint_tools_amd.scan import FootprintScanner
+    g, lat, table, n_iv, L, hw, shw, cp, cm, sq = _cfg1(orc)
+    scales = tuple(int(s) for s in g["scales"])
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, float(g["clip"]), scales)
+    out = sc.scan(cp, cm, sq, interval_len=L)
+    nf = g["exp"].shape[0]
+    assert np.array_equal(out["exp"].reshape(n_iv, L)[:nf], g["exp"])
+    assert np.array_equal(out["obs"].reshape(n_iv, L)[:nf], g["obs"])
+    ep = rel_err(out["pval"].reshape(n_iv, L)[:nf], g["p"])
+    ew = rel_err(out["winp"].reshape(len(scales), n_iv, L)[:, :nf].transpose(1, 0, 2), g["winp"])
+    print("cfg1 golden: p %.2e winp %.2e" % (ep, ew))
+    assert ep < P_TOL and ew < P_TOL
+    assert np.array_equal(out["exp"].reshape(n_iv, L).sum(1), g["sums"][:, 0])
+    assert np.array_equal(out["obs"].reshape(n_iv, L).sum(1), g["sums"][:, 1])
+    assert np.allclose(np.nansum(out["pval"].reshape(n_iv, L), 1), g["sums"][:, 2], rtol=1e-9)
+    W = out["winp"].reshape(len(scales), n_iv, L)
+    for s in range(len(scales)):
+        assert np.array_equal(np.isnan(W[s]).sum(1), g["nan_counts"][:, 1 + s])
+        assert np.allclose(np.nansum(W[s], 1), g["sums"][:, 3 + s], rtol=1e-9)
+    assert not out["status"].any()
+    # and against the oracle on every base
+    e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, float(g["clip"]), table, lat["mu_A"],
+                                   lat["r_A"], scales, n_threads=4)
+    assert np.array_equal(out["exp"], e) and np.array_equal(out["obs"], o)
+    assert rel_err(out["pval"], p) < P_TOL and rel_err(out["winp"], wp) < P_TOL
+
+
+@pytest.mark.parametrize("L,hw,shw,clip,scales,dm", [
+    (1000, 5, 50, 0.01, (3, 5, 10, 20, 40), "A"),   # config 3 shape
+    (500, 5, 50, 0.01, (3,), "B"),                   # config 2 shape, Poisson-like model
+    (137, 5, 50, 0.01, (3, 40), "C"),                # short ragged-ish, scale wider than the edge
+    (2500, 5, 50, 0.01, (3, 5, 10, 20, 40), "A"),    # longer than one workgroup -> tiled with halos
+    (300, 3, 0, 0.01, (3,), "A"),                    # learn_dm setting: no smoothing
+    (260, 5, 50, 0.05, (2, 7), "A"),                 # general-k trimmed mean (k=5)
+    (64, 1, 2, 0.0, (), "C"),                        # k=0, no windows
+])
+def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm):
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    n_iv = 24
+    l = L + 2 * (hw + shw) + 1
+    cp = orc.synth_counts(5, 1000, n_iv * l, 0)
+    cm = orc.synth_counts(5, 1000, n_iv * l, 1)
+    sq = orc.synth_bases(5, 77, n_iv * (l + 6)).copy()
+    sq[::97] = ord("N")
+    sq[5::41] |= 0x20  # lower-case
+    cp[: 3 * l] = 0.0  # an empty stretch: all-zero windows
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales)
+    out = sc.scan(cp, cm, sq, interval_len=L)
+    e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, clip, table, lat["mu_" + dm],
+                                   lat["r_" + dm], np.array(scales, np.int32))
+    assert np.array_equal(out["obs"], o)
+    assert np.array_equal(out["exp"], e)
+    assert rel_err(out["pval"], p) < P_TOL
+    if scales:
+        assert rel_err(out["winp"], wp) < P_TOL
+
+
+def test_fused_scan_ragged(fpt, orc):
+    """variable-length intervals (config 4 shape): CSR offsets, tiles binned by size."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    hw, shw, clip, scales = 5, 50, 0.01, (3, 10)
+    rs = np.random.RandomState(4)
+    lens = np.concatenate([[50, 1, 2000, 256, 257, 512, 513, 1024, 1025, 3100],
+                           np.clip(rs.lognormal(5.0, 0.6, 40).astype(int), 50, 2000)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pad = hw + shw
+    cps, cms, sqs, exp_l, obs_l, p_l, w_l = [], [], [], [], [], [], []
+    pos = 0
+    for L in lens:
+        l = int(L) + 2 * pad + 1
+        cp, cm = orc.synth_counts(9, pos, l, 0), orc.synth_counts(9, pos, l, 1)
+        sq = orc.synth_bases(9, pos, l + 6)
+        pos += l + 6
+        e, o, p, wp = orc.detect_batch(cp, cm, sq, 1, int(L), hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                       np.array(scales, np.int32))
+        cps.append(cp); cms.append(cm); sqs.append(sq)
+        exp_l.append(e); obs_l.append(o); p_l.append(p); w_l.append(wp)
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales)
+    out = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
+    assert np.array_equal(out["exp"], np.concatenate(exp_l))
+    assert np.array_equal(out["obs"], np.concatenate(obs_l))
+    assert rel_err(out["pval"], np.concatenate(p_l)) < P_TOL
+    assert rel_err(out["winp"], np.concatenate(w_l, axis=1)) < P_TOL
+
+
+def test_zero_division_status(fpt, orc):
+    """model D has 1/r exactly 0 at exp=2.5 -- unreachable for integer exp; force it with a model
+    whose first break makes the value 0 at an integer (detect.py:136-140 -> per-interval flag)."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    r = lat["r_A"].copy()
+    r[5], r[10] = -0.04, 0.02  # y0 + k0*2 == 0.0 exactly
+    L, hw, shw = 200, 5, 50
+    l = L + 2 * (hw + shw) + 1
+    n_iv = 6
+    cp = orc.synth_counts(3, 0, n_iv * l, 0) * (np.arange(n_iv * l) % 7 == 0)
+    cm = np.zeros(n_iv * l)
+    cp[2 * l:3 * l] = 0.0  # interval 2 has exp == 0 everywhere -> no division by zero there
+    sq = orc.synth_bases(3, 0, n_iv * (l + 6))
+    sc = FootprintScanner(table, _DM(lat["mu_A"], r), hw, shw, 0.01, (3,))
+    out = sc.scan(cp, cm, sq, interval_len=L)
+    has2 = (out["exp"].reshape(n_iv, L) == 2.0).any(1)
+    assert has2.any() and not has2[2]
+    assert np.array_equal(out["status"] != 0, has2)
+
+
+# ---------------------------------------------------------------- size-independent properties at bench scale
+def test_full_size_properties(fpt, orc):
+    """config 2 size (100,000 x 500 bp): split invariance and sampled oracle agreement, with the
+    workload generated and checksummed on the device."""
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = fpt.get_ctx()
+    n_iv, L, hw, shw, clip, scales = 100000, 500, 5, 50, 0.01, (3,)
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales)
+    l = sc.padded_len(L)
+    total = n_iv * L
+    d_cp, d_cm = DeviceArray(ctx, n_iv * l * 8), DeviceArray(ctx, n_iv * l * 8)
+    d_sq = DeviceArray(ctx, n_iv * (l + 6))
+    d_out = DeviceArray(ctx, 4 * total * 8)
+    sc.synth_dev(1, n_iv, L, d_cp.ptr, d_cm.ptr, d_sq.ptr)
+    t8 = total * 8
+    sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr, d_out.ptr + t8, d_out.ptr + 2 * t8,
+                d_out.ptr + 3 * t8, interval_len=L)
+    ctx.synchronize()
+    sums = [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(4)]
+    # (1) sampled intervals agree with the oracle
+    for iv in (0, 1, 49999, 99999):
+        cp = orc.synth_counts(1, iv * l, l, 0)
+        cm = orc.synth_counts(1, iv * l, l, 1)
+        sq = orc.synth_bases(1, iv * (l + 6), l + 6)
+        assert np.array_equal(d_cp.download(np.float64, l, iv * l * 8), cp)
+        assert np.array_equal(d_sq.download(np.uint8, l + 6, iv * (l + 6)), sq)
+        e, o, p, wp = orc.detect_batch(cp, cm, sq, 1, L, hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                       np.array(scales, np.int32))
+        assert np.array_equal(d_out.download(np.float64, L, iv * L * 8), e)
+        assert np.array_equal(d_out.download(np.float64, L, t8 + iv * L * 8), o)
+        assert rel_err(d_out.download(np.float64, L, 2 * t8 + iv * L * 8), p) < P_TOL
+        assert rel_err(d_out.download(np.float64, L, 3 * t8 + iv * L * 8), wp[0]) < P_TOL
+    # (2) idempotence: same launch again -> identical bits
+    sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr, d_out.ptr + t8, d_out.ptr + 2 * t8,
+                d_out.ptr + 3 * t8, interval_len=L)
+    ctx.synchronize()
+    assert [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(4)] == sums
+    # (3) split invariance: two half batches (as two ranks would run them) checksum to the whole
+    d_o2 = DeviceArray(ctx, 4 * total * 8)
+    half = n_iv // 2
+    for first in (0, half):
+        sc.scan_dev(half, d_cp.ptr + first * l * 8, d_cm.ptr + first * l * 8, d_sq.ptr + first * (l + 6),
+                    d_o2.ptr + first * L * 8, d_o2.ptr + t8 + first * L * 8,
+                    d_o2.ptr + 2 * t8 + first * L * 8, d_o2.ptr + 3 * t8 + first * L * 8, interval_len=L)
+    ctx.synchronize()
+    # winp of a half batch lands at winp_out + s*total_half: with one scale that is the same slot
+    assert [sc.checksum_dev(d_o2.ptr + k * t8, total) for k in range(4)] == sums
+    for d in (d_cp, d_cm, d_sq, d_out, d_o2):
+        d.free()
+
+
+# ---------------------------------------------------------------- reference API flow (notebook cell 4)
+def test_reference_api_flow(fpt, orc, tmp_path):
+    from footprint_tools_amd.modeling import bias, dispersion, predict
+    from footprint_tools_amd.stats import fdr, utils, windowing
+    g = golden("e2e_cfg1.npz")
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    bm = bias.bias_model()
+    import itertools
+    for j, k in enumerate(itertools.product("ACGT", repeat=6)):
+        bm["".join(k)] = float(table[j])
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+    dm2 = dispersion.load_dispersion_model(_write(tmp_path, dispersion.write_dispersion_model(dm)))
+    assert np.array_equal(dm2.mu_params, dm.mu_params) and np.array_equal(dm2.r_params, dm.r_params)
+    L, hw, shw = int(g["L"]), int(g["hw"]), int(g["shw"])
+    l = L + 2 * (hw + shw) + 1
+
+    class Reads(object):
+        def __getitem__(self, iv):
+            return {"+": self.p, "-": self.m}
+
+    class Fasta(object):
+        def fetch(self, chrom, s, e):
+            assert e - s == len(self.seq)
+            return self.seq
+
+    class Interval(object):
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end = c, s, e
+
+        def widen(self, w):
+            return Interval(self.chrom, self.start - w, self.end + w)
+
+    reads, fasta = Reads(), Fasta()
+    pr = predict.prediction(reads, fasta, bm, half_win_width=hw, smoothing_half_win_width=shw,
+                            smoothing_clip=float(g["clip"]))
+    assert pr.padding == hw + shw
+    for i in range(3):
+        reads.p, reads.m = orc.synth_counts(1, i * l, l, 0), orc.synth_counts(1, i * l, l, 1)
+        fasta.seq = orc.synth_bases(1, i * (l + 6), l + 6).tobytes().decode().lower()  # .upper() inside
+        obs, exp, win = pr.compute(Interval("chr1", 1000, 1000 + L))
+        assert len(obs["+"]) == L + 1
+        obs = obs["+"][1:] + obs["-"][:-1]
+        exp = exp["+"][1:] + exp["-"][:-1]
+        assert np.array_equal(exp, g["exp"][i]) and np.array_equal(obs, g["obs"][i])
+        pv = dm.p_values(exp, obs)
+        assert rel_err(pv, g["p"][i]) < P_TOL
+        wp = windowing.stouffers_z(np.ascontiguousarray(pv), 3)
+        assert rel_err(wp, g["winp"][i][0]) < P_TOL
+    np.random.seed(7)
+    vals, pn = dm.sample(exp[:50], 20)
+    assert vals.shape == (50, 20) and pn.shape == (50, 20)
+    r0, mu0 = dm.fit_r(exp[0]), dm.fit_mu(exp[0])
+    assert rel_err(pn[0], orc.lib() and np.array([orc.lib().orc_nb_cdf(int(k), r0 / (r0 + mu0), r0) for k in vals[0]])) < P_TOL
+    wn = np.apply_along_axis(lambda z: windowing.stouffers_z(np.ascontiguousarray(z), 3), 0, pn)
+    ef = fdr.emperical_fdr(wn, wp[:50])
+    assert ef.shape == (50,) and np.all((ef >= 0) & (ef <= 1))
+    assert utils.segment(ef, 0.5, 3, decreasing=True) == orc.segment(ef, 0.5, 3, True)
+
+
+def _write(tmp_path, text):
+    p = tmp_path / "dm.json"
+    p.write_text(text)
+    return str(p)
+
+
+def test_argument_errors(fpt, ctx):
+    from footprint_tools_amd.modeling import predict
+    from footprint_tools_amd.stats import windowing
+    with pytest.raises(ValueError):
+        predict.predict(np.ones(300), np.ones(300), 5, 50, 0.6)  # trims the whole window
+    with pytest.raises(ValueError):
+        windowing.stouffers_z(np.ones(10), -1)
+    assert np.array_equal(windowing.sum(np.ones(4), 3), np.ones(4))
+    assert windowing.stouffers_z(np.zeros(0), 3).shape == (0,)
