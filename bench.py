@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused per-nucleotide footprint scan on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (6-mer lookup -> expected cleavage with trimmed-mean
+smoothing -> NB p-value -> Stouffer windows) over one batch of synthetic intervals that is
+already resident in HBM.  N=1 workload = BASELINE.json configs[1] (100,000 x 500 bp, one
+scale); `--config 3` selects configs[2] (1,000,000 x 1 kb, five scales).  With N>1 every rank
+scans its own shard of N x batch intervals (weak scaling, no data-path collective inside the
+scan) and the per-base p-value track is re-assembled on every rank with one RCCL all-gather
+per step, overlapped with the next step's scan.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the fused
+kernel and `cpu_baseline` = the C oracle timed on this box's host cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1] / configs[2]
+    "2": dict(name="100000x500bp_1scale", n_iv=100000, L=500, scales=(3,)),
+    "3": dict(name="1000000x1kb_5scales", n_iv=1000000, L=1000, scales=(3, 5, 10, 20, 40)),
+    # small shapes for quick checks
+    "1": dict(name="1000x500bp_5scales", n_iv=1000, L=500, scales=(3, 5, 10, 20, 40)),
+}
+HW, SHW, CLIP = 5, 50, 0.01
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_base(L, n_scales):
+    """read (l/L)*(8+8+1) for counts+/-, sequence; write 8*(3+S)."""
+    l = L + 2 * (HW + SHW) + 1
+    return (l / L) * 17.0, 8.0 * (3 + n_scales)
+
+
+def load_models():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kmer_probs.npz"))
+    lat = np.load(os.path.join(ROOT, "tests", "golden", "nb_lattice.npz"))
+
+    class DM(object):  # DM-SYNTH-A
+        mu_params, r_params = lat["mu_A"], lat["r_A"]
+
+    return g["table"], DM
+
+
+def cpu_baseline(cfg, table, DM, budget_s=12.0):
+    """The CPU oracle (a port of the reference algorithm, results identical to the reference on
+    the golden vectors) on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle  # checker / baseline only
+    L, scales = cfg["L"], cfg["scales"]
+    l = L + 2 * (HW + SHW) + 1
+    cores = min(os.cpu_count() or 1, 64)
+
+    def run(n):
+        cp = oracle.synth_counts(1, 0, n * l, 0)
+        cm = oracle.synth_counts(1, 0, n * l, 1)
+        sq = oracle.synth_bases(1, 0, n * (l + 6))
+        t0 = time.perf_counter()
+        oracle.detect_batch(cp, cm, sq, n, L, HW, SHW, CLIP, table, DM.mu_params, DM.r_params, scales,
+                            n_threads=cores)
+        return time.perf_counter() - t0
+
+    probe_n = 4 * cores
+    dt = run(probe_n)
+    rate = probe_n * L / dt
+    n = int(max(probe_n, min(rate * budget_s / L, 200000)))
+    dt = run(n)
+    return dict(value=n * L / dt, unit="bases/s", cores=cores, kind="port",
+                sample="%d intervals x %d bp of the same synthetic workload, oracle/fpt_oracle.c with "
+                       "OpenMP over intervals, %.1f s" % (n, L, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--nb-mode", default="memo", choices=["memo", "direct"],
+                    help="per-base NB p-value: exact (exp,obs) memo table rebuilt inside every step, "
+                         "or direct incbet per base; at N=1 the other mode is timed too and reported")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    cfg = CONFIGS[args.config]
+    n_iv, L, scales = cfg["n_iv"], cfg["L"], cfg["scales"]
+    S = len(scales)
+    table, DM = load_models()
+
+    # the CPU baseline runs first: it is plain host work and must not fork after GPU init
+    base = None
+    if world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(cfg, table, DM)
+
+    from footprint_tools_amd import _lib
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = _lib.Context(local_rank)
+    sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
+    l = sc.padded_len(L)
+    total = n_iv * L  # bases per rank per step
+
+    # ---- resident buffers: inputs generated on the device, outputs written in place
+    if world > 1:
+        dev = torch.device("cuda", local_rank)
+        t_cp = torch.empty(n_iv * l, dtype=torch.float64, device=dev)
+        t_cm = torch.empty(n_iv * l, dtype=torch.float64, device=dev)
+        t_sq = torch.empty(n_iv * (l + 6), dtype=torch.uint8, device=dev)
+        t_out = torch.empty((2 + S) * total, dtype=torch.float64, device=dev)   # exp, obs, winp[S]
+        t_p = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(2)]  # p track, double-buffered
+        t_gather = None if args.no_allgather else torch.empty(world * total, dtype=torch.float64, device=dev)
+        p_cp, p_cm, p_sq, p_out = t_cp.data_ptr(), t_cm.data_ptr(), t_sq.data_ptr(), t_out.data_ptr()
+        p_p = [t.data_ptr() for t in t_p]
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    else:
+        d_cp, d_cm = DeviceArray(ctx, n_iv * l * 8), DeviceArray(ctx, n_iv * l * 8)
+        d_sq = DeviceArray(ctx, n_iv * (l + 6))
+        d_out = DeviceArray(ctx, (2 + S) * total * 8)
+        d_p = [DeviceArray(ctx, total * 8)]
+        p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
+        p_p = [d_p[0].ptr]
+    # rank r owns intervals [r*n_iv, (r+1)*n_iv) of the global synthetic job
+    sc.synth_dev(1, n_iv, L, p_cp, p_cm, p_sq, first_interval=rank * n_iv)
+    ctx.synchronize()
+
+    t8 = total * 8
+
+    def step(i):
+        sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_out, obs_out=p_out + t8,
+                    pval_out=p_p[i % len(p_p)], winp_out=p_out + 2 * t8 if S else None, interval_len=L)
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            ctx.synchronize()
+
+    pending = [None, None]
+
+    def run_steps(k):
+        for i in range(k):
+            if world > 1 and not args.no_allgather:
+                if pending[i % 2] is not None:   # buffer i%2 is still being gathered from step i-2
+                    pending[i % 2].wait()
+                step(i)
+                pending[i % 2] = dist.all_gather_into_tensor(t_gather, t_p[i % 2], async_op=True)
+            else:
+                step(i)
+        for j in (0, 1):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+
+    def measure(steps, warmup):
+        run_steps(warmup)
+        sync()
+        ctx.timing_enable(steps)
+        t0 = time.perf_counter()
+        run_steps(steps)
+        sync()
+        return time.perf_counter() - t0, ctx.timing_read()
+
+    dt, kernel_ms = measure(args.steps, args.warmup)
+    other = None
+    if world == 1:  # the other evaluation mode, same workload, reported beside the headline
+        main_mode = sc.nb_mode
+        sc.nb_mode = _lib.NB_DIRECT if args.nb_mode == "memo" else _lib.NB_MEMO
+        k2 = max(3, args.steps // 4)
+        dt2, kms2 = measure(k2, 1)
+        other = dict(nb_pvalue="direct incbet per base" if args.nb_mode == "memo" else "memo table",
+                     value=total * k2 / dt2, unit="bases/s", ms_per_step=dt2 / k2 * 1e3,
+                     kernel_ms=float(np.mean(kms2)), steps=k2)
+        sc.nb_mode = main_mode
+        step(args.steps - 1)  # leave the headline mode's outputs in the buffers for the parity check
+        sync()
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- parity spot check outside the timed region (oracle = checker only)
+    parity = None
+    if rank == 0:
+        from oracle import oracle
+        iv = n_iv - 1
+        g0 = rank * n_iv + iv
+        cp = oracle.synth_counts(1, g0 * l, l, 0)
+        cm = oracle.synth_counts(1, g0 * l, l, 1)
+        sq = oracle.synth_bases(1, g0 * (l + 6), l + 6)
+        e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, L, HW, SHW, CLIP, table, DM.mu_params,
+                                          DM.r_params, scales)
+        last = (args.steps - 1) % len(p_p)
+        if world > 1:
+            torch.cuda.synchronize()
+            ge = t_out[iv * L:(iv + 1) * L].cpu().numpy()
+            gp = t_p[last][iv * L:(iv + 1) * L].cpu().numpy()
+        else:
+            ge = d_out.download(np.float64, L, iv * L * 8)
+            gp = d_p[0].download(np.float64, L, iv * L * 8)
+        rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
+        parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
+
+    if rank == 0:
+        rd, wr = algorithmic_bytes_per_base(L, S)
+        k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None
+        roof = None
+        if k_ms:
+            achieved = total * (rd + wr) / (k_ms * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(cfg["name"])
+            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        kernel="k_scan_fused", kernel_ms=k_ms,
+                        algorithmic_bytes_per_base=dict(read=rd, write=wr))
+        out = {
+            "metric": "bases/sec per-nucleotide footprint stats",
+            "value": world * total * args.steps / dt,
+            "unit": "bases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": cfg["name"], "intervals_per_gpu": n_iv, "interval_bp": L,
+                       "half_win_width": HW, "smoothing_half_win_width": SHW, "smoothing_clip": CLIP,
+                       "stouffer_half_widths": list(scales), "bias_model": "vierstra_et_al.6mer",
+                       "dispersion_model": "DM-SYNTH-A",
+                       "nb_pvalue": ("exact (exp,obs)->(p,z) memo table, 256x256, rebuilt by the device "
+                                     "incbet inside every step; direct incbet fallback outside it"
+                                     if args.nb_mode == "memo" else "direct incbet per base"),
+                       "allgather_p_track": bool(world > 1 and not args.no_allgather)},
+            "roofline": roof,
+            "cpu_baseline": base,
+            "other_nb_mode": other,
+            "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libfpt_hip.so")
 FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
 NB_CDF, NB_LOGPMF, NB_PMF = range(3)
+NB_AUTO, NB_DIRECT, NB_MEMO = range(3)
 FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8)
 MAX_SCALES = 8
 MAX_DM = 64
@@ -20,7 +21,8 @@ EXPORTS = [
     "fpt_ctx_set_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
-    "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms",
+    "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
+    "fpt_set_memo_dims",
 ]
 
 
@@ -37,6 +39,7 @@ class ScanDesc(C.Structure):
         ("n_scales", C.c_int32),
         ("scales", C.c_int32 * MAX_SCALES),
         ("dm_id", C.c_int32),
+        ("nb_mode", C.c_int32),
         ("counts_plus", C.c_void_p),
         ("counts_minus", C.c_void_p),
         ("seq", C.c_void_p),
@@ -90,6 +93,9 @@ def load():
         L.fpt_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.fpt_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.fpt_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.fpt_set_memo_dims.argtypes = [vp, i32, i32]
+        L.fpt_timing_enable.argtypes = [vp, i32]
+        L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -179,6 +185,20 @@ class Context(object):
 
     def synchronize(self):
         check(self.L.fpt_ctx_synchronize(self.h))
+
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned hipStream_t (integer handle); None/0 = the context's own."""
+        check(self.L.fpt_ctx_set_stream(self.h, hip_stream or None))
+
+    def timing_enable(self, max_records):
+        check(self.L.fpt_timing_enable(self.h, int(max_records)))
+
+    def timing_read(self, cap=100000):
+        """Milliseconds of each scan recorded since timing_enable / the last read (synchronises)."""
+        buf = np.zeros(cap, dtype=np.float32)
+        n = C.c_int(0)
+        check(self.L.fpt_timing_read(self.h, buf.ctypes.data, cap, C.byref(n)))
+        return buf[:min(n.value, cap)].astype(np.float64)
 
 
 _default = None

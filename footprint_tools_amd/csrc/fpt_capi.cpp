@@ -54,7 +54,10 @@ struct fpt_ctx {
     size_t ws_bytes[kSlots] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    std::vector<hipEvent_t> tev;  // event pairs of recorded scans (fpt_timing_enable)
+    int tev_used = 0;
     int n_cu = 0;
+    int memo_exp = 256, memo_obs = 256;
 };
 
 namespace {
@@ -169,6 +172,7 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return FPT_OK;
@@ -488,7 +492,23 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         }
     }
 
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const bool rec = c->tev_used + 2 <= (int)c->tev.size();
+    if (d->nb_mode < 0 || d->nb_mode > 2) return fail(FPT_ERR_INVALID, "bad nb_mode %d", d->nb_mode);
+    const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
+    const bool use_memo = d->nb_mode == FPT_NB_MEMO ||
+                          (d->nb_mode == FPT_NB_AUTO && sl.total_bases >= 8 * memo_n);
+    void *d_memo = nullptr;
+    if (use_memo)
+        if (int rc = ws_get(c, 8, (size_t)memo_n * 16, &d_memo)) return rc;
+    sl.memo = d_memo;
+    sl.memo_exp = c->memo_exp;
+    sl.memo_obs = c->memo_obs;
+
+    HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used] : c->ev0, c->stream));
+    if (use_memo) {  // rebuilt on every call: part of the timed work, never reused across calls
+        fptk::launch_nb_memo(c->stream, sl.model, c->memo_exp, c->memo_obs, d_memo);
+        if (int rc = launch_ok("k_nb_memo")) return rc;
+    }
     for (const launch_t &ln : launches) {
         fptk::scan_launch s2 = sl;
         s2.tile_len = ln.tile_len;
@@ -505,8 +525,45 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             if (int rc = launch_ok("k_scan_fused")) return rc;
         }
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 1] : c->ev1, c->stream));
+    if (rec) c->tev_used += 2;
+    else c->timed = true;
+    return FPT_OK;
+}
+
+int fpt_timing_enable(fpt_ctx *c, int max_records) {
+    if (int rc = check_ctx(c)) return rc;
+    if (max_records < 0 || max_records > 100000) return fail(FPT_ERR_INVALID, "bad record count");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
+    c->tev.clear();
+    c->tev_used = 0;
+    for (int i = 0; i < 2 * max_records; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->tev.push_back(e);
+    }
+    return FPT_OK;
+}
+
+int fpt_timing_read(fpt_ctx *c, float *ms_out, int cap, int *n_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!n_out || (cap > 0 && !ms_out)) return fail(FPT_ERR_INVALID, "null output");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int n = c->tev_used / 2;
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; ++i)
+        HIP_TRY(hipEventElapsedTime(&ms_out[i], c->tev[2 * i], c->tev[2 * i + 1]));
+    c->tev_used = 0;
+    return FPT_OK;
+}
+
+int fpt_set_memo_dims(fpt_ctx *c, int memo_exp, int memo_obs) {
+    if (int rc = check_ctx(c)) return rc;
+    if (memo_exp < 1 || memo_exp > 4096 || memo_obs < 1 || memo_obs > 4096)
+        return fail(FPT_ERR_INVALID, "memo dims out of range");
+    c->memo_exp = memo_exp;
+    c->memo_obs = memo_obs;
     return FPT_OK;
 }
 

@@ -261,7 +261,29 @@ struct scan_args {
     const double *model;         // 24 doubles
     double *exp_out, *obs_out, *pval_out, *winp_out;
     int32_t *status_out;
+    const double2 *memo;         // (p, z) per (exp, obs) pair, or nullptr = direct evaluation
+    int32_t memo_exp, memo_obs;
 };
+
+// (p, z) for every integer pair (exp, obs) of the table: the same device functions the
+// direct path calls, so a lookup returns bit-identical values.
+__global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ model, int memo_exp,
+                                                    int memo_obs, double2 *__restrict__ memo) {
+    __shared__ double par[24];
+    if (threadIdx.x < 24) par[threadIdx.x] = model[threadIdx.x];
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < memo_exp * memo_obs) {
+        const double ex = (double)(idx / memo_obs);
+        const int32_t k = idx % memo_obs;
+        bool zd = false;
+        double r = fptm::fit_r(par + 9, ex, &zd);
+        double mu = fptm::fit_mu(par, ex);
+        double pv = fptm::nb_cdf(k, r / (r + mu), r);
+        double z = fptm::ndtri(1.0 - pv);
+        memo[idx] = make_double2(pv, z);
+    }
+}
 
 template <int NT>
 __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_scan_fused(const scan_args a) {
@@ -368,10 +390,21 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
         bool zd = false;
         double ob = obsm[tp];
         double ex = cP[pad + 1 + tp] + cM[pad + tp];
-        double r = fptm::fit_r(par + 9, ex, &zd);
-        double mu = fptm::fit_mu(par, ex);
-        double pv = fptm::nb_cdf(fptm::c_int(ob), r / (r + mu), r);
-        double z = fptm::ndtri(1.0 - pv);
+        const int32_t k = fptm::c_int(ob);
+        double pv, z;
+        const int ei = (int)ex;
+        if (a.memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
+            k < a.memo_obs) {
+            const double2 pz = a.memo[ei * a.memo_obs + k];
+            pv = pz.x;
+            z = pz.y;
+            zd = fptm::piecewise<5>(par + 9, ex) == 0.0;  // dispersion.pyx:160-161
+        } else {
+            double r = fptm::fit_r(par + 9, ex, &zd);
+            double mu = fptm::fit_mu(par, ex);
+            pv = fptm::nb_cdf(k, r / (r + mu), r);
+            z = fptm::ndtri(1.0 - pv);
+        }
         bool fin = isfinite(z);
         zv = fin ? z : 0.0;
         zc = fin ? 0 : 1;
@@ -599,11 +632,20 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.pval_out = sl.pval_out;
     a.winp_out = sl.winp_out;
     a.status_out = sl.status_out;
+    a.memo = (const double2 *)sl.memo;
+    a.memo_exp = sl.memo_exp;
+    a.memo_obs = sl.memo_obs;
     switch (nt) {
     case 256: hipLaunchKernelGGL(k_scan_fused<256>, dim3(grid), dim3(256), lds, st, a); break;
     case 512: hipLaunchKernelGGL(k_scan_fused<512>, dim3(grid), dim3(512), lds, st, a); break;
     default: hipLaunchKernelGGL(k_scan_fused<1024>, dim3(grid), dim3(1024), lds, st, a); break;
     }
+}
+
+void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo) {
+    int n = memo_exp * memo_obs;
+    hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256), dim3(256), 0, st, model, memo_exp, memo_obs,
+                       (double2 *)memo);
 }
 
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

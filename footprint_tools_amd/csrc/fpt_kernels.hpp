@@ -29,6 +29,8 @@ struct scan_launch {
     const double *model;
     double *exp_out, *obs_out, *pval_out, *winp_out;
     int32_t *status_out;
+    const void *memo;  // double2[memo_exp * memo_obs] or nullptr
+    int32_t memo_exp, memo_obs;
 };
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
@@ -47,6 +49,7 @@ size_t scan_lds_bytes(int nc_max);
 hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu);
 hipError_t scan_set_lds(int nt, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl);
+void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);

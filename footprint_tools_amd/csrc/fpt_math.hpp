@@ -637,6 +637,9 @@ FPT_HD double nb_logpmf(int32_t k, double p, double r) {  // nbinom.pyx:99-100
 // inactive segment still poisons the sum (0 * inf = NaN); reproduced here.
 template <int NSEG>
 FPT_HD double piecewise(const double *par, double x) {
+#if defined(__clang__)
+#pragma clang fp contract(off)  // y + k*x is two roundings in the reference (an fma would miss
+#endif                          // the exact zeros that raise ZeroDivisionError there)
     double acc = 0.0;
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {

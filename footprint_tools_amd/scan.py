@@ -76,7 +76,8 @@ def shard_intervals(lengths, world_size, pad):
 
 class FootprintScanner(object):
     def __init__(self, bias_table, dispersion, half_win_width=5, smoothing_half_win_width=50,
-                 smoothing_clip=0.01, scales=(3,), default_propensity=1e-6, ctx=None):
+                 smoothing_clip=0.01, scales=(3,), default_propensity=1e-6, ctx=None,
+                 nb_mode="auto"):
         """bias_table: 4096 propensities in 2-bit order (bias_model.table());
         dispersion: object with mu_params / r_params (modeling.dispersion.dispersion_model)."""
         self.ctx = ctx or _lib.get_ctx()
@@ -89,6 +90,8 @@ class FootprintScanner(object):
         if len(self.scales) > _lib.MAX_SCALES:
             raise ValueError("at most %d scales" % _lib.MAX_SCALES)
         self.pad = self.hw + self.shw
+        # how the per-base NB p-value is evaluated (fpt_nb_mode of include/fpt.h)
+        self.nb_mode = {"auto": _lib.NB_AUTO, "direct": _lib.NB_DIRECT, "memo": _lib.NB_MEMO}[nb_mode]
 
     # ---- geometry ------------------------------------------------------------------------
     def padded_len(self, L):
@@ -120,6 +123,7 @@ class FootprintScanner(object):
         for i, s in enumerate(self.scales):
             d.scales[i] = s
         d.dm_id = ctx.dispersion_slot(self.mu, self.r)
+        d.nb_mode = self.nb_mode
         d.counts_plus, d.counts_minus, d.seq = counts_plus, counts_minus, seq
         d.exp_out, d.obs_out, d.pval_out, d.winp_out = exp_out, obs_out, pval_out, winp_out
         d.status_out = status_out

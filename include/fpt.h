@@ -138,6 +138,8 @@ typedef struct fpt_scan_desc {
     int32_t n_scales;                 /* number of Stouffer windows (detect uses one, hw=3) */
     int32_t scales[FPT_MAX_SCALES];   /* half window widths                       detect.py:84   */
     int32_t dm_id;                    /* dispersion model slot */
+    int32_t nb_mode;                  /* how p = nbinom.cdf(obs; exp) is evaluated per base:
+                                       * FPT_NB_AUTO, FPT_NB_DIRECT or FPT_NB_MEMO (see below) */
     /* inputs (DEVICE).  With pad = hw + shw, interval i of length L_i owns
      *   counts_*[ off_i + i*(2*pad+1) .. +L_i+2*pad+1 )   padded cut counts, genomic order
      *   seq     [ off_i + i*(2*pad+7) .. +L_i+2*pad+7 )   ASCII bases, 3 extra on each side
@@ -154,6 +156,20 @@ typedef struct fpt_scan_desc {
     /* optional per-interval status (DEVICE int32[n_intervals]): bit 0 = ZeroDivisionError */
     int32_t *status_out;
 } fpt_scan_desc;
+
+/* p-value evaluation modes of the fused scan.  Both give the same numbers: expected counts are
+ * integers (a sum of two round()s) and the reference truncates obs to a C int
+ * (dispersion.pyx:314), so p and z = ndtri(1-p) are functions of the integer pair (exp, obs).
+ *   DIRECT  every base evaluates hcephes incbet / ndtri itself.
+ *   MEMO    each fpt_scan_dev call first fills a (memo_exp x memo_obs) table of (p, z) with the
+ *           same device incbet/ndtri (one small launch on the same stream, so it is part of the
+ *           timed work), the scan kernel looks pairs up and falls back to DIRECT evaluation for
+ *           pairs outside the table or non-integer / non-finite exp.
+ *   AUTO    MEMO when the batch has at least 8x more bases than the table has entries. */
+enum fpt_nb_mode { FPT_NB_AUTO = 0, FPT_NB_DIRECT = 1, FPT_NB_MEMO = 2 };
+
+/* table extent for FPT_NB_MEMO (defaults 256 x 256; each in [1, 4096]) */
+int fpt_set_memo_dims(fpt_ctx *ctx, int memo_exp, int memo_obs);
 
 /* Enqueue the fused scan on the context's stream (no synchronisation). */
 int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
@@ -179,6 +195,13 @@ int fpt_memcpy_d2h(fpt_ctx *ctx, void *host, const void *dev, int64_t bytes);
 /* timing of the most recent fpt_scan_dev launch sequence measured with HIP events on the
  * context's stream (valid after fpt_ctx_synchronize): milliseconds of the fused kernel. */
 int fpt_last_scan_ms(fpt_ctx *ctx, float *ms_out);
+
+/* Per-launch timing for benchmarks: after fpt_timing_enable(ctx, n) each fpt_scan_dev records
+ * a HIP event pair on the context's stream (up to n scans; further scans fall back to the
+ * single pair behind fpt_last_scan_ms).  fpt_timing_read synchronises the stream, writes the
+ * elapsed milliseconds of the recorded scans (at most cap) and resets the record count. */
+int fpt_timing_enable(fpt_ctx *ctx, int max_records);
+int fpt_timing_read(fpt_ctx *ctx, float *ms_out, int cap, int *n_out);
 
 #ifdef __cplusplus
 }

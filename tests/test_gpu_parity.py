@@ -95,9 +95,9 @@ def test_predict_golden(fpt):
     worst = 0.0
     for c, (hw, shw, clip, l) in enumerate(g["meta"]):
         e, w = predict.predict(g["obs%d" % c], g["probs%d" % c], int(hw), int(shw), float(clip))
-        assert np.array_equal(e, g["exp%d" % c]), "exp case %d %s" % (c, g["meta"][c])
+        assert np.array_equal(e, g["exp%d" % c], equal_nan=True), "exp case %d %s" % (c, g["meta"][c])
         if g["win%d" % c].size:
-            err = float(np.max(np.abs(w - g["win%d" % c]) / np.maximum(np.abs(g["win%d" % c]), 1e-300)))
+            err = rel_err(w, g["win%d" % c])
             worst = max(worst, err)
             assert err < 1e-12, "win case %d %s err %g" % (c, g["meta"][c], err)
     print("predict: exp bit-exact on %d cases, max win rel err %.2e" % (len(g["meta"]), worst))
@@ -232,7 +232,8 @@ def test_fused_scan_config1_golden(fpt, orc):
     (260, 5, 50, 0.05, (2, 7), "A"),                 # general-k trimmed mean (k=5)
     (64, 1, 2, 0.0, (), "C"),                        # k=0, no windows
 ])
-def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm):
+@pytest.mark.parametrize("nb_mode", ["direct", "memo"])
+def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm, nb_mode):
     from footprint_tools_amd.scan import FootprintScanner
     lat = golden("nb_lattice.npz")
     table = golden("kmer_probs.npz")["table"]
@@ -244,7 +245,8 @@ def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm):
     sq[::97] = ord("N")
     sq[5::41] |= 0x20  # lower-case
     cp[: 3 * l] = 0.0  # an empty stretch: all-zero windows
-    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales)
+    cm[5 * l + 70: 5 * l + 75] = [300.0, 1e6, 2.5, -3.0, 40.0]  # obs outside the memo table / non-integer
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales, nb_mode=nb_mode)
     out = sc.scan(cp, cm, sq, interval_len=L)
     e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, clip, table, lat["mu_" + dm],
                                    lat["r_" + dm], np.array(scales, np.int32))
@@ -305,6 +307,27 @@ def test_zero_division_status(fpt, orc):
     has2 = (out["exp"].reshape(n_iv, L) == 2.0).any(1)
     assert has2.any() and not has2[2]
     assert np.array_equal(out["status"] != 0, has2)
+    sc2 = FootprintScanner(table, _DM(lat["mu_A"], r), hw, shw, 0.01, (3,), nb_mode="memo")
+    out2 = sc2.scan(cp, cm, sq, interval_len=L)
+    assert np.array_equal(out2["status"], out["status"])
+    assert np.array_equal(out2["pval"], out["pval"], equal_nan=True)
+
+
+def test_memo_equals_direct_bitwise(fpt, orc):
+    """the memo table is filled by the same device functions: identical bits, NaNs included."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    n_iv, L = 200, 500
+    outs = []
+    for mode in ("direct", "memo"):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3, 5, 10, 20, 40), nb_mode=mode)
+        l = sc.padded_len(L)
+        cp, cm = orc.synth_counts(1, 0, n_iv * l, 0), orc.synth_counts(1, 0, n_iv * l, 1)
+        cp[::501] *= 30  # a few large counts: some pairs fall outside the 256x256 table
+        outs.append(sc.scan(cp, cm, orc.synth_bases(1, 0, n_iv * (l + 6)), interval_len=L))
+    for key in ("exp", "obs", "pval", "winp"):
+        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
 
 
 # ---------------------------------------------------------------- size-independent properties at bench scale
