@@ -6,7 +6,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfpt_hip.so")
+LIB_PATH = os.environ.get("FPT_LIB_PATH") or os.path.join(HERE, "libfpt_hip.so")
 
 FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)

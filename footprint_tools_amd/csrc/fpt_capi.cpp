@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -500,6 +501,9 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     void *d_memo = nullptr;
     if (use_memo)
         if (int rc = ws_get(c, 8, (size_t)memo_n * 16, &d_memo)) return rc;
+#ifdef FPT_ABLATE
+    if (const char *e = getenv("FPT_ABLATE")) sl.ablate = atoi(e);
+#endif
     sl.memo = d_memo;
     sl.memo_exp = c->memo_exp;
     sl.memo_obs = c->memo_obs;
@@ -512,7 +516,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     for (const launch_t &ln : launches) {
         fptk::scan_launch s2 = sl;
         s2.tile_len = ln.tile_len;
-        s2.nc_max = ln.nt + 2 * pad + 1;
+        s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
         s2.tile_first = ln.first;
         size_t lds = fptk::scan_lds_bytes(s2.nc_max);
         if (lds > 160 * 1024)

@@ -48,7 +48,8 @@ struct trim_result {
 };
 
 // k == 1 (w=101, clip=0.01: the `detect` default): two smallest / two largest in one pass.
-__device__ __forceinline__ double trimmed_mean_k1(const double *x, int n) {
+// Returns the trimmed SUM (the caller divides by n - 2).
+__device__ __forceinline__ double trimmed_sum_k1(const double *x, int n) {
 #pragma clang fp contract(off)
     double lo1 = fptm::kInf, lo2 = fptm::kInf, hi1 = -fptm::kInf, hi2 = -fptm::kInf, s = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -61,18 +62,16 @@ __device__ __forceinline__ double trimmed_mean_k1(const double *x, int n) {
         hi2 = fmax(hi2, fmin(hi1, v));
         hi1 = b;
     }
-    double t;
-    if (lo2 < hi2) {
-        // OS1 < OS2: sum of sorted[1 .. n-2]
-        t = (s - lo1) - hi1;
-    } else {
-        // OS1 == OS2 == c: only the OS1 weight is applied (smoothing.h:61-69), giving
-        // (b + bm - k) * c with b = #{== c}, bm = #{< c}
-        double c = lo2;
-        double cnt = (double)(n - 1) - ((hi1 > c) ? 1.0 : 0.0);
-        t = cnt * c;
-    }
-    return t / (double)(n - 2);
+    if (lo2 < hi2) return (s - lo1) - hi1;  // OS1 < OS2: sum of sorted[1 .. n-2]
+    // OS1 == OS2 == c: only the OS1 weight is applied (smoothing.h:61-69), giving
+    // (b + bm - k) * c with b = #{== c}, bm = #{< c}
+    double c = lo2;
+    double cnt = (double)(n - 1) - ((hi1 > c) ? 1.0 : 0.0);
+    return cnt * c;
+}
+
+__device__ __forceinline__ double trimmed_mean_k1(const double *x, int n) {
+    return trimmed_sum_k1(x, n) / (double)(n - 2);
 }
 
 // general k >= 0: order statistics by walking distinct values from each end, then one
@@ -139,17 +138,87 @@ __device__ __forceinline__ double trimmed_mean(const double *x, int n, int k) {
     return trimmed_mean_general(x, n, k);
 }
 
-// ---- wave64 inclusive prefix sum (double + int) with __shfl_up
-__device__ __forceinline__ void wave_scan(double &v, int &c, int lane) {
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        double pv = __shfl_up(v, d, kWave);
-        int pc = __shfl_up(c, d, kWave);
-        if (lane >= d) {
-            v += pv;
-            c += pc;
-        }
+// ---- wave64 inclusive scans on the DPP cross-lane path of the vector ALU (no LDS traffic).
+// gfx9-family pattern: row_shr:1,2,4,8 scan each row of 16 lanes, row_bcast:15 carries rows
+// 0->1 and 2->3, row_bcast:31 carries the lower half into rows 2,3.  Lanes whose DPP source is
+// masked or out of the row receive `ident`, the identity of the operator.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_i32(int ident, int x) {
+    return __builtin_amdgcn_update_dpp(ident, x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double ident, double x) {
+    int lo = dpp_i32<CTRL, ROW_MASK, BANK_MASK>(__double2loint(ident), __double2loint(x));
+    int hi = dpp_i32<CTRL, ROW_MASK, BANK_MASK>(__double2hiint(ident), __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+struct op_add {
+    __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
+    __device__ __forceinline__ int operator()(int a, int b) const { return a + b; }
+};
+struct op_min {
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); }
+};
+struct op_max {
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+};
+
+#define FPT_DPP_SCAN_STEPS(MOV)                                      \
+    x = op(MOV<0x111, 0xf, 0xf>(ident, x), x); /* row_shr:1 */       \
+    x = op(MOV<0x112, 0xf, 0xf>(ident, x), x); /* row_shr:2 */       \
+    x = op(MOV<0x114, 0xf, 0xf>(ident, x), x); /* row_shr:4 */       \
+    x = op(MOV<0x118, 0xf, 0xf>(ident, x), x); /* row_shr:8 */       \
+    x = op(MOV<0x142, 0xa, 0xf>(ident, x), x); /* row_bcast:15 */    \
+    x = op(MOV<0x143, 0xc, 0xf>(ident, x), x); /* row_bcast:31 */
+
+template <typename Op>
+__device__ __forceinline__ double wave_scan_f64(double x, double ident, Op op) {
+    FPT_DPP_SCAN_STEPS(dpp_f64)
+    return x;
+}
+
+__device__ __forceinline__ int wave_scan_i32(int x) {
+    const int ident = 0;
+    op_add op;
+    FPT_DPP_SCAN_STEPS(dpp_i32)
+    return x;
+}
+
+// inclusive prefix sum of a (double, int) pair across the 64 lanes
+__device__ __forceinline__ void wave_scan(double &v, int &c, int /*lane*/) {
+    v = wave_scan_f64(v, 0.0, op_add());
+    c = wave_scan_i32(c);
+}
+
+// sum over [lo, hi] (lo <= hi) from per-tile inclusive prefix sums (tile = 64 positions):
+// suffix of the first tile + whole middle tiles + prefix of the last tile
+template <typename T>
+__device__ __forceinline__ T tile_range_sum(const T *ps, int lo, int hi) {
+    const int qlo = lo >> 6, qhi = hi >> 6;
+    T s = ps[hi];
+    if (qlo == qhi) {
+        if (lo & 63) s -= ps[lo - 1];
+        return s;
     }
+    for (int q = qlo + 1; q < qhi; ++q) s += ps[(q << 6) + 63];
+    T head = ps[(qlo << 6) + 63];
+    if (lo & 63) head -= ps[lo - 1];
+    return head + s;
+}
+
+// min / max over [lo, hi] spanning at least two tiles, from per-tile prefix (p) and suffix (s) scans
+__device__ __forceinline__ double tile_range_min(const double *p, const double *s, int lo, int hi) {
+    double m = fmin(s[lo], p[hi]);
+    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = fmin(m, p[(q << 6) + 63]);
+    return m;
+}
+
+__device__ __forceinline__ double tile_range_max(const double *p, const double *s, int lo, int hi) {
+    double m = fmax(s[lo], p[hi]);
+    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = fmax(m, p[(q << 6) + 63]);
+    return m;
 }
 
 }  // namespace fptd

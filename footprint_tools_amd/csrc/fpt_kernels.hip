@@ -227,15 +227,16 @@ __global__ void __launch_bounds__(256) k_window_rows(int op, const double *__res
 //   B  6-mer lookup from the LDS table, 2*hw-wide window sums of the counts, strand-merged obs
 //   C  trimmed-mean smoothing, window sum of the propensities, expected = round(P/Q*W')
 //   D  strand merge, NB lower-tail p-value, z = ndtri(1-p)      (one base per thread)
-//   E  block-wide prefix scan of z (wave64 __shfl_up + LDS carries) and per-scale
-//      Stouffer windows from prefix differences
+//   E  per-wavefront prefix scan of z (wave64 __shfl_up) published per 64-base tile, and
+//      per-scale Stouffer windows assembled from tile prefixes / totals
 // One tile per workgroup and one base per thread in D on purpose: any loop around the
 // incbet body makes the compiler hoist its ~150 fp64 coefficients into registers.
 // The hardware workgroup dispatcher balances ragged tiles.
 //
-// LDS (doubles unless noted): table[4098] par[24] carry[64] | cE+[nc] cE-[nc] P+[nc] P-[nc]
-//   W+[nc] W-[nc] obs[nc] | codes u8[nc+8];  expected counts overwrite the counts (dead after
-//   B), z / non-finite prefix arrays overwrite the window sums (dead after C).
+// LDS (doubles unless noted): table[4098] par[24] | cE+[nc] cE-[nc] P+[nc] P-[nc] W+[nc] W-[nc]
+//   xA[nc] xB[nc] | codes u8[nc+8] (nc rounded up to 64);  expected counts overwrite the counts
+//   (dead after B), z / non-finite prefix arrays overwrite the window sums (dead after C); xA/xB
+//   and the dead count arrays are the scratch of the fast smoothing path.
 // ===========================================================================
 struct scan_args {
     int64_t n_intervals;
@@ -263,7 +264,14 @@ struct scan_args {
     int32_t *status_out;
     const double2 *memo;         // (p, z) per (exp, obs) pair, or nullptr = direct evaluation
     int32_t memo_exp, memo_obs;
+    int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
+    int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
 };
+#ifdef FPT_ABLATE
+#define ABL(bit) (a.ablate & (bit))
+#else
+#define ABL(bit) 0
+#endif
 
 // (p, z) for every integer pair (exp, obs) of the table: the same device functions the
 // direct path calls, so a lookup returns bit-identical values.
@@ -286,24 +294,22 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
 }
 
 template <int NT>
-__global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_scan_fused(const scan_args a) {
+__global__ void __launch_bounds__(NT, 4) k_scan_fused(const scan_args a) {
     extern __shared__ double smem[];
     double *tbl = smem;                       // kTable + 1 (+1 pad to keep 16-B alignment)
     double *par = tbl + (kTable + 2);         // 24
-    double *wsum = par + 24;                  // wave totals / carries of the scan
-    double *cP = wsum + 64;                   // counts '+', later expected '+'
+    double *cP = par + 24;                    // counts '+', scratch in C, expected '+' for D
     double *cM = cP + a.nc_max;
-    double *pP = cM + a.nc_max;
+    double *pP = cM + a.nc_max;               // propensities
     double *pM = pP + a.nc_max;
     double *wP = pM + a.nc_max;               // window sums, later z prefix
     double *wM = wP + a.nc_max;               // window sums, later non-finite prefix (int)
-    double *obsm = wM + a.nc_max;             // strand-merged observed counts
-    uint8_t *sq = reinterpret_cast<uint8_t *>(obsm + a.nc_max);  // nc_max + 8 bytes
+    double *xA = wM + a.nc_max;               // scratch of the fast smoothing path
+    double *xB = xA + a.nc_max;
+    uint8_t *sq = reinterpret_cast<uint8_t *>(xB + a.nc_max);  // nc_max + 8 bytes
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid >> 6;
-    constexpr int NW = NT / kWave;
 
     const int hw = a.hw, shw = a.shw, pad = hw + shw;
     const int H = a.max_scale;
@@ -329,6 +335,7 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
     const int tb = min(L, t0 + tl + H);
     const int nt = tb - ta;              // positions needing p / z   (<= NT by construction)
     const int nc = nt + 2 * pad + 1;     // padded positions staged   (<= nc_max)
+    const int ncr = (nc + kWave - 1) & ~(kWave - 1);  // rounded up to whole 64-position tiles
     const int64_t cbase = out_off + iv * (int64_t)(2 * pad + 1) + ta;
     const int64_t sbase = out_off + iv * (int64_t)(2 * pad + 7) + ta;
 
@@ -341,12 +348,21 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
     }
     for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
     __syncthreads();
+    if (ABL(32)) return;
 
     // ---- B: bias lookup (bias.py:101-111), count window sums (predict.h:41-48),
-    //         strand merge of the observed counts (detect.py:121)
+    //         strand merge of the observed counts (detect.py:121; kept in a register: the
+    //         thread that owns padded position v = tid also owns output base t' = tid)
+    double ob = 0.0;
+    if (tid < nt) ob = cP[pad + 1 + tid] + cM[pad + tid];
     for (int v = tid; v < nc; v += NT) {
         int fi, ri;
-        kmer_indices(sq + v, fi, ri);
+        if (ABL(8)) {
+            fi = v & 4095;
+            ri = (v * 7) & 4095;
+        } else {
+            kmer_indices(sq + v, fi, ri);
+        }
         pP[v] = tbl[fi];
         pM[v] = tbl[ri];
         double sp = 0.0, sm = 0.0;
@@ -358,20 +374,132 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
         }
         wP[v] = sp;
         wM[v] = sm;
-        if (v < nt) obsm[v] = cP[pad + 1 + v] + cM[pad + v];
     }
     __syncthreads();
+    if (ABL(64)) return;
 
     // ---- C: smoothing (smoothing.h:107-133) + expected counts (predict.h:60-63);
     //         E overwrites the counts, which nobody reads any more
-    {
+    if (a.fast_trim) {
+        // k == 1 and w = 2*shw+1 >= 65 (the `detect` default is w = 101): the trimmed sum of a
+        // window is S - min - max unless the 2nd smallest equals the 2nd largest element
+        // (smoothing.h:61-69 then applies only one weight).  Every 64-lane wavefront owns an
+        // aligned 64-position tile, scans it with __shfl_up / __shfl_down (prefix sums, prefix
+        // and suffix minima / maxima) and publishes the result in LDS; a window is then the
+        // suffix of its first tile + whole middle tiles + the prefix of its last tile, so no
+        // carry has to cross wavefronts.  Near-constant windows (at most 4 value changes between
+        // neighbours) are the only ones that can hit the equal-order-statistics rule and are
+        // re-done element by element, so every case keeps the reference's value.
+        constexpr int MAXI = 3;
+        const int w = 2 * shw + 1;
+        const int ni = (ncr + NT - 1) / NT;  // <= MAXI (checked on the host)
+        int *chP = reinterpret_cast<int *>(xA);
+        int *chM = chP + a.nc_max;
+        double winS[2][MAXI];
+        int winC[2][MAXI];
+        // C1: tile prefix sums of W and of the neighbour-change flags, both strands
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            if (i < ni && v < ncr) {  // uniform per wavefront
+                double v0 = 0.0, v1 = 0.0;
+                int c0 = 0, c1 = 0;
+                if (v < nc) {
+                    v0 = wP[v];
+                    v1 = wM[v];
+                    if (v + 1 < nc) {
+                        c0 = wP[v + 1] != v0;
+                        c1 = wM[v + 1] != v1;
+                    }
+                }
+                wave_scan(v0, c0, lane);
+                wave_scan(v1, c1, lane);
+                cP[v] = v0;
+                cM[v] = v1;
+                chP[v] = c0;
+                chM[v] = c1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            winS[0][i] = winS[1][i] = 0.0;
+            winC[0][i] = winC[1][i] = 0;
+            if (i < ni && v >= pad && v < nc - pad) {
+                const int lo = v - shw, hi = v + shw;
+                winS[0][i] = tile_range_sum(cP, lo, hi);
+                winS[1][i] = tile_range_sum(cM, lo, hi);
+                winC[0][i] = tile_range_sum(chP, lo, hi - 1);
+                winC[1][i] = tile_range_sum(chM, lo, hi - 1);
+            }
+        }
+        __syncthreads();
+        // C2: per strand, tile prefix / suffix extrema, then the expected counts
+        double eOut[2][MAXI];
+#pragma unroll
+        for (int strand = 0; strand < 2; ++strand) {
+            const double *ws = strand ? wM : wP;
+            const double *ps = strand ? pM : pP;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int v = i * NT + tid;
+                if (i < ni && v < ncr) {
+                    // forward order for the prefixes, reversed order within the tile for the
+                    // suffixes (a suffix scan is a prefix scan of the mirrored tile)
+                    const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
+                    const bool okf = v < nc, okr = vr < nc;
+                    const double xf = okf ? ws[v] : 0.0;
+                    const double xr = okr ? ws[vr] : 0.0;
+                    cP[v] = wave_scan_f64(okf ? xf : fptm::kInf, fptm::kInf, op_min());
+                    xA[v] = wave_scan_f64(okf ? xf : -fptm::kInf, -fptm::kInf, op_max());
+                    cM[vr] = wave_scan_f64(okr ? xr : fptm::kInf, fptm::kInf, op_min());
+                    xB[vr] = wave_scan_f64(okr ? xr : -fptm::kInf, -fptm::kInf, op_max());
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int v = i * NT + tid;
+                eOut[strand][i] = 0.0;
+                if (i < ni && v >= pad && v < nc - pad) {
+#pragma clang fp contract(off)
+                    const int lo = v - shw, hi = v + shw;
+                    double t;
+                    const int nchg = winC[strand][i];
+                    if (nchg > 4) {
+                        const double lo1 = tile_range_min(cP, cM, lo, hi);
+                        const double hi1 = tile_range_max(xA, xB, lo, hi);
+                        t = (winS[strand][i] - lo1) - hi1;
+                    } else if (nchg == 0) {
+                        t = (double)(w - 1) * ws[lo];
+                    } else {
+                        t = trimmed_sum_k1(ws + lo, w);
+                    }
+                    const double wsm = ABL(1) ? ws[v] : t / (double)(w - 2);
+                    double q = 0.0;
+                    for (int j = -hw; j < hw; ++j) q += ps[v + j];
+                    eOut[strand][i] = round((ps[v] / q) * wsm);
+                }
+            }
+            __syncthreads();  // extrema buffers are reused by the other strand / overwritten by E
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            if (i < ni && v >= pad && v < nc - pad) {
+                cP[v] = eOut[0][i];
+                cM[v] = eOut[1][i];
+            }
+        }
+    } else {
         const int ne = nt + 1;  // padded positions [pad, nc-pad) per strand
         for (int idx = tid; idx < 2 * ne; idx += NT) {
             const bool minus = idx >= ne;
             const int v = pad + (minus ? idx - ne : idx);
             const double *ws = minus ? wM : wP;
             const double *ps = minus ? pM : pP;
-            double wsm = (shw > 0) ? trimmed_mean(ws + v - shw, 2 * shw + 1, a.k_trim) : ws[v];
+            double wsm = (shw > 0 && !ABL(1)) ? trimmed_mean(ws + v - shw, 2 * shw + 1, a.k_trim) : ws[v];
             double q = 0.0;
             for (int j = -hw; j < hw; ++j) q += ps[v + j];
             double e = round((ps[v] / q) * wsm);
@@ -379,6 +507,7 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
         }
     }
     __syncthreads();
+    if (ABL(128)) return;
 
     // ---- D: expected merge (detect.py:122), p-value (dispersion.pyx:311-314), z = ndtri(1-p)
     double *zb = wP;  // window sums are dead now
@@ -388,12 +517,14 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
     if (tid < nt) {
         const int tp = tid;
         bool zd = false;
-        double ob = obsm[tp];
         double ex = cP[pad + 1 + tp] + cM[pad + tp];
         const int32_t k = fptm::c_int(ob);
         double pv, z;
         const int ei = (int)ex;
-        if (a.memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
+        if (ABL(2)) {
+            pv = 0.5;
+            z = ob * 0.01;
+        } else if (a.memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
             k < a.memo_obs) {
             const double2 pz = a.memo[ei * a.memo_obs + k];
             pv = pz.x;
@@ -417,50 +548,28 @@ __global__ void __launch_bounds__(NT, NT >= 1024 ? 4 : (NT >= 512 ? 4 : 4)) k_sc
         }
         if (zd && a.status_out) atomicOr(&a.status_out[iv], 1);
     }
-    if (a.n_scales == 0) return;
+    if (a.n_scales == 0 || ABL(256)) return;
 
-    // ---- E: inclusive prefix scan of (z, non-finite count) over [0, nt), nt <= NT
+    // ---- E: tile prefix sums of (z, non-finite count); a Stouffer window is assembled from the
+    //         tiles it touches like the smoothing windows above (windowing.h:53-84)
     wave_scan(zv, zc, lane);
-    __syncthreads();  // everyone is done reading W before the prefix arrays overwrite it
-    if (lane == kWave - 1) {
-        wsum[wave] = zv;
-        wsum[32 + wave] = (double)zc;
+    if (tid < ((nt + kWave - 1) & ~(kWave - 1))) {
+        zb[tid] = zv;
+        nf[tid] = zc;
     }
     __syncthreads();
-    if (wave == 0) {
-        double tv = (lane < NW) ? wsum[lane] : 0.0;
-        int tc = (lane < NW) ? (int)wsum[32 + lane] : 0;
-        wave_scan(tv, tc, lane);
-        if (lane < NW) {
-            wsum[lane] = tv;
-            wsum[32 + lane] = (double)tc;
-        }
-    }
-    __syncthreads();
-    if (tid < nt) {
-        zb[tid] = zv + (wave > 0 ? wsum[wave - 1] : 0.0);
-        nf[tid] = zc + (wave > 0 ? (int)wsum[32 + wave - 1] : 0);
-    }
-    __syncthreads();
-
-    // ---- Stouffer windows (windowing.h:53-84; edges 1.0: windowing.pyx:51)
     for (int s = 0; s < a.n_scales; ++s) {
         const int hs = a.scales[s];
         const double rk = a.scale_sqrt[s];
         double *dst = a.winp_out + (int64_t)s * a.total_bases + out_off;
         for (int v = tid; v < tl; v += NT) {
             int t = t0 + v;
-            double res = 1.0;
+            double res = 1.0;  // edges are 1.0 (windowing.pyx:51)
             if (t >= hs && t < L - hs) {
-                int hi = t - ta + hs;
-                int lo = t - ta - hs - 1;
-                double sv = zb[hi];
-                int sc = nf[hi];
-                if (lo >= 0) {
-                    sv -= zb[lo];
-                    sc -= nf[lo];
-                }
-                res = (sc > 0) ? NAN : fptm::ndtr(-(sv / rk));
+                const int lo = t - ta - hs, hi = t - ta + hs;
+                const double sv = tile_range_sum(zb, lo, hi);
+                const int sc = tile_range_sum(nf, lo, hi);
+                res = (sc > 0) ? NAN : (ABL(4) ? sv : fptm::ndtr(-(sv / rk)));
             }
             dst[t] = res;
         }
@@ -580,7 +689,7 @@ void launch_window_rows(hipStream_t st, int op, const double *x, const double *w
 }
 
 size_t scan_lds_bytes(int nc_max) {
-    return (size_t)(kTable + 2 + 24 + 64 + 7 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
+    return (size_t)(kTable + 2 + 24 + 8 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
 }
 
 hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu) {
@@ -635,6 +744,8 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo = (const double2 *)sl.memo;
     a.memo_exp = sl.memo_exp;
     a.memo_obs = sl.memo_obs;
+    a.ablate = sl.ablate;
+    a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
     switch (nt) {
     case 256: hipLaunchKernelGGL(k_scan_fused<256>, dim3(grid), dim3(256), lds, st, a); break;
     case 512: hipLaunchKernelGGL(k_scan_fused<512>, dim3(grid), dim3(512), lds, st, a); break;

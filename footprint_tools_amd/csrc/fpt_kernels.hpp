@@ -31,6 +31,7 @@ struct scan_launch {
     int32_t *status_out;
     const void *memo;  // double2[memo_exp * memo_obs] or nullptr
     int32_t memo_exp, memo_obs;
+    int32_t ablate;
 };
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
