@@ -91,6 +91,7 @@ def main():
                     help="per-base NB p-value: exact (exp,obs) memo table rebuilt inside every step, "
                          "or direct incbet per base; at N=1 the other mode is timed too and reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
     args = ap.parse_args()
 
@@ -187,7 +188,7 @@ def main():
 
     dt, kernel_ms = measure(args.steps, args.warmup)
     other = None
-    if world == 1:  # the other evaluation mode, same workload, reported beside the headline
+    if world == 1 and not args.no_other_mode:  # the other evaluation mode, reported beside the headline
         main_mode = sc.nb_mode
         sc.nb_mode = _lib.NB_DIRECT if args.nb_mode == "memo" else _lib.NB_MEMO
         k2 = max(3, args.steps // 4)

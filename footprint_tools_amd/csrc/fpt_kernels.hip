@@ -293,7 +293,9 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
     }
 }
 
-template <int NT>
+// HWC / SHWC: compile-time half window widths (0 = take them from the arguments); the
+// `detect` defaults 5 / 50 get their own instance so the window loops unroll.
+template <int NT, int HWC, int SHWC>
 __global__ void __launch_bounds__(NT, 4) k_scan_fused(const scan_args a) {
     extern __shared__ double smem[];
     double *tbl = smem;                       // kTable + 1 (+1 pad to keep 16-B alignment)
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(NT, 4) k_scan_fused(const scan_args a) {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
 
-    const int hw = a.hw, shw = a.shw, pad = hw + shw;
+    const int hw = HWC ? HWC : a.hw, shw = SHWC ? SHWC : a.shw, pad = hw + shw;
     const int H = a.max_scale;
     const int64_t tile = a.tile_first + blockIdx.x;
 
@@ -576,9 +578,10 @@ __global__ void __launch_bounds__(NT, 4) k_scan_fused(const scan_args a) {
     }
 }
 
-template __global__ void k_scan_fused<256>(const scan_args);
-template __global__ void k_scan_fused<512>(const scan_args);
-template __global__ void k_scan_fused<1024>(const scan_args);
+#define FPT_SCAN_INSTANCES(X) X(256, 0, 0) X(512, 0, 0) X(1024, 0, 0) X(256, 5, 50) X(512, 5, 50) X(1024, 5, 50)
+#define FPT_INST(NT, H_, S_) template __global__ void k_scan_fused<NT, H_, S_>(const scan_args);
+FPT_SCAN_INSTANCES(FPT_INST)
+#undef FPT_INST
 
 // ===========================================================================
 // synthetic workload + checksum
@@ -692,20 +695,24 @@ size_t scan_lds_bytes(int nc_max) {
     return (size_t)(kTable + 2 + 24 + 8 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
 }
 
-hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu) {
+typedef void (*scan_kernel_t)(const scan_args);
+
+static scan_kernel_t scan_kernel(int nt, int hw, int shw) {
+    const bool dflt = (hw == 5 && shw == 50);
     switch (nt) {
-    case 256: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<256>, 256, lds);
-    case 512: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<512>, 512, lds);
-    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_scan_fused<1024>, 1024, lds);
+    case 256: return dflt ? k_scan_fused<256, 5, 50> : k_scan_fused<256, 0, 0>;
+    case 512: return dflt ? k_scan_fused<512, 5, 50> : k_scan_fused<512, 0, 0>;
+    default: return dflt ? k_scan_fused<1024, 5, 50> : k_scan_fused<1024, 0, 0>;
     }
 }
 
-hipError_t scan_set_lds(int nt, size_t lds) {
-    switch (nt) {
-    case 256: return hipFuncSetAttribute((const void *)k_scan_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    case 512: return hipFuncSetAttribute((const void *)k_scan_fused<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    default: return hipFuncSetAttribute((const void *)k_scan_fused<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+hipError_t scan_occupancy(int nt, int hw, int shw, size_t lds, int *blocks_per_cu) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, scan_kernel(nt, hw, shw), nt, lds);
+}
+
+hipError_t scan_set_lds(int nt, int hw, int shw, size_t lds) {
+    return hipFuncSetAttribute((const void *)scan_kernel(nt, hw, shw),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl) {
@@ -746,11 +753,7 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo_obs = sl.memo_obs;
     a.ablate = sl.ablate;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
-    switch (nt) {
-    case 256: hipLaunchKernelGGL(k_scan_fused<256>, dim3(grid), dim3(256), lds, st, a); break;
-    case 512: hipLaunchKernelGGL(k_scan_fused<512>, dim3(grid), dim3(512), lds, st, a); break;
-    default: hipLaunchKernelGGL(k_scan_fused<1024>, dim3(grid), dim3(1024), lds, st, a); break;
-    }
+    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw), dim3(grid), dim3(nt), lds, st, a);
 }
 
 void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo) {

@@ -47,8 +47,8 @@ void launch_special(hipStream_t st, int fn, const double *a, const double *b, co
 void launch_window_rows(hipStream_t st, int op, const double *x, const double *w, int64_t n_rows,
                         int n, int hw, double *out);
 size_t scan_lds_bytes(int nc_max);
-hipError_t scan_occupancy(int nt, size_t lds, int *blocks_per_cu);
-hipError_t scan_set_lds(int nt, size_t lds);
+hipError_t scan_occupancy(int nt, int hw, int shw, size_t lds, int *blocks_per_cu);
+hipError_t scan_set_lds(int nt, int hw, int shw, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl);
 void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

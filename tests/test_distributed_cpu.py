@@ -1,0 +1,80 @@
+"""world_size-2 check of the multi-GPU path's host logic on CPU (gloo): interval sharding by
+padded bases + the single all-gather that re-assembles the per-base p-value track.  The
+per-shard compute is stood in for by the CPU oracle (test infrastructure) -- the product's
+scan needs a GPU -- so this covers exactly what differs between N=1 and N>1."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from .conftest import ROOT
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["FPT_ROOT"])
+from oracle import oracle
+from footprint_tools_amd.scan import shard_intervals
+from footprint_tools_amd.distributed import allgather_track, shard_track_sizes
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = np.load(os.path.join(os.environ["FPT_ROOT"], "tests/golden/kmer_probs.npz"))
+lat = np.load(os.path.join(os.environ["FPT_ROOT"], "tests/golden/nb_lattice.npz"))
+hw, shw, clip, scales = 5, 50, 0.01, np.array([3], np.int32)
+pad = hw + shw
+mode = os.environ["FPT_MODE"]
+if mode == "uniform":
+    lens = np.full(37, 200)
+else:
+    lens = np.clip(np.random.RandomState(3).lognormal(5, .6, 41).astype(int), 50, 900)
+bounds = shard_intervals(lens if mode != "uniform" else (37, 200), world, pad)
+sizes = shard_track_sizes(lens, bounds)
+
+def run(first, last):
+    ps = []
+    pos = int((lens[:first] + 2 * pad + 7).sum())
+    for L in lens[first:last]:
+        l = int(L) + 2 * pad + 1
+        cp, cm = oracle.synth_counts(4, pos, l, 0), oracle.synth_counts(4, pos, l, 1)
+        sq = oracle.synth_bases(4, pos, l + 6)
+        pos += l + 6
+        ps.append(oracle.detect_batch(cp, cm, sq, 1, int(L), hw, shw, clip, g["table"], lat["mu_A"],
+                                      lat["r_A"], scales)[2])
+    return np.concatenate(ps) if ps else np.zeros(0)
+
+a, b = bounds[rank]
+local = torch.from_numpy(run(a, b))
+full = allgather_track(local, sizes).numpy()
+if rank == 0:
+    want = run(0, len(lens))
+    assert full.shape == want.shape and np.array_equal(full, want, equal_nan=True), "gathered track differs"
+    print("OK", mode, bounds, sizes)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["uniform", "ragged"])
+def test_shard_and_allgather_two_ranks_gloo(tmp_path, mode):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FPT_ROOT=ROOT, FPT_MODE=mode, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "OK " + mode in out.stdout
