@@ -233,13 +233,20 @@ def main():
         roof = None
         if k_ms:
             achieved = total * (rd + wr) / (k_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM bytes per launch measured with rocprofv3 --pmc (separate run, committed under
+            # profiles/), expressed like `achieved`: bytes per launch / this run's kernel time
+            traffic = traffic_bytes = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
-                traffic = json.load(open(tf)).get(cfg["name"])
+                rec = json.load(open(tf)).get(cfg["name"])
+                if rec:
+                    traffic_bytes = rec["bytes_per_launch"]
+                    traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         kernel="k_scan_fused", kernel_ms=k_ms,
+                        algorithmic_bytes_per_launch=total * (rd + wr),
+                        traffic_bytes_per_launch=traffic_bytes,
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))
         out = {
             "metric": "bases/sec per-nucleotide footprint stats",
