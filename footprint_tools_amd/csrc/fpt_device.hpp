@@ -138,6 +138,18 @@ __device__ __forceinline__ double trimmed_mean(const double *x, int n, int k) {
     return trimmed_mean_general(x, n, k);
 }
 
+// Correctly rounded t / d for a divisor whose reciprocal rd = RN(1/d) is computed once
+// (Markstein: q = RN(t*rd) is within an ulp, the remainder fma is exact, the corrected quotient
+// rounds like the true division).  Replaces the ~25-instruction IEEE divide where the divisor
+// is loop invariant (the w - 2k of the trimmed mean).
+__device__ __forceinline__ double div_invariant(double t, double d, double rd) {
+#pragma clang fp contract(off)
+    const double q = t * rd;
+    const double r = fma(-q, d, t);
+    const double q2 = fma(r, rd, q);
+    return isfinite(q) ? q2 : t / d;
+}
+
 // ---- wave64 inclusive scans on the DPP cross-lane path of the vector ALU (no LDS traffic).
 // gfx9-family pattern: row_shr:1,2,4,8 scan each row of 16 lanes, row_bcast:15 carries rows
 // 0->1 and 2->3, row_bcast:31 carries the lower half into rows 2,3.  Lanes whose DPP source is
