@@ -31,6 +31,9 @@ CONFIGS = {
     # BASELINE.json configs[1] / configs[2]
     "2": dict(name="100000x500bp_1scale", n_iv=100000, L=500, scales=(3,)),
     "3": dict(name="1000000x1kb_5scales", n_iv=1000000, L=1000, scales=(3, 5, 10, 20, 40)),
+    # BASELINE.json configs[3] shape, scaled to one GPU's share (1/8 of ~3.5M intervals):
+    # variable-length intervals, lognormal lengths clipped to [50, 2000], mean ~171 bp
+    "4": dict(name="437500xragged171bp_1scale", n_iv=437500, L=0, scales=(3,)),
     # small shapes for quick checks
     "1": dict(name="1000x500bp_5scales", n_iv=1000, L=500, scales=(3, 5, 10, 20, 40)),
 }
@@ -107,7 +110,7 @@ def main():
 
     # the CPU baseline runs first: it is plain host work and must not fork after GPU init
     base = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cfg["L"] > 0:
         base = cpu_baseline(cfg, table, DM)
 
     from footprint_tools_amd import _lib
@@ -121,15 +124,24 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = _lib.Context(local_rank)
     sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
-    l = sc.padded_len(L)
-    total = n_iv * L  # bases per rank per step
+    ragged = L == 0
+    if ragged:
+        rs = np.random.RandomState(4 + rank)
+        lens = np.clip(rs.lognormal(4.9, 0.62, n_iv), 50, 2000).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        total = int(off[-1])
+        n_counts, n_seq = sc.input_sizes(n_iv, total)
+    else:
+        l = sc.padded_len(L)
+        total = n_iv * L  # bases per rank per step
+        n_counts, n_seq = n_iv * l, n_iv * (l + 6)
 
     # ---- resident buffers: inputs generated on the device, outputs written in place
     if world > 1:
         dev = torch.device("cuda", local_rank)
-        t_cp = torch.empty(n_iv * l, dtype=torch.float64, device=dev)
-        t_cm = torch.empty(n_iv * l, dtype=torch.float64, device=dev)
-        t_sq = torch.empty(n_iv * (l + 6), dtype=torch.uint8, device=dev)
+        t_cp = torch.empty(n_counts, dtype=torch.float64, device=dev)
+        t_cm = torch.empty(n_counts, dtype=torch.float64, device=dev)
+        t_sq = torch.empty(n_seq, dtype=torch.uint8, device=dev)
         t_out = torch.empty((2 + S) * total, dtype=torch.float64, device=dev)   # exp, obs, winp[S]
         t_p = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(2)]  # p track, double-buffered
         t_gather = None if args.no_allgather else torch.empty(world * total, dtype=torch.float64, device=dev)
@@ -137,21 +149,28 @@ def main():
         p_p = [t.data_ptr() for t in t_p]
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     else:
-        d_cp, d_cm = DeviceArray(ctx, n_iv * l * 8), DeviceArray(ctx, n_iv * l * 8)
-        d_sq = DeviceArray(ctx, n_iv * (l + 6))
+        d_cp, d_cm = DeviceArray(ctx, n_counts * 8), DeviceArray(ctx, n_counts * 8)
+        d_sq = DeviceArray(ctx, n_seq)
         d_out = DeviceArray(ctx, (2 + S) * total * 8)
         d_p = [DeviceArray(ctx, total * 8)]
         p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
         p_p = [d_p[0].ptr]
     # rank r owns intervals [r*n_iv, (r+1)*n_iv) of the global synthetic job
-    sc.synth_dev(1, n_iv, L, p_cp, p_cm, p_sq, first_interval=rank * n_iv)
+    d_off = None
+    if ragged:
+        _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1 + rank, 0, n_counts, p_cp, p_cm, 0, n_seq, p_sq))
+        d_off = DeviceArray(ctx, off.nbytes).upload(off)
+    else:
+        sc.synth_dev(1, n_iv, L, p_cp, p_cm, p_sq, first_interval=rank * n_iv)
     ctx.synchronize()
 
     t8 = total * 8
 
     def step(i):
         sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_out, obs_out=p_out + t8,
-                    pval_out=p_p[i % len(p_p)], winp_out=p_out + 2 * t8 if S else None, interval_len=L)
+                    pval_out=p_p[i % len(p_p)], winp_out=p_out + 2 * t8 if S else None,
+                    interval_len=None if ragged else L, interval_off_dev=d_off.ptr if ragged else None,
+                    interval_off_host=off if ragged else None)
 
     def sync():
         if world > 1:
@@ -210,25 +229,34 @@ def main():
     if rank == 0:
         from oracle import oracle
         iv = n_iv - 1
-        g0 = rank * n_iv + iv
-        cp = oracle.synth_counts(1, g0 * l, l, 0)
-        cm = oracle.synth_counts(1, g0 * l, l, 1)
-        sq = oracle.synth_bases(1, g0 * (l + 6), l + 6)
-        e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, L, HW, SHW, CLIP, table, DM.mu_params,
+        if ragged:
+            Li, pad2 = int(lens[iv]), 2 * (HW + SHW)
+            li = Li + pad2 + 1
+            c0, s0 = int(off[iv]) + iv * (pad2 + 1), int(off[iv]) + iv * (pad2 + 7)
+            cp, cm = oracle.synth_counts(1 + rank, c0, li, 0), oracle.synth_counts(1 + rank, c0, li, 1)
+            sq = oracle.synth_bases(1 + rank, s0, li + 6)
+            o0 = int(off[iv])
+        else:
+            Li, g0 = L, rank * n_iv + iv
+            cp = oracle.synth_counts(1, g0 * l, l, 0)
+            cm = oracle.synth_counts(1, g0 * l, l, 1)
+            sq = oracle.synth_bases(1, g0 * (l + 6), l + 6)
+            o0 = iv * L
+        e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, Li, HW, SHW, CLIP, table, DM.mu_params,
                                           DM.r_params, scales)
         last = (args.steps - 1) % len(p_p)
         if world > 1:
             torch.cuda.synchronize()
-            ge = t_out[iv * L:(iv + 1) * L].cpu().numpy()
-            gp = t_p[last][iv * L:(iv + 1) * L].cpu().numpy()
+            ge = t_out[o0:o0 + Li].cpu().numpy()
+            gp = t_p[last][o0:o0 + Li].cpu().numpy()
         else:
-            ge = d_out.download(np.float64, L, iv * L * 8)
-            gp = d_p[0].download(np.float64, L, iv * L * 8)
+            ge = d_out.download(np.float64, Li, o0 * 8)
+            gp = d_p[0].download(np.float64, Li, o0 * 8)
         rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
         parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
 
     if rank == 0:
-        rd, wr = algorithmic_bytes_per_base(L, S)
+        rd, wr = algorithmic_bytes_per_base(L if not ragged else total / n_iv, S)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None
         roof = None
         if k_ms:
@@ -261,7 +289,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": cfg["name"], "intervals_per_gpu": n_iv, "interval_bp": L,
+            "config": {"workload": cfg["name"], "intervals_per_gpu": n_iv, "interval_bp": L if not ragged else "lognormal, mean %.0f, [50,2000]" % (total / n_iv),
                        "half_win_width": HW, "smoothing_half_win_width": SHW, "smoothing_clip": CLIP,
                        "stouffer_half_widths": list(scales), "bias_model": "vierstra_et_al.6mer",
                        "dispersion_model": "DM-SYNTH-A",

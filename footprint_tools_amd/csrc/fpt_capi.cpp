@@ -59,6 +59,11 @@ struct fpt_ctx {
     int tev_used = 0;
     int n_cu = 0;
     int memo_exp = 256, memo_obs = 256;
+    // tile-table cache of the last ragged batch (reused while the offsets and geometry match)
+    std::vector<int64_t> plan_off;
+    int plan_H = -1;
+    int64_t plan_tiles = 0;
+    int64_t plan_cls_count[3] = {0, 0, 0};
 };
 
 namespace {
@@ -445,51 +450,61 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             off = off_host.data();
         }
         if (d->n_intervals > 0x7fffffff) return fail(FPT_ERR_INVALID, "too many intervals");
-        std::vector<int32_t> tiv[3], tt0[3], ttl[3];
-        for (int64_t i = 0; i < d->n_intervals; ++i) {
-            int64_t L64 = off[i + 1] - off[i];
-            if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
-            int L = (int)L64;
-            if (L == 0) continue;
-            if (L <= 1024) {
-                int cls = L <= 256 ? 0 : (L <= 512 ? 1 : 2);
-                tiv[cls].push_back((int32_t)i);
-                tt0[cls].push_back(0);
-                ttl[cls].push_back(L);
-            } else {
-                for (int t0 = 0; t0 < L; t0 += split_len) {
-                    int tl = std::min(split_len, L - t0);
-                    int ta = std::max(0, t0 - H), tb = std::min(L, t0 + tl + H);
-                    int n = tb - ta;
-                    int cls = n <= 256 ? 0 : (n <= 512 ? 1 : 2);
+        const size_t n_off = (size_t)d->n_intervals + 1;
+        const bool cached = c->plan_H == H && c->plan_off.size() == n_off && c->ws[9] != nullptr &&
+                            std::memcmp(c->plan_off.data(), off, n_off * sizeof(int64_t)) == 0;
+        if (!cached) {
+            std::vector<int32_t> tiv[3], tt0[3], ttl[3];
+            for (int64_t i = 0; i < d->n_intervals; ++i) {
+                int64_t L64 = off[i + 1] - off[i];
+                if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
+                int L = (int)L64;
+                if (L == 0) continue;
+                if (L <= 1024) {
+                    int cls = L <= 256 ? 0 : (L <= 512 ? 1 : 2);
                     tiv[cls].push_back((int32_t)i);
-                    tt0[cls].push_back(t0);
-                    ttl[cls].push_back(tl);
+                    tt0[cls].push_back(0);
+                    ttl[cls].push_back(L);
+                } else {
+                    for (int t0 = 0; t0 < L; t0 += split_len) {
+                        int tl = std::min(split_len, L - t0);
+                        int ta = std::max(0, t0 - H), tb = std::min(L, t0 + tl + H);
+                        int n = tb - ta;
+                        int cls = n <= 256 ? 0 : (n <= 512 ? 1 : 2);
+                        tiv[cls].push_back((int32_t)i);
+                        tt0[cls].push_back(t0);
+                        ttl[cls].push_back(tl);
+                    }
                 }
             }
+            std::vector<int32_t> flat;
+            int64_t n_tiles = (int64_t)(tiv[0].size() + tiv[1].size() + tiv[2].size());
+            flat.reserve((size_t)n_tiles * 3);
+            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
+            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
+            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
+            void *d_new;
+            c->plan_H = -1;  // invalid while the table is being replaced
+            if (int rc = ws_get(c, 9, flat.size() * 4, &d_new)) return rc;
+            if (!flat.empty())
+                HIP_TRY(hipMemcpyAsync(d_new, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
+            c->plan_off.assign(off, off + n_off);
+            c->plan_tiles = n_tiles;
+            for (int cls = 0; cls < 3; ++cls) c->plan_cls_count[cls] = (int64_t)tiv[cls].size();
+            c->plan_H = H;
         }
         sl.total_bases = off[d->n_intervals];
         sl.interval_off = d->interval_off;
-        std::vector<int32_t> flat;
-        int64_t n_tiles = (int64_t)(tiv[0].size() + tiv[1].size() + tiv[2].size());
-        flat.reserve((size_t)n_tiles * 3);
-        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
-        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
-        for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
-        void *d_tiles;
-        if (int rc = ws_get(c, 9, flat.size() * 4, &d_tiles)) return rc;
-        if (!flat.empty())
-            HIP_TRY(hipMemcpyAsync(d_tiles, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
-        sl.tile_iv = (const int32_t *)d_tiles;
-        sl.tile_t0 = sl.tile_iv + n_tiles;
-        sl.tile_tl = sl.tile_t0 + n_tiles;
+        sl.tile_iv = (const int32_t *)c->ws[9];
+        sl.tile_t0 = sl.tile_iv + c->plan_tiles;
+        sl.tile_tl = sl.tile_t0 + c->plan_tiles;
         int64_t first = 0;
         const int cls_nt[3] = {256, 512, 1024};
         for (int cls = 0; cls < 3; ++cls) {
-            if (!tiv[cls].empty())
-                launches.push_back({cls_nt[cls], first, (int64_t)tiv[cls].size(), split_len});
-            first += (int64_t)tiv[cls].size();
+            if (c->plan_cls_count[cls] > 0)
+                launches.push_back({cls_nt[cls], first, c->plan_cls_count[cls], split_len});
+            first += c->plan_cls_count[cls];
         }
     }
 

@@ -400,6 +400,13 @@ def g6():
         out["seg%d" % k] = np.array(s, dtype=np.int64).reshape(-1, 2)
         segs.append((thr, w, int(dec)))
     out["seg_x"], out["seg_params"] = x, np.array(segs)
+    # dispersion_model.sample (dispersion.pyx:318-355): numpy's global legacy RNG, seeded
+    dm = make_dm("A")
+    sx = np.round(rs.gamma(2.0, 12.0, 60))
+    np.random.seed(12345)
+    vals, pv = dm.sample(sx, 9)
+    out["sample_x"], out["sample_vals"], out["sample_pvals"] = sx, np.asarray(vals), np.asarray(pv)
+    out["sample_seed"] = np.array(12345)
     save("fdr.npz", **out)
 
 

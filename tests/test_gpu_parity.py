@@ -450,6 +450,40 @@ def _write(tmp_path, text):
     return str(p)
 
 
+def test_sample_matches_reference_draws(fpt):
+    """dm.sample draws from numpy's global legacy RNG exactly like the reference, so a seeded
+    call reproduces the reference's sampled counts bit for bit; their p-values come from the GPU."""
+    from footprint_tools_amd.modeling import dispersion
+    g = golden("fdr.npz")
+    lat = golden("nb_lattice.npz")
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+    np.random.seed(int(g["sample_seed"]))
+    vals, pv = dm.sample(g["sample_x"], 9)
+    assert np.array_equal(vals, g["sample_vals"])
+    assert rel_err(pv, g["sample_pvals"]) < P_TOL
+
+
+def test_posterior_log_likelihood(fpt):
+    """stats/posterior.py:93-149 with the windowed NB log-likelihoods on the GPU."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    g = golden("posterior.npz")
+    lat = golden("nb_lattice.npz")
+    dms = []
+    for key in g["dm_keys"]:
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + str(key)], lat["r_" + str(key)]
+        dms.append(dm)
+    prior = posterior.compute_prior_weighted(g["fdr"], g["w"], cutoff=0.05)
+    delta = posterior.compute_delta_prior(g["obs"], g["exp"], g["fdr"], g["betas"], cutoff=0.05)
+    ll_on = posterior.log_likelihood(g["obs"], g["exp"], dms, delta=delta, w=3)
+    ll_off = posterior.log_likelihood(g["obs"], g["exp"], dms, w=3)
+    assert rel_err(ll_on, g["ll_on"]) < P_TOL and rel_err(ll_off, g["ll_off"]) < P_TOL
+    post = posterior.posterior(prior, ll_on, ll_off)
+    assert np.allclose(post, g["post"], rtol=1e-6, atol=1e-9, equal_nan=True)
+
+
 def test_argument_errors(fpt, ctx):
     from footprint_tools_amd.modeling import predict
     from footprint_tools_amd.stats import windowing
