@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 collective backend; gloo is a smoke-test mode for boxes with fewer GPUs "
+                         "than ranks (all ranks share GPU 0, the track is gathered through host memory)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,8 +123,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = _lib.Context(local_rank)
     sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
     ragged = L == 0
@@ -144,7 +152,8 @@ def main():
         t_sq = torch.empty(n_seq, dtype=torch.uint8, device=dev)
         t_out = torch.empty((2 + S) * total, dtype=torch.float64, device=dev)   # exp, obs, winp[S]
         t_p = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(2)]  # p track, double-buffered
-        t_gather = None if args.no_allgather else torch.empty(world * total, dtype=torch.float64, device=dev)
+        t_gather = None if args.no_allgather else torch.empty(
+            world * total, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         p_cp, p_cm, p_sq, p_out = t_cp.data_ptr(), t_cm.data_ptr(), t_sq.data_ptr(), t_out.data_ptr()
         p_p = [t.data_ptr() for t in t_p]
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -188,7 +197,10 @@ def main():
                 if pending[i % 2] is not None:   # buffer i%2 is still being gathered from step i-2
                     pending[i % 2].wait()
                 step(i)
-                pending[i % 2] = dist.all_gather_into_tensor(t_gather, t_p[i % 2], async_op=True)
+                if args.backend == "nccl":
+                    pending[i % 2] = dist.all_gather_into_tensor(t_gather, t_p[i % 2], async_op=True)
+                else:
+                    dist.all_gather_into_tensor(t_gather, t_p[i % 2].cpu())
             else:
                 step(i)
         for j in (0, 1):
@@ -296,7 +308,8 @@ def main():
                        "nb_pvalue": ("exact (exp,obs)->(p,z) memo table, 256x256, rebuilt by the device "
                                      "incbet inside every step; direct incbet fallback outside it"
                                      if args.nb_mode == "memo" else "direct incbet per base"),
-                       "allgather_p_track": bool(world > 1 and not args.no_allgather)},
+                       "allgather_p_track": bool(world > 1 and not args.no_allgather),
+                       "allgather_backend": (args.backend if world > 1 else None)},
             "roofline": roof,
             "cpu_baseline": base,
             "other_nb_mode": other,
