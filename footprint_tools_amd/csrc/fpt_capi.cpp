@@ -533,20 +533,32 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         fptk::launch_nb_memo(c->stream, sl.model, c->memo_exp, c->memo_obs, d_memo);
         if (int rc = launch_ok("k_nb_memo")) return rc;
     }
+    // memo mode runs two passes per size class: the light memo-only instance over every tile,
+    // then the full instance over the tiles it flagged (early exit for the others)
+    int64_t tiles_total = 0;
+    for (const launch_t &ln : launches) tiles_total = std::max(tiles_total, ln.first + ln.count);
+    void *d_redo = nullptr;
+    if (use_memo && sl.table_global) {
+        if (int rc = ws_get(c, 7, (size_t)tiles_total * sizeof(int32_t), &d_redo)) return rc;
+        HIP_TRY(hipMemsetAsync(d_redo, 0, (size_t)tiles_total * sizeof(int32_t), c->stream));
+    }
     for (const launch_t &ln : launches) {
         fptk::scan_launch s2 = sl;
         s2.tile_len = ln.tile_len;
         s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
-        s2.tile_first = ln.first;
-        size_t lds = fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0);
-        if (lds > 160 * 1024)
-            return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
-        HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, lds));
-        for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
-            int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
-            s2.tile_first = ln.first + done;
-            fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2);
-            if (int rc = launch_ok("k_scan_fused")) return rc;
+        s2.redo = (int32_t *)d_redo;
+        for (int pass = d_redo ? 0 : 1; pass < 2; ++pass) {
+            const bool memo_only = pass == 0;
+            size_t lds = fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
+            if (lds > 160 * 1024)
+                return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
+            HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, lds));
+            for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
+                int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
+                s2.tile_first = ln.first + done;
+                fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
+                if (int rc = launch_ok("k_scan_fused")) return rc;
+            }
         }
     }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 1] : c->ev1, c->stream));

@@ -147,7 +147,7 @@ __device__ __forceinline__ double div_invariant(double t, double d, double rd) {
     const double q = t * rd;
     const double r = fma(-q, d, t);
     const double q2 = fma(r, rd, q);
-    return isfinite(q) ? q2 : t / d;
+    return isfinite(q) ? q2 : q;  // d > 1, so q is non-finite only when t is (inf / NaN pass through)
 }
 
 // ---- wave64 inclusive scans on the DPP cross-lane path of the vector ALU (no LDS traffic).

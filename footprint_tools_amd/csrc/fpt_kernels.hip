@@ -266,6 +266,7 @@ struct scan_args {
     int32_t memo_exp, memo_obs;
     int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
+    int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
 };
 #ifdef FPT_ABLATE
 #define ABL(bit) (a.ablate & (bit))
@@ -299,12 +300,22 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
 // every workgroup, and stays cache resident) instead of being copied into LDS by every
 // workgroup.  Measured on config 2: 2.07 ms vs 2.75 ms with the LDS copy, because the copy
 // costs 33 KB of LDS (2 instead of 3 workgroups per CU) and ~0.4 ms of staging.
-template <int NT, int HWC, int SHWC, bool TBLG>
-__global__ void __launch_bounds__(NT, (TBLG && NT < 1024) ? 6 : 4) k_scan_fused(const scan_args a) {
+// MO ("memo only"): the instance used first in memo mode.  It has no direct incbet/ndtri body,
+// so it needs 56 instead of 76 VGPRs and 8 wavefronts per SIMD fit; the model parameters are
+// read with scalar loads and the sequence codes share LDS with a scratch array, so a 500-base
+// tile takes exactly 40 KB (4 workgroups per CU) and a 1 kb tile 72 KB (2 per CU).  A tile in
+// which some base misses the table (pair outside it, non-integer or non-finite exp) is flagged
+// in `redo` and computed again by the full instance, launched right behind on the same stream
+// over the same tiles with an early exit for unflagged ones.
+#define FPT_SCAN_WAVES(NT, TBLG, MO) ((MO) ? 8 : (((TBLG) && (NT) < 1024) ? 6 : 4))
+template <int NT, int HWC, int SHWC, bool TBLG, bool MO>
+__global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused(const scan_args a) {
     extern __shared__ double smem[];
+    if (!MO && a.redo && a.redo[a.tile_first + blockIdx.x] == 0) return;  // second pass: flagged tiles only
     const double *tbl = TBLG ? a.table : smem;  // kTable + 1 (+1 pad to keep 16-B alignment)
-    double *par = smem + (TBLG ? 0 : (kTable + 2));  // 24
-    double *cP = par + 24;                    // counts '+', scratch in C, expected '+' for D
+    double *par_lds = smem + (TBLG ? 0 : (kTable + 2));  // 24 (unused when MO)
+    const double *par = MO ? a.model : par_lds;
+    double *cP = par_lds + (MO ? 0 : 24);     // counts '+', scratch in C, expected '+' for D
     double *cM = cP + a.nc_max;
     double *pP = cM + a.nc_max;               // propensities
     double *pM = pP + a.nc_max;
@@ -312,7 +323,8 @@ __global__ void __launch_bounds__(NT, (TBLG && NT < 1024) ? 6 : 4) k_scan_fused(
     double *wM = wP + a.nc_max;               // window sums, later non-finite prefix (int)
     double *xA = wM + a.nc_max;               // scratch of the fast smoothing path
     double *xB = xA + a.nc_max;
-    uint8_t *sq = reinterpret_cast<uint8_t *>(xB + a.nc_max);  // nc_max + 8 bytes
+    // sequence codes: nc_max + 8 bytes; with MO they share xB (first written in phase C)
+    uint8_t *sq = reinterpret_cast<uint8_t *>(MO ? xB : xB + a.nc_max);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -348,7 +360,7 @@ __global__ void __launch_bounds__(NT, (TBLG && NT < 1024) ? 6 : 4) k_scan_fused(
     // ---- A: stage table, model, counts and sequence codes
     if (!TBLG)
         for (int i = tid; i <= kTable; i += NT) smem[i] = a.table[i];
-    if (tid < 24) par[tid] = a.model[tid];
+    if (!MO && tid < 24) par_lds[tid] = a.model[tid];
     for (int v = tid; v < nc; v += NT) {
         cP[v] = a.counts_plus[cbase + v];
         cM[v] = a.counts_minus[cbase + v];
@@ -538,6 +550,9 @@ __global__ void __launch_bounds__(NT, (TBLG && NT < 1024) ? 6 : 4) k_scan_fused(
             pv = pz.x;
             z = pz.y;
             zd = fptm::piecewise<5>(par + 9, ex) == 0.0;  // dispersion.pyx:160-161
+        } else if (MO) {
+            pv = z = NAN;
+            a.redo[tile] = 1;  // the full instance recomputes this tile
         } else {
             double r = fptm::fit_r(par + 9, ex, &zd);
             double mu = fptm::fit_mu(par, ex);
@@ -585,9 +600,10 @@ __global__ void __launch_bounds__(NT, (TBLG && NT < 1024) ? 6 : 4) k_scan_fused(
 }
 
 #define FPT_SCAN_INSTANCES(X) X(256, 0, 0) X(512, 0, 0) X(1024, 0, 0) X(256, 5, 50) X(512, 5, 50) X(1024, 5, 50)
-#define FPT_INST(NT, H_, S_)                                                  \
-    template __global__ void k_scan_fused<NT, H_, S_, false>(const scan_args); \
-    template __global__ void k_scan_fused<NT, H_, S_, true>(const scan_args);
+#define FPT_INST(NT, H_, S_)                                                         \
+    template __global__ void k_scan_fused<NT, H_, S_, false, false>(const scan_args); \
+    template __global__ void k_scan_fused<NT, H_, S_, true, false>(const scan_args);  \
+    template __global__ void k_scan_fused<NT, H_, S_, true, true>(const scan_args);
 FPT_SCAN_INSTANCES(FPT_INST)
 #undef FPT_INST
 
@@ -699,36 +715,34 @@ void launch_window_rows(hipStream_t st, int op, const double *x, const double *w
     }
 }
 
-size_t scan_lds_bytes(int nc_max, bool tblg) {
+size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only) {
+    if (memo_only) return (size_t)(8 * (size_t)nc_max) * sizeof(double);
     return (size_t)((tblg ? 0 : kTable + 2) + 24 + 8 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
 }
 
 typedef void (*scan_kernel_t)(const scan_args);
 
-template <bool TBLG>
+template <bool TBLG, bool MO>
 static scan_kernel_t scan_kernel_t_(int nt, bool dflt) {
     switch (nt) {
-    case 256: return dflt ? k_scan_fused<256, 5, 50, TBLG> : k_scan_fused<256, 0, 0, TBLG>;
-    case 512: return dflt ? k_scan_fused<512, 5, 50, TBLG> : k_scan_fused<512, 0, 0, TBLG>;
-    default: return dflt ? k_scan_fused<1024, 5, 50, TBLG> : k_scan_fused<1024, 0, 0, TBLG>;
+    case 256: return dflt ? k_scan_fused<256, 5, 50, TBLG, MO> : k_scan_fused<256, 0, 0, TBLG, MO>;
+    case 512: return dflt ? k_scan_fused<512, 5, 50, TBLG, MO> : k_scan_fused<512, 0, 0, TBLG, MO>;
+    default: return dflt ? k_scan_fused<1024, 5, 50, TBLG, MO> : k_scan_fused<1024, 0, 0, TBLG, MO>;
     }
 }
 
-static scan_kernel_t scan_kernel(int nt, int hw, int shw, bool tblg) {
+static scan_kernel_t scan_kernel(int nt, int hw, int shw, bool tblg, bool memo_only) {
     const bool dflt = (hw == 5 && shw == 50);
-    return tblg ? scan_kernel_t_<true>(nt, dflt) : scan_kernel_t_<false>(nt, dflt);
+    if (memo_only) return scan_kernel_t_<true, true>(nt, dflt);
+    return tblg ? scan_kernel_t_<true, false>(nt, dflt) : scan_kernel_t_<false, false>(nt, dflt);
 }
 
-hipError_t scan_occupancy(int nt, int hw, int shw, bool tblg, size_t lds, int *blocks_per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, scan_kernel(nt, hw, shw, tblg), nt, lds);
-}
-
-hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, size_t lds) {
-    return hipFuncSetAttribute((const void *)scan_kernel(nt, hw, shw, tblg),
+hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds) {
+    return hipFuncSetAttribute((const void *)scan_kernel(nt, hw, shw, tblg, memo_only),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl) {
+void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only) {
     scan_args a;
     a.n_intervals = sl.n_intervals;
     a.interval_len = sl.interval_len;
@@ -767,8 +781,9 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo_exp = sl.memo_exp;
     a.memo_obs = sl.memo_obs;
     a.ablate = sl.ablate;
+    a.redo = sl.redo;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
-    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0), dim3(grid), dim3(nt), lds, st, a);
+    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only), dim3(grid), dim3(nt), lds, st, a);
 }
 
 void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo) {

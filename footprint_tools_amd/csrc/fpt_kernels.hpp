@@ -32,6 +32,7 @@ struct scan_launch {
     const void *memo;  // double2[memo_exp * memo_obs] or nullptr
     int32_t memo_exp, memo_obs;
     int32_t ablate;
+    int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
 };
 
@@ -47,10 +48,9 @@ void launch_special(hipStream_t st, int fn, const double *a, const double *b, co
                     int64_t n, double *out);
 void launch_window_rows(hipStream_t st, int op, const double *x, const double *w, int64_t n_rows,
                         int n, int hw, double *out);
-size_t scan_lds_bytes(int nc_max, bool tblg);
-hipError_t scan_occupancy(int nt, int hw, int shw, bool tblg, size_t lds, int *blocks_per_cu);
-hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, size_t lds);
-void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl);
+size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
+hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds);
+void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
 void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
