@@ -22,7 +22,7 @@ EXPORTS = [
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
-    "fpt_set_memo_dims",
+    "fpt_set_memo_dims", "fpt_fdr_dev",
 ]
 
 
@@ -48,6 +48,24 @@ class ScanDesc(C.Structure):
         ("pval_out", C.c_void_p),
         ("winp_out", C.c_void_p),
         ("status_out", C.c_void_p),
+    ]
+
+
+class FdrDesc(C.Structure):
+    """struct fpt_fdr_desc of include/fpt.h"""
+    _fields_ = [
+        ("n_intervals", C.c_int64),
+        ("interval_len", C.c_int32),
+        ("interval_off", C.c_void_p),
+        ("base_index0", C.c_int64),
+        ("half_win_width", C.c_int32),
+        ("times", C.c_int32),
+        ("seed", C.c_uint64),
+        ("dm_id", C.c_int32),
+        ("exp", C.c_void_p),
+        ("winp", C.c_void_p),
+        ("efdr_out", C.c_void_p),
+        ("null_uniform", C.c_void_p),
     ]
 
 
@@ -86,6 +104,7 @@ def load():
         L.fpt_window.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp]
         L.fpt_special.argtypes = [vp, i32, vp, vp, vp, i64, vp]
         L.fpt_scan_dev.argtypes = [vp, C.POINTER(ScanDesc)]
+        L.fpt_fdr_dev.argtypes = [vp, C.POINTER(FdrDesc)]
         L.fpt_synth_dev.argtypes = [vp, C.c_uint64, i64, i64, vp, vp, i64, i64, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
         L.fpt_dev_alloc.argtypes = [vp, i64, C.POINTER(vp)]

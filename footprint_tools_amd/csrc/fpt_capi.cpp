@@ -594,6 +594,63 @@ int fpt_timing_read(fpt_ctx *c, float *ms_out, int cap, int *n_out) {
     return FPT_OK;
 }
 
+int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
+    if (d->dm_id < 0 || d->dm_id >= FPT_MAX_DISPERSION_MODELS || !c->have_model[d->dm_id])
+        return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id);
+    if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
+    if (d->n_intervals == 0) return FPT_OK;
+    if (d->times < 1 || d->times > 1000000) return fail(FPT_ERR_INVALID, "times %d out of range", d->times);
+    if (d->half_win_width < 0 || d->half_win_width > 200)
+        return fail(FPT_ERR_INVALID, "half window %d out of range", d->half_win_width);
+    if (!d->exp || !d->winp || !d->efdr_out) return fail(FPT_ERR_INVALID, "null track");
+    int lmax = d->interval_len;
+    if (d->interval_off) {
+        if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
+        // longest interval: the offsets live on the device, so take them back once
+        std::vector<int64_t> off((size_t)d->n_intervals + 1);
+        HIP_TRY(hipMemcpyAsync(off.data(), d->interval_off, off.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        lmax = 0;
+        for (int64_t i = 0; i < d->n_intervals; ++i) {
+            int64_t L = off[i + 1] - off[i];
+            if (L < 0) return fail(FPT_ERR_INVALID, "bad interval offsets");
+            if (L > lmax) lmax = (int)std::min<int64_t>(L, 1 << 30);
+        }
+    } else if (lmax <= 0) {
+        return fail(FPT_ERR_INVALID, "interval_len must be positive");
+    }
+    if (lmax > 4096) return fail(FPT_ERR_INVALID, "interval of %d bases: fpt_fdr_dev handles at most 4096", lmax);
+    int n2 = 64;
+    while (n2 < lmax) n2 <<= 1;
+    const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
+    void *d_memo;
+    if (int rc = ws_get(c, 8, (size_t)memo_n * 16, &d_memo)) return rc;
+    const double *model = c->d_models + (size_t)d->dm_id * kModelDoubles;
+    fptk::launch_nb_memo(c->stream, model, c->memo_exp, c->memo_obs, d_memo);
+    if (int rc = launch_ok("k_nb_memo")) return rc;
+    fptk::fdr_launch fl{};
+    fl.n_intervals = d->n_intervals;
+    fl.interval_len = d->interval_off ? 0 : d->interval_len;
+    fl.interval_off = d->interval_off;
+    fl.base_index0 = d->base_index0;
+    fl.hw = d->half_win_width;
+    fl.times = d->times;
+    fl.seed = d->seed;
+    fl.model = model;
+    fl.memo = d_memo;
+    fl.memo_exp = c->memo_exp;
+    fl.memo_obs = c->memo_obs;
+    fl.exp = d->exp;
+    fl.winp = d->winp;
+    fl.efdr = d->efdr_out;
+    fl.null_uniform = d->null_uniform;
+    fl.n2_max = n2;
+    HIP_TRY(fptk::launch_fdr(c->stream, fl));
+    return launch_ok("k_fdr_null");
+}
+
 int fpt_set_memo_dims(fpt_ctx *c, int memo_exp, int memo_obs) {
     if (int rc = check_ctx(c)) return rc;
     if (memo_exp < 1 || memo_exp > 4096 || memo_obs < 1 || memo_obs > 4096)

@@ -234,3 +234,36 @@ __device__ __forceinline__ double tile_range_max(const double *p, const double *
 }
 
 }  // namespace fptd
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11): the null draws of the
+// empirical-FDR pass are a pure function of (seed, base index, sample index).
+// ---------------------------------------------------------------------------
+namespace fptd {
+
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform in [0, 1) with 53 random bits for (seed, base, sample)
+__host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), sample, 0x66707464u /* "fptd" */,
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const uint64_t x = ((uint64_t)o[1] << 32) | o[0];
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace fptd

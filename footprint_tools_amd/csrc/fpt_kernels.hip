@@ -608,6 +608,225 @@ FPT_SCAN_INSTANCES(FPT_INST)
 #undef FPT_INST
 
 // ===========================================================================
+// k_fdr_null: empirical FDR of one interval per workgroup (cli/detect.py:132-135).
+//   1. the interval's observed window p-values are sorted in LDS (bitonic, NaN last)
+//   2. `times` null tracks: per base an inverse-CDF NB draw whose p-value (and z) is read off the
+//      (exp, obs) table, Stouffer window like phase E of the scan, and every null window
+//      p-value is ranked in the sorted observed values with a binary search + LDS histogram
+//   3. a prefix sum of the histogram gives #{null <= observed} for every base
+// The null values are never stored: 100 draws per base stay on chip.
+// ===========================================================================
+struct fdr_args {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    int64_t base_index0;
+    int32_t hw, times;
+    uint64_t seed;
+    const double *model;
+    const double2 *memo;
+    int32_t memo_exp, memo_obs;
+    const double *exp;
+    const double *winp;
+    double *efdr;
+    const double *null_uniform;
+    int32_t n2_max;      // LDS capacity: power of two >= longest interval
+    double inv_sqrt_k;
+};
+
+// smallest k with cdf(k) >= u, returned as (cdf(k), ndtri(1 - cdf(k))): inverse-CDF sampling of
+// the NB count at expected value `ex` together with the p-value of the draw.
+__device__ __forceinline__ double2 nb_inverse_cdf(const fdr_args &a, const double *par, double ex, double u) {
+    const int ei = (int)ex;
+    int lo = -1;  // largest k known to have cdf(k) < u
+    if (ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex) {
+        const double2 *row = a.memo + (size_t)ei * a.memo_obs;
+        const double2 last = row[a.memo_obs - 1];
+        if (!(last.x < u)) {  // the answer is inside the table (also taken for NaN rows)
+            int l = 0, h = a.memo_obs - 1;  // invariant: cdf(h) >= u
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (row[mid].x >= u) h = mid; else l = mid + 1;
+            }
+            return row[h];
+        }
+        lo = a.memo_obs - 1;
+    }
+    // outside the table: gallop, then bisect on the direct evaluation
+    bool zd = false;
+    const double r = fptm::fit_r(par + 9, ex, &zd);
+    const double mu = fptm::fit_mu(par, ex);
+    const double pr = r / (r + mu);
+    int step = 1, hi = lo + 1;
+    double chi = fptm::nb_cdf(hi, pr, r);
+    while (chi < u && hi < (1 << 28)) {
+        lo = hi;
+        step <<= 1;
+        hi = lo + step;
+        chi = fptm::nb_cdf(hi, pr, r);
+    }
+    while (hi - lo > 1) {
+        const int mid = lo + ((hi - lo) >> 1);
+        const double cm = fptm::nb_cdf(mid, pr, r);
+        if (cm >= u) {
+            hi = mid;
+            chi = cm;
+        } else {
+            lo = mid;
+        }
+    }
+    return make_double2(chi, fptm::ndtri(1.0 - chi));
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
+    extern __shared__ double smem[];
+    const int n2 = a.n2_max;
+    double *par = smem;                              // 24
+    double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
+    double *zb = skey + n2;                          // n2 tile prefix sums of z
+    int *sidx = reinterpret_cast<int *>(zb + n2);    // n2 original positions
+    int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z
+    int *hist = nf + n2;                             // n2 + 2 histogram / prefix
+    int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int64_t iv = blockIdx.x;
+    int64_t off;
+    int L;
+    if (a.interval_off) {
+        off = a.interval_off[iv];
+        L = (int)(a.interval_off[iv + 1] - off);
+    } else {
+        L = a.interval_len;
+        off = iv * (int64_t)L;
+    }
+    if (L <= 0) return;
+    const int Lr = (L + kWave - 1) & ~(kWave - 1);
+    int np2 = 1;
+    while (np2 < L) np2 <<= 1;
+
+    if (tid < 24) par[tid] = a.model[tid];
+    // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last)
+    for (int i = tid; i < np2; i += NT) {
+        double v = fptm::kInf;
+        int id = -1;
+        if (i < L) {
+            v = a.winp[off + i];
+            id = i;
+            if (isnan(v)) v = fptm::kInf;
+        }
+        skey[i] = v;
+        sidx[i] = id;
+    }
+    for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const double x = skey[i], y = skey[ixj];
+                    const int xi = sidx[i], yi = sidx[ixj];
+                    // ties broken by position so the order is total (pads, id -1 -> last)
+                    const bool gt = (x > y) || (x == y && (unsigned)xi > (unsigned)yi);
+                    const bool up = (i & k) == 0;
+                    if (gt == up) {
+                        skey[i] = y; skey[ixj] = x;
+                        sidx[i] = yi; sidx[ixj] = xi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // m = number of observed values that are not NaN (NaN / pads were mapped to +inf)
+    if (tid == 0) {
+        int l = 0, h = np2;
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (skey[mid] == fptm::kInf) h = mid; else l = mid + 1;
+        }
+        misc[1] = l;
+    }
+    __syncthreads();
+    const int m = misc[1];
+
+    // ---- 2. null tracks
+    const int hs = a.hw;
+    for (int s = 0; s < a.times; ++s) {
+        for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
+            double zv = 0.0;
+            int zc = 0;
+            if (t < L) {
+                const uint64_t gbase = (uint64_t)(a.base_index0 + off + t);
+                const double u = a.null_uniform ? a.null_uniform[(size_t)(off + t) * a.times + s]
+                                                : philox_uniform(a.seed, gbase, (uint32_t)s);
+                const double2 pz = nb_inverse_cdf(a, par, a.exp[off + t], u);
+                const bool fin = isfinite(pz.y);
+                zv = fin ? pz.y : 0.0;
+                zc = fin ? 0 : 1;
+            }
+            wave_scan(zv, zc, lane);
+            zb[t] = zv;
+            nf[t] = zc;
+        }
+        __syncthreads();
+        for (int t = tid; t < L; t += NT) {
+            double x = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
+            if (t >= hs && t < L - hs) {
+                const double sv = tile_range_sum(zb, t - hs, t + hs);
+                const int sc = tile_range_sum(nf, t - hs, t + hs);
+                x = (sc > 0) ? NAN : fptm::ndtr(-(sv * a.inv_sqrt_k));
+            }
+            if (isnan(x)) {
+                atomicAdd(&misc[0], 1);
+            } else {
+                int l = 0, h = m;  // first sorted observed value >= x
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (skey[mid] >= x) h = mid; else l = mid + 1;
+                }
+                atomicAdd(&hist[l], 1);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- 3. counts: inclusive prefix of the histogram (one wavefront, carried over chunks)
+    if (tid < kWave) {
+        int carry = 0;
+        for (int base = 0; base <= m; base += kWave) {
+            const int i = base + lane;
+            int v = (i <= m) ? hist[i] : 0;
+            v = wave_scan_i32(v) + carry;
+            if (i <= m) hist[i] = v;
+            carry = __shfl(v, kWave - 1, kWave);
+        }
+    }
+    __syncthreads();
+    const int n_finite = hist[m];
+    const int n_nan = misc[0];
+    const double denom = (double)L * (double)a.times;
+    for (int i = tid; i < np2; i += NT) {
+        const int pos = sidx[i];
+        if (pos < 0) continue;
+        double f = 1.0;  // NaN observed: the two-pointer walk runs to the end (utils.pyx:76)
+        if (i < m) {
+            int cnt = hist[i];
+            if (cnt == n_finite) cnt += n_nan;  // nothing finite above: the walk passes the NaNs too
+            f = (double)cnt / denom;
+            if (f > 1.0) f = 1.0;
+        }
+        a.efdr[off + pos] = f;
+    }
+}
+
+template __global__ void k_fdr_null<256>(const fdr_args);
+
+// ===========================================================================
 // synthetic workload + checksum
 // ===========================================================================
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -790,6 +1009,48 @@ void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_
     int n = memo_exp * memo_obs;
     hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256), dim3(256), 0, st, model, memo_exp, memo_obs,
                        (double2 *)memo);
+}
+
+size_t fdr_lds_bytes(int n2) {
+    return (size_t)(24 + 2 * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8) * sizeof(int);
+}
+
+hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
+    fdr_args a;
+    a.n_intervals = fl.n_intervals;
+    a.interval_len = fl.interval_len;
+    a.interval_off = fl.interval_off;
+    a.base_index0 = fl.base_index0;
+    a.hw = fl.hw;
+    a.times = fl.times;
+    a.seed = fl.seed;
+    a.model = fl.model;
+    a.memo = (const double2 *)fl.memo;
+    a.memo_exp = fl.memo_exp;
+    a.memo_obs = fl.memo_obs;
+    a.exp = fl.exp;
+    a.winp = fl.winp;
+    a.efdr = fl.efdr;
+    a.null_uniform = fl.null_uniform;
+    a.n2_max = fl.n2_max;
+    a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
+    size_t lds = fdr_lds_bytes(fl.n2_max);
+    hipError_t e = hipFuncSetAttribute((const void *)k_fdr_null<256>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    for (int64_t done = 0; done < fl.n_intervals; done += 0x7fffff00) {
+        fdr_args b = a;
+        int64_t n = fl.n_intervals - done < 0x7fffff00 ? fl.n_intervals - done : 0x7fffff00;
+        if (done) {  // later chunks: shift the interval base (uniform batches only reach this)
+            b.exp += done * (int64_t)fl.interval_len;
+            b.winp += done * (int64_t)fl.interval_len;
+            b.efdr += done * (int64_t)fl.interval_len;
+            b.base_index0 += done * (int64_t)fl.interval_len;
+            if (b.null_uniform) b.null_uniform += done * (int64_t)fl.interval_len * fl.times;
+        }
+        hipLaunchKernelGGL(k_fdr_null<256>, dim3((unsigned)n), dim3(256), lds, st, b);
+    }
+    return hipSuccess;
 }
 
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

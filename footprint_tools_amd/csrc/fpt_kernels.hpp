@@ -36,6 +36,25 @@ struct scan_launch {
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
 };
 
+struct fdr_launch {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    int64_t base_index0;
+    int32_t hw, times;
+    uint64_t seed;
+    const double *model;
+    const void *memo;
+    int32_t memo_exp, memo_obs;
+    const double *exp, *winp;
+    double *efdr;
+    const double *null_uniform;
+    int32_t n2_max;
+};
+
+hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl);
+size_t fdr_lds_bytes(int n2);
+
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
                        double *fwd, double *rev);
 void launch_predict_rows(hipStream_t st, const double *obs, const double *probs, int64_t n_rows,

@@ -182,6 +182,54 @@ class FootprintScanner(object):
         return dict(exp=flat[:total], obs=flat[total:2 * total], pval=flat[2 * total:3 * total],
                     winp=flat[3 * total:].reshape(S, total), status=status)
 
+    # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
+    def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,
+                interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None):
+        """Enqueue the null sampling + ranking on device pointers; does not synchronise."""
+        ctx = self.ctx
+        d = _lib.FdrDesc()
+        d.n_intervals = int(n_intervals)
+        d.interval_len = int(interval_len or 0)
+        d.interval_off = interval_off_dev
+        d.base_index0 = int(base_index0)
+        d.half_win_width, d.times, d.seed = int(half_win_width), int(times), int(seed)
+        d.dm_id = ctx.dispersion_slot(self.mu, self.r)
+        d.exp, d.winp, d.efdr_out, d.null_uniform = exp, winp, efdr_out, null_uniform
+        _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))
+
+    def fdr(self, exp, winp, times=100, seed=0, half_win_width=3, interval_len=None, interval_off=None,
+            base_index0=0, null_uniform=None):
+        """Empirical FDR of observed window p-values (host arrays in / out)."""
+        ctx = self.ctx
+        exp, winp = _lib.f64(exp).ravel(), _lib.f64(winp).ravel()
+        total = exp.size
+        if interval_off is not None:
+            off = np.ascontiguousarray(interval_off, dtype=np.int64)
+            n_iv = off.size - 1
+        else:
+            off, n_iv = None, total // int(interval_len)
+        bufs = []
+        try:
+            d_e = DeviceArray(ctx, max(exp.nbytes, 16)).upload(exp); bufs.append(d_e)
+            d_w = DeviceArray(ctx, max(winp.nbytes, 16)).upload(winp); bufs.append(d_w)
+            d_o = DeviceArray(ctx, max(total * 8, 16)); bufs.append(d_o)
+            d_off = d_u = None
+            if off is not None:
+                d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
+            if null_uniform is not None:
+                nu = _lib.f64(null_uniform).ravel()
+                if nu.size != total * times:
+                    raise ValueError("null_uniform needs total_bases * times values")
+                d_u = DeviceArray(ctx, nu.nbytes).upload(nu); bufs.append(d_u)
+            self.fdr_dev(n_iv, d_e.ptr, d_w.ptr, d_o.ptr, times, seed, half_win_width,
+                         interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
+                         base_index0=base_index0, null_uniform=d_u.ptr if d_u else None)
+            ctx.synchronize()
+            return d_o.download(np.float64, total)
+        finally:
+            for b in bufs:
+                b.free()
+
     # ---- synthetic workload (BASELINE.json configs 1-3) ---------------------------------
     def synth_dev(self, seed, n_intervals, interval_len, counts_plus, counts_minus, seq,
                   first_interval=0):

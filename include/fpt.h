@@ -174,6 +174,41 @@ int fpt_set_memo_dims(fpt_ctx *ctx, int memo_exp, int memo_obs);
 /* Enqueue the fused scan on the context's stream (no synchronisation). */
 int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
 
+/* ---- empirical FDR of the window p-values (cli/detect.py:132-135 for many intervals)
+ *
+ * Reference, per interval: `_, pvals_null = dm.sample(exp, times)` draws `times` NB counts per
+ * base from the model at that base's expected count and takes their lower-tail p-values
+ * (dispersion.pyx:318-355); every column of draws goes through the same Stouffer window
+ * (detect.py:133); `emperical_fdr` ranks each observed window p-value in the interval's
+ * pooled null values: efdr = min(1, #{null <= p} / (L*times)), NaN -> 1 (fdr/__init__.py:12-33,
+ * utils.pyx:52-79).
+ *
+ * Here all of that is one kernel per interval.  The draw and its p-value are taken together by
+ * inverse-CDF sampling on the (exp, obs) table of FPT_NB_MEMO: for u ~ U(0,1) the draw is the
+ * smallest k with cdf(k) >= u and its p-value is that cdf(k) (outside the table: galloping +
+ * bisection on the direct incbet).  u comes from Philox4x32-10 keyed by `seed` with counter
+ * (global base index, sample index), so results are reproducible and independent of how
+ * intervals are sharded; they are statistically, not bitwise, the reference's (numpy MT19937). */
+typedef struct fpt_fdr_desc {
+    int64_t n_intervals;
+    int32_t interval_len;             /* uniform batches (interval_off == NULL) */
+    const int64_t *interval_off;      /* ragged: DEVICE offsets into the tracks (n_intervals+1) */
+    int64_t base_index0;              /* global index of this batch's first base (RNG counter) */
+    int32_t half_win_width;           /* Stouffer window of the null tracks (detect: 3) */
+    int32_t times;                    /* fdr_shuffle_n (detect default 100) */
+    uint64_t seed;
+    int32_t dm_id;
+    const double *exp;                /* DEVICE: expected counts track */
+    const double *winp;               /* DEVICE: observed window p-values, same window */
+    double *efdr_out;                 /* DEVICE: empirical FDR track */
+    const double *null_uniform;       /* optional DEVICE [sum(L) * times] uniforms replacing Philox
+                                       * (row-major base x sample): deterministic tests */
+} fpt_fdr_desc;
+
+/* Enqueue the null sampling + ranking on the context's stream (no synchronisation).
+ * Intervals longer than 4096 bases are rejected (FPT_ERR_INVALID). */
+int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
+
 /* Fill device buffers with the synthetic workload of BASELINE.json configs 1-3:
  * counter-hash generator, element at global position p of stream s is
  * mix(mix(seed+s)+p); counts = U{0..19} as float64, bases uniform ACGT.

@@ -1059,3 +1059,100 @@ void orc_synth_fill(uint64_t seed, int64_t pos0, int64_t n, int stream, double *
         if (bases) bases[i] = (uint8_t)("ACGT"[(h >> 13) & 3u]);
     }
 }
+
+/* ------------------------------------------------------------------ empirical FDR with the
+ * library's reproducible null sampler (cli/detect.py:132-135 with the NB draws taken by
+ * inverse-CDF from Philox uniforms instead of numpy's MT19937; see include/fpt.h fpt_fdr_dev) */
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+void orc_philox_raw(uint32_t *c4, uint32_t k0, uint32_t k1) { philox4x32_10(c4, k0, k1); }
+
+double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
+    uint32_t c[4] = {(uint32_t)base, (uint32_t)(base >> 32), sample, 0x66707464u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint64_t x = ((uint64_t)c[1] << 32) | c[0];
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* smallest k with cdf(k) >= u -> cdf(k); table_k = number of tabulated k per integer exp */
+static double inverse_cdf_pvalue(const double *mu_par9, const double *r_par15, double ex, double u,
+                                 int table_exp, int table_k, double **rows) {
+    double r, mu;
+    orc_fit_r(r_par15, ex, &r);
+    mu = orc_fit_mu(mu_par9, ex);
+    double pr = r / (r + mu);
+    int lo = -1;
+    int ei = (int)ex;
+    if (ex >= 0.0 && ex < (double)table_exp && (double)ei == ex) {
+        if (!rows[ei]) {
+            rows[ei] = (double *)malloc(table_k * sizeof(double));
+            for (int k = 0; k < table_k; k++) rows[ei][k] = orc_nb_cdf(k, pr, r);
+        }
+        const double *row = rows[ei];
+        if (!(row[table_k - 1] < u)) {
+            int l = 0, h = table_k - 1;
+            while (l < h) {
+                int mid = (l + h) >> 1;
+                if (row[mid] >= u) h = mid; else l = mid + 1;
+            }
+            return row[h];
+        }
+        lo = table_k - 1;
+    }
+    int step = 1, hi = lo + 1;
+    double chi = orc_nb_cdf(hi, pr, r);
+    while (chi < u && hi < (1 << 28)) {
+        lo = hi;
+        step <<= 1;
+        hi = lo + step;
+        chi = orc_nb_cdf(hi, pr, r);
+    }
+    while (hi - lo > 1) {
+        int mid = lo + ((hi - lo) >> 1);
+        double cm = orc_nb_cdf(mid, pr, r);
+        if (cm >= u) { hi = mid; chi = cm; } else lo = mid;
+    }
+    return chi;
+}
+
+/* one interval: exp_[L], winp[L] -> efdr[L].  uniforms (L*times, base-major) may be NULL
+ * (then Philox(seed, base0 + t, s)); null_out (L*times) optionally receives the null p-values */
+void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *exp_, const double *winp,
+                  int L, int hw, int times, uint64_t seed, int64_t base0, const double *uniforms,
+                  int table_exp, int table_k, double *efdr_out, double *null_out) {
+    double **rows = (double **)calloc(table_exp > 0 ? table_exp : 1, sizeof(double *));
+    double *pn = (double *)malloc((size_t)L * times * sizeof(double));   /* [L][times] like sample() */
+    double *wn = (double *)malloc((size_t)L * times * sizeof(double));
+    double *col = (double *)malloc((size_t)L * sizeof(double));
+    double *wcol = (double *)malloc((size_t)L * sizeof(double));
+    for (int t = 0; t < L; t++)
+        for (int s = 0; s < times; s++) {
+            double u = uniforms ? uniforms[(size_t)t * times + s]
+                                : orc_philox_uniform(seed, (uint64_t)(base0 + t), (uint32_t)s);
+            pn[(size_t)t * times + s] = inverse_cdf_pvalue(mu_par9, r_par15, exp_[t], u, table_exp,
+                                                           table_k, rows);
+        }
+    /* detect.py:133: np.apply_along_axis(win_pval_fn, 0, pvals_null) */
+    for (int s = 0; s < times; s++) {
+        for (int t = 0; t < L; t++) col[t] = pn[(size_t)t * times + s];
+        orc_window(ORC_WIN_STOUFFER, col, NULL, L, hw, wcol);
+        for (int t = 0; t < L; t++) wn[(size_t)t * times + s] = wcol[t];
+    }
+    if (null_out) memcpy(null_out, wn, (size_t)L * times * sizeof(double));
+    orc_emperical_fdr(wn, (int64_t)L * times, winp, L, efdr_out);
+    for (int i = 0; i < table_exp; i++) free(rows[i]);
+    free(rows); free(pn); free(wn); free(col); free(wcol);
+}

@@ -105,6 +105,13 @@ int orc_detect_batch(const double *counts_plus, const double *counts_minus, cons
 int orc_log_likelihood_row(const double *mu_par9, const double *r_par15, const double *obs,
                            const double *exp, const double *delta, int n, int w, double *out);
 
+/* ---- empirical FDR with the library's reproducible (Philox, inverse-CDF) null sampler */
+void orc_philox_raw(uint32_t *c4, uint32_t k0, uint32_t k1); /* Philox4x32-10 */
+double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample);
+void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *exp_, const double *winp,
+                  int L, int hw, int times, uint64_t seed, int64_t base0, const double *uniforms,
+                  int table_exp, int table_k, double *efdr_out, double *null_out);
+
 /* ---- synthetic inputs (bench-defined): splitmix64 counter hash */
 uint64_t orc_splitmix64(uint64_t x);
 void orc_synth_fill(uint64_t seed, int64_t pos0, int64_t n, int stream, double *counts,

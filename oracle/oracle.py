@@ -67,6 +67,10 @@ def lib():
                                        C.c_double, f64p, C.c_double, f64p, f64p, i32p, C.c_int,
                                        f64p, f64p, f64p, f64p, C.c_int]
         L.orc_log_likelihood_row.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int, C.c_int, f64p]
+        L.orc_philox_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.orc_philox_uniform.restype = C.c_double
+        L.orc_fdr_null.argtypes = [f64p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64,
+                                   C.c_void_p, C.c_int, C.c_int, f64p, C.c_void_p]
         L.orc_synth_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                      C.c_void_p]
         _LIB = L
@@ -219,6 +223,22 @@ def log_likelihood_row(mu_par, r_par, obs, exp, delta, w):
     if lib().orc_log_likelihood_row(_f(mu_par), _f(r_par), obs, exp, delta, obs.size, w, out):
         raise ZeroDivisionError("float division")
     return out
+
+
+def fdr_null(mu_par, r_par, exp, winp, hw, times, seed, base0=0, uniforms=None, table=(256, 256),
+             return_null=False):
+    """One interval of the reproducible empirical-FDR pass (see fpt_fdr_dev in include/fpt.h)."""
+    exp, winp = _f(exp), _f(winp)
+    L = exp.size
+    out = np.empty(L)
+    nul = np.empty((L, times)) if return_null else None
+    up = None
+    if uniforms is not None:
+        uniforms = _f(uniforms)
+        up = uniforms.ctypes.data
+    lib().orc_fdr_null(_f(mu_par), _f(r_par), exp, winp, L, hw, times, seed, base0, up, table[0], table[1],
+                       out, nul.ctypes.data if return_null else None)
+    return (out, nul) if return_null else out
 
 
 def synth_counts(seed, pos0, n, stream):

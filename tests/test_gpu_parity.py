@@ -484,6 +484,72 @@ def test_posterior_log_likelihood(fpt):
     assert np.allclose(post, g["post"], rtol=1e-6, atol=1e-9, equal_nan=True)
 
 
+# ---------------------------------------------------------------- A10: empirical FDR on the device
+def _scan_small(orc, n_iv, L, seed, dm="A", bump=None):
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), 5, 50, 0.01, (3,))
+    l = sc.padded_len(L)
+    cp, cm = orc.synth_counts(seed, 0, n_iv * l, 0), orc.synth_counts(seed, 0, n_iv * l, 1)
+    if bump is not None:
+        cp[bump] *= 40
+    out = sc.scan(cp, cm, orc.synth_bases(seed, 0, n_iv * (l + 6)), interval_len=L)
+    return sc, lat, out
+
+
+def test_fdr_null_vs_oracle(fpt, orc):
+    """fpt_fdr_dev against the oracle restatement with the same Philox uniforms: only ranks that
+    sit within rounding of an observed value may differ (a count of 1 in L*times)."""
+    n_iv, L, times = 5, 300, 60
+    sc, lat, out = _scan_small(orc, n_iv, L, 21, bump=slice(1000, 1400, 7))  # some exp beyond the table
+    winp = out["winp"][0].copy()
+    winp[17] = np.nan
+    ef = sc.fdr(out["exp"], winp, times=times, seed=99, interval_len=L, base_index0=1000)
+    assert (out["exp"] >= 256).any()
+    for i in range(n_iv):
+        sl = slice(i * L, (i + 1) * L)
+        want = orc.fdr_null(lat["mu_A"], lat["r_A"], out["exp"][sl], winp[sl], 3, times, seed=99,
+                            base0=1000 + i * L)
+        assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (L * times), i
+    assert ef[17] == 1.0
+
+
+def test_fdr_null_given_uniforms_and_ragged(fpt, orc):
+    n_iv, L, times = 4, 260, 25
+    sc, lat, out = _scan_small(orc, n_iv, L, 8)
+    lens = np.array([100, 260, 37, 643])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp, winp = out["exp"][:off[-1]].copy(), out["winp"][0][:off[-1]].copy()
+    from footprint_tools_amd.stats import windowing
+    for a, b in zip(off[:-1], off[1:]):  # window p-values of the re-cut intervals
+        winp[a:b] = windowing.stouffers_z(np.ascontiguousarray(out["pval"][a:b]), 3)
+    u = np.random.RandomState(2).uniform(0, 1, (off[-1], times))
+    ef = sc.fdr(exp, winp, times=times, interval_off=off, null_uniform=u)
+    for a, b in zip(off[:-1], off[1:]):
+        want = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[a:b], winp[a:b], 3, times, seed=0, uniforms=u[a:b])
+        assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times)
+
+
+def test_fdr_null_vs_reference_sampler(fpt, orc):
+    """statistical agreement with the reference procedure (numpy negative_binomial draws through
+    dm.sample, windows, emperical_fdr): Monte-Carlo noise only."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import fdr, windowing
+    n_iv, L, times = 1, 500, 300
+    sc, lat, out = _scan_small(orc, n_iv, L, 5)
+    ef = sc.fdr(out["exp"], out["winp"][0], times=times, seed=1, interval_len=L)
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+    np.random.seed(3)
+    _, pn = dm.sample(out["exp"], times)
+    wn = np.apply_along_axis(lambda z: windowing.stouffers_z(np.ascontiguousarray(z), 3), 0, pn)
+    ref = fdr.emperical_fdr(wn, out["winp"][0])
+    d = np.abs(ef - ref)
+    print("efdr gpu vs reference sampler: mean |d| %.4f max %.4f" % (d.mean(), d.max()))
+    assert d.mean() < 0.004 and d.max() < 0.03
+
+
 def test_argument_errors(fpt, ctx):
     from footprint_tools_amd.modeling import predict
     from footprint_tools_amd.stats import windowing

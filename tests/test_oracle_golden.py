@@ -209,3 +209,41 @@ def test_synth_generator_matches_numpy_definition(orc):
     for stream in (0, 1):
         assert np.array_equal(orc.synth_counts(7, 12345, 999, stream), ns["synth"](7, 12345, 999, stream))
     assert np.array_equal(orc.synth_bases(7, 5, 777), ns["synth"](7, 5, 777, 2))
+
+
+def test_philox_known_answers(orc):
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors)."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_philox_raw.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    for ctr, key, want in [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]:
+        c = (C.c_uint32 * 4)(*ctr)
+        L.orc_philox_raw(c, key[0], key[1])
+        assert tuple(c) == want
+    u = [L.orc_philox_uniform(5, b, s) for b in range(50) for s in range(40)]
+    assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.03
+
+
+def test_fdr_null_oracle_matches_reference_statistically(orc):
+    """the reproducible inverse-CDF null sampler gives the same empirical FDR as the reference's
+    numpy sampler up to Monte-Carlo noise (one interval, 400 draws per base)."""
+    lat = golden("nb_lattice.npz")
+    g = golden("e2e_cfg1.npz")
+    exp, winp = g["exp"][0], g["winp"][0][0]
+    L, times = exp.size, 400
+    ef = orc.fdr_null(lat["mu_A"], lat["r_A"], exp, winp, 3, times, seed=3)
+    rs = np.random.RandomState(0)
+    r = np.array([orc.fit_r(lat["r_A"], x) for x in exp])
+    mu = np.array([orc.fit_mu(lat["mu_A"], x) for x in exp])
+    pn = np.empty((L, times))
+    for i in range(L):  # dispersion.pyx:349-353
+        k = rs.negative_binomial(r[i], r[i] / (r[i] + mu[i]), times)
+        pn[i] = orc.nb_values("cdf", lat["mu_A"], lat["r_A"], np.full(times, exp[i]), k.astype(float))
+    wn = np.stack([orc.window("stouffers_z", pn[:, s].copy(), 3) for s in range(times)], axis=1)
+    ref = orc.emperical_fdr(wn, winp)
+    assert np.mean(np.abs(ef - ref)) < 0.004 and np.max(np.abs(ef - ref)) < 0.03
