@@ -215,15 +215,16 @@ def main():
         t0 = time.perf_counter()
         run_steps(steps)
         sync()
-        return time.perf_counter() - t0, ctx.timing_read()
+        seq_ms, main_ms = ctx.timing_read()
+        return time.perf_counter() - t0, main_ms, seq_ms
 
-    dt, kernel_ms = measure(args.steps, args.warmup)
+    dt, kernel_ms, seq_ms = measure(args.steps, args.warmup)
     other = None
     if world == 1 and not args.no_other_mode:  # the other evaluation mode, reported beside the headline
         main_mode = sc.nb_mode
         sc.nb_mode = _lib.NB_DIRECT if args.nb_mode == "memo" else _lib.NB_MEMO
         k2 = max(3, args.steps // 4)
-        dt2, kms2 = measure(k2, 1)
+        dt2, kms2, _ = measure(k2, 1)
         other = dict(nb_pvalue="direct incbet per base" if args.nb_mode == "memo" else "memo table",
                      value=total * k2 / dt2, unit="bases/s", ms_per_step=dt2 / k2 * 1e3,
                      kernel_ms=float(np.mean(kms2)), steps=k2)
@@ -284,7 +285,9 @@ def main():
                     traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                        kernel="k_scan_fused", kernel_ms=k_ms,
+                        kernel=("k_scan_fused<NT,HW,SHW,table=L2,memo_only> (first pass of the step)"
+                                if args.nb_mode == "memo" else "k_scan_fused<NT,HW,SHW,table=L2,full>"),
+                        kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),
                         traffic_bytes_per_launch=traffic_bytes,
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))

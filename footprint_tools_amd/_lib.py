@@ -213,11 +213,14 @@ class Context(object):
         check(self.L.fpt_timing_enable(self.h, int(max_records)))
 
     def timing_read(self, cap=100000):
-        """Milliseconds of each scan recorded since timing_enable / the last read (synchronises)."""
-        buf = np.zeros(cap, dtype=np.float32)
+        """(sequence_ms, dominant_pass_ms) arrays of the scans recorded since timing_enable /
+        the last read (synchronises)."""
+        buf = np.zeros(2 * cap, dtype=np.float32)
         n = C.c_int(0)
         check(self.L.fpt_timing_read(self.h, buf.ctypes.data, cap, C.byref(n)))
-        return buf[:min(n.value, cap)].astype(np.float64)
+        m = min(n.value, cap)
+        pairs = buf[:2 * m].astype(np.float64).reshape(m, 2)
+        return pairs[:, 0], pairs[:, 1]
 
 
 _default = None

@@ -508,7 +508,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         }
     }
 
-    const bool rec = c->tev_used + 2 <= (int)c->tev.size();
+    const bool rec = c->tev_used + 4 <= (int)c->tev.size();
     if (d->nb_mode < 0 || d->nb_mode > 2) return fail(FPT_ERR_INVALID, "bad nb_mode %d", d->nb_mode);
     const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
     const bool use_memo = d->nb_mode == FPT_NB_MEMO ||
@@ -542,13 +542,17 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         if (int rc = ws_get(c, 7, (size_t)tiles_total * sizeof(int32_t), &d_redo)) return rc;
         HIP_TRY(hipMemsetAsync(d_redo, 0, (size_t)tiles_total * sizeof(int32_t), c->stream));
     }
-    for (const launch_t &ln : launches) {
-        fptk::scan_launch s2 = sl;
-        s2.tile_len = ln.tile_len;
-        s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
-        s2.redo = (int32_t *)d_redo;
-        for (int pass = d_redo ? 0 : 1; pass < 2; ++pass) {
-            const bool memo_only = pass == 0;
+    // pass 0 (memo mode only): memo-only instance over every tile; pass 1: full instance (over
+    // the flagged tiles in memo mode, over everything in direct mode)
+    for (int pass = d_redo ? 0 : 1; pass < 2; ++pass) {
+        const bool memo_only = pass == 0;
+        const bool main_pass = memo_only || !d_redo;
+        if (rec && main_pass) HIP_TRY(hipEventRecord(c->tev[c->tev_used + 1], c->stream));
+        for (const launch_t &ln : launches) {
+            fptk::scan_launch s2 = sl;
+            s2.tile_len = ln.tile_len;
+            s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
+            s2.redo = (int32_t *)d_redo;
             size_t lds = fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)
                 return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
@@ -560,9 +564,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
                 if (int rc = launch_ok("k_scan_fused")) return rc;
             }
         }
+        if (rec && main_pass) HIP_TRY(hipEventRecord(c->tev[c->tev_used + 2], c->stream));
     }
-    HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 1] : c->ev1, c->stream));
-    if (rec) c->tev_used += 2;
+    HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 3] : c->ev1, c->stream));
+    if (rec) c->tev_used += 4;
     else c->timed = true;
     return FPT_OK;
 }
@@ -574,7 +579,7 @@ int fpt_timing_enable(fpt_ctx *c, int max_records) {
     for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
     c->tev.clear();
     c->tev_used = 0;
-    for (int i = 0; i < 2 * max_records; ++i) {
+    for (int i = 0; i < 4 * max_records; ++i) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         c->tev.push_back(e);
@@ -586,10 +591,12 @@ int fpt_timing_read(fpt_ctx *c, float *ms_out, int cap, int *n_out) {
     if (int rc = check_ctx(c)) return rc;
     if (!n_out || (cap > 0 && !ms_out)) return fail(FPT_ERR_INVALID, "null output");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int n = c->tev_used / 2;
+    int n = c->tev_used / 4;
     *n_out = n;
-    for (int i = 0; i < n && i < cap; ++i)
-        HIP_TRY(hipEventElapsedTime(&ms_out[i], c->tev[2 * i], c->tev[2 * i + 1]));
+    for (int i = 0; i < n && i < cap; ++i) {
+        HIP_TRY(hipEventElapsedTime(&ms_out[2 * i], c->tev[4 * i], c->tev[4 * i + 3]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[2 * i + 1], c->tev[4 * i + 1], c->tev[4 * i + 2]));
+    }
     c->tev_used = 0;
     return FPT_OK;
 }

@@ -232,9 +232,11 @@ int fpt_memcpy_d2h(fpt_ctx *ctx, void *host, const void *dev, int64_t bytes);
 int fpt_last_scan_ms(fpt_ctx *ctx, float *ms_out);
 
 /* Per-launch timing for benchmarks: after fpt_timing_enable(ctx, n) each fpt_scan_dev records
- * a HIP event pair on the context's stream (up to n scans; further scans fall back to the
- * single pair behind fpt_last_scan_ms).  fpt_timing_read synchronises the stream, writes the
- * elapsed milliseconds of the recorded scans (at most cap) and resets the record count. */
+ * HIP events on the context's stream (up to n scans; further scans fall back to the single
+ * pair behind fpt_last_scan_ms).  fpt_timing_read synchronises the stream and writes TWO floats
+ * per recorded scan (at most cap scans): the milliseconds of the whole launch sequence (memo
+ * table build + scan passes) and of the dominant pass alone (the memo-only k_scan_fused
+ * instance in memo mode, the full instance in direct mode); it resets the record count. */
 int fpt_timing_enable(fpt_ctx *ctx, int max_records);
 int fpt_timing_read(fpt_ctx *ctx, float *ms_out, int cap, int *n_out);
 

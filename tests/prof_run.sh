@@ -33,18 +33,23 @@ print()
 print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
 for f in glob.glob("$OUT/trace/*/*_kernel_stats.csv"):
     print(open(f).read())
-print("== rocprofv3 --pmc passes, per dispatch of k_scan_fused (mean over dispatches)")
-agg = collections.defaultdict(list)
+print("== rocprofv3 --pmc passes, per dispatch (mean over dispatches), by kernel")
+per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         if "scan_fused" in row["Kernel_Name"]:
-            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k in sorted(agg):
-    v = agg[k]
-    print("%-24s n=%d mean=%.6g min=%.6g max=%.6g" % (k, len(v), sum(v)/len(v), min(v), max(v)))
+            per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+agg = collections.defaultdict(float)
+for name in sorted(per):
+    print("--", name)
+    for k in sorted(per[name]):
+        v = per[name][k]
+        print("   %-24s n=%d mean=%.6g min=%.6g max=%.6g" % (k, len(v), sum(v)/len(v), min(v), max(v)))
+        agg[k] += sum(v) / len(v)
 if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
-    f, w = sum(agg["FETCH_SIZE"])/len(agg["FETCH_SIZE"]), sum(agg["WRITE_SIZE"])/len(agg["WRITE_SIZE"])
+    f, w = agg["FETCH_SIZE"], agg["WRITE_SIZE"]
     print()
+    print("(summed over the k_scan_fused instances of one step)")
     print("HBM traffic per launch (MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB;")
     print("on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read -> doubled):")
     print("  read  = 2 * %.6g KiB = %.4f GB" % (f, 2 * f * 1024 / 1e9))
