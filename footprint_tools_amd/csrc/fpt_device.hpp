@@ -198,6 +198,43 @@ __device__ __forceinline__ int wave_scan_i32(int x) {
     return x;
 }
 
+struct op_min_i {
+    __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; }
+};
+struct op_max_i {
+    __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+
+template <typename Op>
+__device__ __forceinline__ int wave_scan_i32_op(int x, int ident, Op op) {
+    FPT_DPP_SCAN_STEPS(dpp_i32)
+    return x;
+}
+
+// typed front-ends: the smoothing phase runs its scans either on doubles or, when every window
+// sum of the tile is a small integer (cut counts are), on int32, where a DPP scan step is one
+// v_add/v_min/v_max with a DPP operand instead of 5-7 instructions for a 64-bit value
+__device__ __forceinline__ double scan_add(double x) { return wave_scan_f64(x, 0.0, op_add()); }
+__device__ __forceinline__ int scan_add(int x) { return wave_scan_i32(x); }
+__device__ __forceinline__ double scan_min(double x) { return wave_scan_f64(x, fptm::kInf, op_min()); }
+__device__ __forceinline__ int scan_min(int x) { return wave_scan_i32_op(x, 0x7fffffff, op_min_i()); }
+__device__ __forceinline__ double scan_max(double x) { return wave_scan_f64(x, -fptm::kInf, op_max()); }
+__device__ __forceinline__ int scan_max(int x) { return wave_scan_i32_op(x, (int)0x80000000, op_max_i()); }
+
+template <typename T> struct scan_lim;
+template <> struct scan_lim<double> {
+    static __device__ __forceinline__ double hi() { return fptm::kInf; }
+    static __device__ __forceinline__ double lo() { return -fptm::kInf; }
+    static __device__ __forceinline__ double pick_min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double pick_max(double a, double b) { return fmax(a, b); }
+};
+template <> struct scan_lim<int> {
+    static __device__ __forceinline__ int hi() { return 0x7fffffff; }
+    static __device__ __forceinline__ int lo() { return (int)0x80000000; }
+    static __device__ __forceinline__ int pick_min(int a, int b) { return a < b ? a : b; }
+    static __device__ __forceinline__ int pick_max(int a, int b) { return a > b ? a : b; }
+};
+
 // inclusive prefix sum of a (double, int) pair across the 64 lanes
 __device__ __forceinline__ void wave_scan(double &v, int &c, int /*lane*/) {
     v = wave_scan_f64(v, 0.0, op_add());
@@ -221,15 +258,17 @@ __device__ __forceinline__ T tile_range_sum(const T *ps, int lo, int hi) {
 }
 
 // min / max over [lo, hi] spanning at least two tiles, from per-tile prefix (p) and suffix (s) scans
-__device__ __forceinline__ double tile_range_min(const double *p, const double *s, int lo, int hi) {
-    double m = fmin(s[lo], p[hi]);
-    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = fmin(m, p[(q << 6) + 63]);
+template <typename T>
+__device__ __forceinline__ T tile_range_min(const T *p, const T *s, int lo, int hi) {
+    T m = scan_lim<T>::pick_min(s[lo], p[hi]);
+    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = scan_lim<T>::pick_min(m, p[(q << 6) + 63]);
     return m;
 }
 
-__device__ __forceinline__ double tile_range_max(const double *p, const double *s, int lo, int hi) {
-    double m = fmax(s[lo], p[hi]);
-    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = fmax(m, p[(q << 6) + 63]);
+template <typename T>
+__device__ __forceinline__ T tile_range_max(const T *p, const T *s, int lo, int hi) {
+    T m = scan_lim<T>::pick_max(s[lo], p[hi]);
+    for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = scan_lim<T>::pick_max(m, p[(q << 6) + 63]);
     return m;
 }
 

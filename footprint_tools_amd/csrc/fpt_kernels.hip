@@ -300,6 +300,131 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
 // every workgroup, and stays cache resident) instead of being copied into LDS by every
 // workgroup.  Measured on config 2: 2.07 ms vs 2.75 ms with the LDS copy, because the copy
 // costs 33 KB of LDS (2 instead of 3 workgroups per CU) and ~0.4 ms of staging.
+// Fast smoothing + expected counts of one tile (phase C of k_scan_fused) for k == 1 and
+// w = 2*shw+1 >= 65 (the `detect` default is w = 101): the trimmed sum of a window is
+// S - min - max unless the 2nd smallest equals the 2nd largest element (smoothing.h:61-69 then
+// applies only one weight).  Every 64-lane wavefront owns an aligned 64-position tile, scans it
+// on the DPP path (prefix sums, prefix and suffix minima / maxima) and publishes the result in
+// LDS; a window is then the suffix of its first tile + whole middle tiles + the prefix of its
+// last tile, so no carry has to cross wavefronts.  Near-constant windows (at most 4 value
+// changes between neighbours) are the only ones that can hit the equal-order-statistics rule and
+// are re-done element by element, so every case keeps the reference's value.
+// T = int when every window sum of the tile is an integer of magnitude <= 2^24 (cut counts
+// are): the same scans on int32 are exact and cost a third of the instructions; T = double
+// otherwise.  Each thread owns padded positions v = tid + i*NT.
+template <int NT, typename T>
+__device__ __forceinline__ void smooth_expected_fast(const double *wP, const double *wM, const double *pP,
+                                                     const double *pM, double *cP, double *cM, double *xA,
+                                                     double *xB, int nc, int ncr, int nc_max, int pad,
+                                                     int hw, int shw, bool skip_trim) {
+    constexpr int MAXI = 3;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int w = 2 * shw + 1;
+    const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
+    const int ni = (ncr + NT - 1) / NT;  // <= MAXI (checked on the host)
+    T *b0 = reinterpret_cast<T *>(cP), *b1 = reinterpret_cast<T *>(cM);
+    T *b2 = reinterpret_cast<T *>(xA), *b3 = reinterpret_cast<T *>(xB);
+    int *chP = reinterpret_cast<int *>(xA);
+    int *chM = chP + nc_max;
+    double winS[2][MAXI];
+    int winC[2][MAXI];
+    // C1: tile prefix sums of W and of the neighbour-change flags, both strands
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int v = i * NT + tid;
+        if (i < ni && v < ncr) {  // uniform per wavefront
+            T v0 = 0, v1 = 0;
+            int c0 = 0, c1 = 0;
+            if (v < nc) {
+                const double d0 = wP[v], d1 = wM[v];
+                v0 = (T)d0;
+                v1 = (T)d1;
+                if (v + 1 < nc) {
+                    c0 = wP[v + 1] != d0;
+                    c1 = wM[v + 1] != d1;
+                }
+            }
+            b0[v] = scan_add(v0);
+            b1[v] = scan_add(v1);
+            chP[v] = scan_add(c0);
+            chM[v] = scan_add(c1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int v = i * NT + tid;
+        winS[0][i] = winS[1][i] = 0.0;
+        winC[0][i] = winC[1][i] = 0;
+        if (i < ni && v >= pad && v < nc - pad) {
+            const int lo = v - shw, hi = v + shw;
+            winS[0][i] = (double)tile_range_sum(b0, lo, hi);
+            winS[1][i] = (double)tile_range_sum(b1, lo, hi);
+            winC[0][i] = tile_range_sum(chP, lo, hi - 1);
+            winC[1][i] = tile_range_sum(chM, lo, hi - 1);
+        }
+    }
+    __syncthreads();
+    // C2: per strand, tile prefix / suffix extrema, then the expected counts
+    double eOut[2][MAXI];
+#pragma unroll
+    for (int strand = 0; strand < 2; ++strand) {
+        const double *ws = strand ? wM : wP;
+        const double *ps = strand ? pM : pP;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            if (i < ni && v < ncr) {
+                // forward order for the prefixes, reversed order within the tile for the
+                // suffixes (a suffix scan is a prefix scan of the mirrored tile)
+                const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
+                const bool okf = v < nc, okr = vr < nc;
+                const T xf = okf ? (T)ws[v] : (T)0;
+                const T xr = okr ? (T)ws[vr] : (T)0;
+                b0[v] = scan_min(okf ? xf : scan_lim<T>::hi());
+                b2[v] = scan_max(okf ? xf : scan_lim<T>::lo());
+                b1[vr] = scan_min(okr ? xr : scan_lim<T>::hi());
+                b3[vr] = scan_max(okr ? xr : scan_lim<T>::lo());
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            eOut[strand][i] = 0.0;
+            if (i < ni && v >= pad && v < nc - pad) {
+#pragma clang fp contract(off)
+                const int lo = v - shw, hi = v + shw;
+                double t;
+                const int nchg = winC[strand][i];
+                if (nchg > 4) {
+                    const double lo1 = (double)tile_range_min(b0, b1, lo, hi);
+                    const double hi1 = (double)tile_range_max(b2, b3, lo, hi);
+                    t = (winS[strand][i] - lo1) - hi1;
+                } else if (nchg == 0) {
+                    t = (double)(w - 1) * ws[lo];
+                } else {
+                    t = trimmed_sum_k1(ws + lo, w);
+                }
+                const double wsm = skip_trim ? ws[v] : div_invariant(t, w_div, w_rdiv);
+                double q = 0.0;
+                for (int j = -hw; j < hw; ++j) q += ps[v + j];
+                eOut[strand][i] = round((ps[v] / q) * wsm);
+            }
+        }
+        __syncthreads();  // extrema buffers are reused by the other strand / overwritten by E
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int v = i * NT + tid;
+        if (i < ni && v >= pad && v < nc - pad) {
+            cP[v] = eOut[0][i];
+            cM[v] = eOut[1][i];
+        }
+    }
+}
+
 // MO ("memo only"): the instance used first in memo mode.  It has no direct incbet/ndtri body,
 // so it needs 56 instead of 76 VGPRs and 8 wavefronts per SIMD fit; the model parameters are
 // read with scalar loads and the sequence codes share LDS with a scratch array, so a 500-base
@@ -374,6 +499,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     //         thread that owns padded position v = tid also owns output base t' = tid)
     double ob = 0.0;
     if (tid < nt) ob = cP[pad + 1 + tid] + cM[pad + tid];
+    int small_int = 1;
     for (int v = tid; v < nc; v += NT) {
         int fi, ri;
         if (ABL(8)) {
@@ -393,125 +519,22 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         }
         wP[v] = sp;
         wM[v] = sm;
+        // small-integer test for the int32 smoothing scans: |W| <= 2^24 and integral
+        small_int &= (int)(fabs(sp) <= 16777216.0) & (int)(fabs(sm) <= 16777216.0) &
+                     (int)((double)(int)sp == sp) & (int)((double)(int)sm == sm);
     }
-    __syncthreads();
+    const bool all_small_int = __syncthreads_and(small_int) != 0;
     if (ABL(64)) return;
 
     // ---- C: smoothing (smoothing.h:107-133) + expected counts (predict.h:60-63);
     //         E overwrites the counts, which nobody reads any more
     if (a.fast_trim) {
-        // k == 1 and w = 2*shw+1 >= 65 (the `detect` default is w = 101): the trimmed sum of a
-        // window is S - min - max unless the 2nd smallest equals the 2nd largest element
-        // (smoothing.h:61-69 then applies only one weight).  Every 64-lane wavefront owns an
-        // aligned 64-position tile, scans it with __shfl_up / __shfl_down (prefix sums, prefix
-        // and suffix minima / maxima) and publishes the result in LDS; a window is then the
-        // suffix of its first tile + whole middle tiles + the prefix of its last tile, so no
-        // carry has to cross wavefronts.  Near-constant windows (at most 4 value changes between
-        // neighbours) are the only ones that can hit the equal-order-statistics rule and are
-        // re-done element by element, so every case keeps the reference's value.
-        constexpr int MAXI = 3;
-        const int w = 2 * shw + 1;
-        const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
-        const int ni = (ncr + NT - 1) / NT;  // <= MAXI (checked on the host)
-        int *chP = reinterpret_cast<int *>(xA);
-        int *chM = chP + a.nc_max;
-        double winS[2][MAXI];
-        int winC[2][MAXI];
-        // C1: tile prefix sums of W and of the neighbour-change flags, both strands
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int v = i * NT + tid;
-            if (i < ni && v < ncr) {  // uniform per wavefront
-                double v0 = 0.0, v1 = 0.0;
-                int c0 = 0, c1 = 0;
-                if (v < nc) {
-                    v0 = wP[v];
-                    v1 = wM[v];
-                    if (v + 1 < nc) {
-                        c0 = wP[v + 1] != v0;
-                        c1 = wM[v + 1] != v1;
-                    }
-                }
-                wave_scan(v0, c0, lane);
-                wave_scan(v1, c1, lane);
-                cP[v] = v0;
-                cM[v] = v1;
-                chP[v] = c0;
-                chM[v] = c1;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int v = i * NT + tid;
-            winS[0][i] = winS[1][i] = 0.0;
-            winC[0][i] = winC[1][i] = 0;
-            if (i < ni && v >= pad && v < nc - pad) {
-                const int lo = v - shw, hi = v + shw;
-                winS[0][i] = tile_range_sum(cP, lo, hi);
-                winS[1][i] = tile_range_sum(cM, lo, hi);
-                winC[0][i] = tile_range_sum(chP, lo, hi - 1);
-                winC[1][i] = tile_range_sum(chM, lo, hi - 1);
-            }
-        }
-        __syncthreads();
-        // C2: per strand, tile prefix / suffix extrema, then the expected counts
-        double eOut[2][MAXI];
-#pragma unroll
-        for (int strand = 0; strand < 2; ++strand) {
-            const double *ws = strand ? wM : wP;
-            const double *ps = strand ? pM : pP;
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const int v = i * NT + tid;
-                if (i < ni && v < ncr) {
-                    // forward order for the prefixes, reversed order within the tile for the
-                    // suffixes (a suffix scan is a prefix scan of the mirrored tile)
-                    const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
-                    const bool okf = v < nc, okr = vr < nc;
-                    const double xf = okf ? ws[v] : 0.0;
-                    const double xr = okr ? ws[vr] : 0.0;
-                    cP[v] = wave_scan_f64(okf ? xf : fptm::kInf, fptm::kInf, op_min());
-                    xA[v] = wave_scan_f64(okf ? xf : -fptm::kInf, -fptm::kInf, op_max());
-                    cM[vr] = wave_scan_f64(okr ? xr : fptm::kInf, fptm::kInf, op_min());
-                    xB[vr] = wave_scan_f64(okr ? xr : -fptm::kInf, -fptm::kInf, op_max());
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const int v = i * NT + tid;
-                eOut[strand][i] = 0.0;
-                if (i < ni && v >= pad && v < nc - pad) {
-#pragma clang fp contract(off)
-                    const int lo = v - shw, hi = v + shw;
-                    double t;
-                    const int nchg = winC[strand][i];
-                    if (nchg > 4) {
-                        const double lo1 = tile_range_min(cP, cM, lo, hi);
-                        const double hi1 = tile_range_max(xA, xB, lo, hi);
-                        t = (winS[strand][i] - lo1) - hi1;
-                    } else if (nchg == 0) {
-                        t = (double)(w - 1) * ws[lo];
-                    } else {
-                        t = trimmed_sum_k1(ws + lo, w);
-                    }
-                    const double wsm = ABL(1) ? ws[v] : div_invariant(t, w_div, w_rdiv);
-                    double q = 0.0;
-                    for (int j = -hw; j < hw; ++j) q += ps[v + j];
-                    eOut[strand][i] = round((ps[v] / q) * wsm);
-                }
-            }
-            __syncthreads();  // extrema buffers are reused by the other strand / overwritten by E
-        }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int v = i * NT + tid;
-            if (i < ni && v >= pad && v < nc - pad) {
-                cP[v] = eOut[0][i];
-                cM[v] = eOut[1][i];
-            }
-        }
+        // T = int when the whole tile's window sums are small integers (decided block-wide at the
+        // barrier that ends phase B), else double
+        if (all_small_int)
+            smooth_expected_fast<NT, int>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
+        else
+            smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
     } else {
         const int ne = nt + 1;  // padded positions [pad, nc-pad) per strand
         for (int idx = tid; idx < 2 * ne; idx += NT) {

@@ -257,6 +257,35 @@ def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm, nb_mode):
         assert rel_err(out["winp"], wp) < P_TOL
 
 
+@pytest.mark.parametrize("kind", ["float", "huge", "mixed"])
+def test_fused_scan_non_integer_counts(fpt, orc, kind):
+    """the smoothing scans run on int32 when a tile's window sums are small integers and on
+    float64 otherwise: fractional and very large counts must take the float64 path and still
+    match the oracle (exp bit-exact: E is compared after rounding)."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    n_iv, L, hw, shw, clip, scales = 12, 500, 5, 50, 0.01, (3, 10)
+    l = L + 2 * (hw + shw) + 1
+    rs = np.random.RandomState(17)
+    cp = orc.synth_counts(2, 0, n_iv * l, 0)
+    cm = orc.synth_counts(2, 0, n_iv * l, 1)
+    if kind == "float":
+        cp, cm = rs.gamma(2.0, 1.7, n_iv * l), rs.gamma(0.3, 2.0, n_iv * l)
+    elif kind == "huge":
+        cp[::53] = 3.0e7   # window sums beyond 2^24
+    else:
+        cp[4 * l:5 * l] += 0.5   # one interval fractional, the others integral
+    sq = orc.synth_bases(2, 0, n_iv * (l + 6))
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales)
+    out = sc.scan(cp, cm, sq, interval_len=L)
+    e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                   np.array(scales, np.int32))
+    assert np.array_equal(out["obs"], o)
+    assert np.array_equal(out["exp"], e)
+    assert rel_err(out["pval"], p) < P_TOL and rel_err(out["winp"], wp) < P_TOL
+
+
 def test_fused_scan_ragged(fpt, orc):
     """variable-length intervals (config 4 shape): CSR offsets, tiles binned by size."""
     from footprint_tools_amd.scan import FootprintScanner
