@@ -10,8 +10,9 @@ smoothing -> NB p-value -> Stouffer windows) over one batch of synthetic interva
 already resident in HBM.  N=1 workload = BASELINE.json configs[1] (100,000 x 500 bp, one
 scale); `--config 3` selects configs[2] (1,000,000 x 1 kb, five scales).  With N>1 every rank
 scans its own shard of N x batch intervals (weak scaling, no data-path collective inside the
-scan) and the per-base p-value track is re-assembled on every rank with one RCCL all-gather
-per step, overlapped with the next step's scan.
+scan) and, after the K steps and still inside the timed region, the per-base p-value track of
+the resident batch is re-assembled on every rank with ONE RCCL all-gather (N x 400 MB for
+config 2): "a single all-gather at the end", as BASELINE.json's north_star words it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the fused
 kernel and `cpu_baseline` = the C oracle timed on this box's host cores (N=1 only).
@@ -151,7 +152,7 @@ def main():
         t_cm = torch.empty(n_counts, dtype=torch.float64, device=dev)
         t_sq = torch.empty(n_seq, dtype=torch.uint8, device=dev)
         t_out = torch.empty((2 + S) * total, dtype=torch.float64, device=dev)   # exp, obs, winp[S]
-        t_p = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(2)]  # p track, double-buffered
+        t_p = [torch.empty(total, dtype=torch.float64, device=dev)]  # p-value track of the resident batch
         t_gather = None if args.no_allgather else torch.empty(
             world * total, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         p_cp, p_cm, p_sq, p_out = t_cp.data_ptr(), t_cm.data_ptr(), t_sq.data_ptr(), t_out.data_ptr()
@@ -189,31 +190,27 @@ def main():
         else:
             ctx.synchronize()
 
-    pending = [None, None]
-
     def run_steps(k):
         for i in range(k):
-            if world > 1 and not args.no_allgather:
-                if pending[i % 2] is not None:   # buffer i%2 is still being gathered from step i-2
-                    pending[i % 2].wait()
-                step(i)
-                if args.backend == "nccl":
-                    pending[i % 2] = dist.all_gather_into_tensor(t_gather, t_p[i % 2], async_op=True)
-                else:
-                    dist.all_gather_into_tensor(t_gather, t_p[i % 2].cpu())
+            step(i)
+
+    def gather_track():
+        """The one collective of the job: every rank ends up with the whole p-value track."""
+        if world > 1 and not args.no_allgather:
+            last = t_p[(args.steps - 1) % len(t_p)]
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(t_gather, last)
             else:
-                step(i)
-        for j in (0, 1):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
+                dist.all_gather_into_tensor(t_gather, last.cpu())
 
     def measure(steps, warmup):
         run_steps(warmup)
+        gather_track()  # also brings the communicator up before the timed region
         sync()
         ctx.timing_enable(steps)
         t0 = time.perf_counter()
         run_steps(steps)
+        gather_track()
         sync()
         seq_ms, main_ms = ctx.timing_read()
         return time.perf_counter() - t0, main_ms, seq_ms
