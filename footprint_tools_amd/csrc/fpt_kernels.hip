@@ -274,6 +274,16 @@ struct scan_args {
 #define ABL(bit) 0
 #endif
 
+// Direct evaluation of (p, z) for one base (dispersion.pyx:311-314 + the z of windowing.h:61).
+// Build note: this library is compiled with `-mllvm -disable-machine-licm`; with machine LICM
+// on, any loop around this body makes the compiler hoist the ~150 fp64 polynomial
+// coefficients of incbet / ndtri into registers (70 -> 170+ VGPRs, or spills).
+__device__ __forceinline__ double2 nb_pz_direct(double r, double mu, int32_t k) {
+    const double pv = fptm::nb_cdf(k, r / (r + mu), r);
+    const double z = fptm::ndtri(1.0 - pv);
+    return make_double2(pv, z);
+}
+
 // (p, z) for every integer pair (exp, obs) of the table: the same device functions the
 // direct path calls, so a lookup returns bit-identical values.
 __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ model, int memo_exp,
@@ -557,18 +567,68 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     int *nf = reinterpret_cast<int *>(wM);
     double zv = 0.0;
     int zc = 0;
-    if (tid < nt) {
-        const int tp = tid;
-        bool zd = false;
-        double ex = cP[pad + 1 + tp] + cM[pad + tp];
-        const int32_t k = fptm::c_int(ob);
-        double pv, z;
+    double ex = 0.0, pv = 0.0, z = 0.0;
+    bool zd = false;
+    if (tid < nt) ex = cP[pad + 1 + tid] + cM[pad + tid];
+    const int32_t k = fptm::c_int(ob);
+    if (!MO && !a.memo && !ABL(2)) {
+        // Direct mode: every base evaluates incbet itself.  Lanes are regrouped first so that a
+        // wavefront mostly runs ONE of incbet's expansions (power series / continued fraction 1 /
+        // continued fraction 2) on similar observed counts: a counting sort of the tile's bases
+        // by (expansion, obs/4) through LDS, evaluation in sorted order, results handed back
+        // through LDS.  Values are unchanged; only who computes them moves.
+        int *bins = reinterpret_cast<int *>(sq);       // 64 counters, then bases (sq is dead)
+        int *order = reinterpret_cast<int *>(pP);      // propensities are dead after C
+        double *s_r = pM, *s_mu = xB;
+        int *s_k = reinterpret_cast<int *>(xA);
+        if (tid < 64) bins[tid] = 0;
+        __syncthreads();
+        int key = 0;
+        if (tid < nt) {
+            const double r = fptm::fit_r(par + 9, ex, &zd);
+            const double mu = fptm::fit_mu(par, ex);
+            const double xx = r / (r + mu), bb = (double)fptm::wrap_inc(k);
+            int cls = 0;  // trivial / domain
+            if (r > 0.0 && bb > 0.0 && xx > 0.0 && xx < 1.0) {
+                const bool direct = (bb * xx) <= 1.0 && xx <= 0.95;
+                const bool flipped = !direct && xx > (r / (r + bb));
+                const double ia = flipped ? bb : r, ib = flipped ? r : bb, ix = flipped ? 1.0 - xx : xx;
+                const bool series = direct || (flipped && (ib * ix) <= 1.0 && ix <= 0.95);
+                cls = series ? 1 : ((ix * (ia + ib - 2.0) - (ia - 1.0)) < 0.0 ? 2 : 3);
+            }
+            key = cls * 16 + min(max(k, 0) >> 2, 15);
+            s_r[tid] = r;
+            s_mu[tid] = mu;
+            s_k[tid] = k;
+            atomicAdd(&bins[key], 1);
+        }
+        __syncthreads();
+        if (tid < kWave) {  // exclusive prefix of the 64 bins
+            const int c = bins[tid];
+            const int incl = wave_scan_i32(c);
+            bins[tid] = incl - c;
+        }
+        __syncthreads();
+        if (tid < nt) order[atomicAdd(&bins[key], 1)] = tid;
+        __syncthreads();
+        if (tid < nt) {
+            const int src = order[tid];
+            const double2 pz = nb_pz_direct(s_r[src], s_mu[src], s_k[src]);
+            s_r[src] = pz.x;
+            s_mu[src] = pz.y;
+        }
+        __syncthreads();
+        if (tid < nt) {
+            pv = s_r[tid];
+            z = s_mu[tid];
+        }
+    } else if (tid < nt) {
         const int ei = (int)ex;
         if (ABL(2)) {
             pv = 0.5;
             z = ob * 0.01;
         } else if (a.memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
-            k < a.memo_obs) {
+                   k < a.memo_obs) {
             const double2 pz = a.memo[ei * a.memo_obs + k];
             pv = pz.x;
             z = pz.y;
@@ -577,11 +637,15 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
             pv = z = NAN;
             a.redo[tile] = 1;  // the full instance recomputes this tile
         } else {
-            double r = fptm::fit_r(par + 9, ex, &zd);
-            double mu = fptm::fit_mu(par, ex);
-            pv = fptm::nb_cdf(k, r / (r + mu), r);
-            z = fptm::ndtri(1.0 - pv);
+            const double r = fptm::fit_r(par + 9, ex, &zd);
+            const double mu = fptm::fit_mu(par, ex);
+            const double2 pz = nb_pz_direct(r, mu, k);
+            pv = pz.x;
+            z = pz.y;
         }
+    }
+    if (tid < nt) {
+        const int tp = tid;
         bool fin = isfinite(z);
         zv = fin ? z : 0.0;
         zc = fin ? 0 : 1;
