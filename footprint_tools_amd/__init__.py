@@ -12,4 +12,4 @@ runs in hand-written HIP kernels behind the C ABI of ``include/fpt.h``
 (``libfpt_hip.so``); there is no CPU fallback.
 """
 __version__ = "0.1.0"
-__all__ = ["modeling", "stats", "scan"]
+__all__ = ["modeling", "stats", "scan", "detect", "distributed"]

@@ -134,3 +134,28 @@ def test_shard_intervals_balanced():
     cost = lens + 111
     per = [cost[a:b].sum() for a, b in sh]
     assert sum(b - a for a, b in sh) == 5000 and max(per) / (cost.sum() / 8) < 1.02
+
+
+def test_output_writers_text_format():
+    """bedGraph / BED text of cli/utils.py:86-210: "%.4f" scores, merged segments."""
+    import io
+    from footprint_tools_amd import detect
+
+    class IV(object):
+        chrom, start, end = "chr7", 1000, 1004
+
+    stats = np.array([[3.0, 2.0, 0.123456, np.nan, 1.0], [0.0, 10.0, 33.3, 0.00004, 0.5]])
+    buf = io.StringIO()
+    detect.write_stats_to_output(IV, stats, file=buf)
+    assert buf.getvalue() == ("chr7\t1000\t1001\t3.0000\t2.0000\t0.1235\tnan\t1.0000\n"
+                              "chr7\t1001\t1002\t0.0000\t10.0000\t33.3000\t0.0000\t0.5000\n")
+    buf = io.StringIO()
+    detect.write_stats_to_output(IV, stats, file=buf, filter_fn=lambda x: x[:, 1] >= 5)
+    assert buf.getvalue().count("\n") == 1 and buf.getvalue().startswith("chr7\t1001\t1002")
+    fdr_col = np.array([1, 1, .001, .001, .002, 1, 1, 1, .0005, 1.0])
+    buf = io.StringIO()
+    detect.write_segments_to_output(IV, fdr_col, 0.01, file=buf, decreasing=True)
+    assert buf.getvalue() == "chr7\t1000\t1011\t.\t0.0005\n"
+    buf = io.StringIO()
+    detect.write_output_header(["exp", "obs"], file=buf, include_name=False, extra=["a", "b"])
+    assert buf.getvalue().splitlines()[1:] == ["# a", "# b", "# chrom\tstart\tend\texp\tobs"]
