@@ -676,6 +676,16 @@ int fpt_last_scan_ms(fpt_ctx *c, float *ms_out) {
     return FPT_OK;
 }
 
+int fpt_hist2d_dev(fpt_ctx *c, const double *exp_dev, const double *obs_dev, int64_t n, int rows, int cols,
+                   uint64_t *hist_dev) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 0 || rows < 1 || cols < 1 || (int64_t)rows * cols > (1 << 28))
+        return fail(FPT_ERR_INVALID, "bad histogram shape or length");
+    if (!hist_dev || ((!exp_dev || !obs_dev) && n > 0)) return fail(FPT_ERR_INVALID, "null buffer");
+    fptk::launch_hist2d(c->stream, exp_dev, obs_dev, n, rows, cols, (unsigned long long *)hist_dev);
+    return launch_ok("k_hist2d");
+}
+
 int fpt_synth_dev(fpt_ctx *c, uint64_t seed, int64_t pos0_counts, int64_t n_counts, double *cp,
                   double *cm, int64_t pos0_seq, int64_t n_seq, uint8_t *seq) {
     if (int rc = check_ctx(c)) return rc;

@@ -914,6 +914,36 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
 template __global__ void k_fdr_null<256>(const fdr_args);
 
 // ===========================================================================
+// k_hist2d: hist[int(exp), int(obs)] += 1 (cli/learn_dm.py:276-287), pairs outside the
+// histogram ignored.  The dense low corner (64 x 64 bins) is accumulated per workgroup in LDS,
+// the rest goes straight to global atomics.
+// ===========================================================================
+__global__ void __launch_bounds__(256) k_hist2d(const double *__restrict__ ex, const double *__restrict__ ob,
+                                                int64_t n, int rows, int cols,
+                                                unsigned long long *__restrict__ hist) {
+    constexpr int C = 64;
+    __shared__ unsigned int sub[C * C];
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) sub[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double e = ex[i], o = ob[i];
+        // int(x) truncates toward zero; non-finite and negative values are skipped
+        if (!(e >= 0.0) || !(o >= 0.0) || !(e < 2147483647.0) || !(o < 2147483647.0)) continue;
+        const int r = (int)e, c = (int)o;
+        if (r >= rows || c >= cols) continue;  // IndexError -> pass (learn_dm.py:285-287)
+        if (r < C && c < C) atomicAdd(&sub[r * C + c], 1u);
+        else atomicAdd(&hist[(size_t)r * cols + c], 1ull);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const unsigned int v = sub[i];
+        const int r = i / C, c = i % C;
+        if (v && r < rows && c < cols) atomicAdd(&hist[(size_t)r * cols + c], (unsigned long long)v);
+    }
+}
+
+// ===========================================================================
 // synthetic workload + checksum
 // ===========================================================================
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -1138,6 +1168,12 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         hipLaunchKernelGGL(k_fdr_null<256>, dim3((unsigned)n), dim3(256), lds, st, b);
     }
     return hipSuccess;
+}
+
+void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
+                   unsigned long long *hist) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_hist2d, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, ex, ob, n, rows, cols, hist);
 }
 
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

@@ -71,6 +71,8 @@ size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
 hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
 void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo);
+void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
+                   unsigned long long *hist);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);

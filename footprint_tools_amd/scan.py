@@ -230,6 +230,26 @@ class FootprintScanner(object):
             for b in bufs:
                 b.free()
 
+    # ---- (exp, obs) histogram of `ftd learn_dm` (cli/learn_dm.py:276-287) --------------
+    def histogram(self, exp, obs, dims=(200, 1000)):
+        """hist[int(exp), int(obs)] += 1 over host arrays; pairs outside `dims` are ignored."""
+        ctx = self.ctx
+        exp, obs = _lib.f64(exp).ravel(), _lib.f64(obs).ravel()
+        if exp.size != obs.size:
+            raise ValueError("exp and obs differ in length")
+        rows, cols = int(dims[0]), int(dims[1])
+        bufs = []
+        try:
+            d_e = DeviceArray(ctx, max(exp.nbytes, 16)).upload(exp); bufs.append(d_e)
+            d_o = DeviceArray(ctx, max(obs.nbytes, 16)).upload(obs); bufs.append(d_o)
+            d_h = DeviceArray(ctx, rows * cols * 8).upload(np.zeros(rows * cols, np.uint64)); bufs.append(d_h)
+            _lib.check(ctx.L.fpt_hist2d_dev(ctx.h, d_e.ptr, d_o.ptr, exp.size, rows, cols, d_h.ptr))
+            ctx.synchronize()
+            return d_h.download(np.uint64, rows * cols).reshape(rows, cols).astype(np.int64)
+        finally:
+            for b in bufs:
+                b.free()
+
     # ---- synthetic workload (BASELINE.json configs 1-3) ---------------------------------
     def synth_dev(self, seed, n_intervals, interval_len, counts_plus, counts_minus, seq,
                   first_interval=0):

@@ -209,6 +209,13 @@ typedef struct fpt_fdr_desc {
  * Intervals longer than 4096 bases are rejected (FPT_ERR_INVALID). */
 int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
 
+/* (exp, obs) histogram of `ftd learn_dm` (cli/learn_dm.py:276-287): hist[int(exp), int(obs)] += 1
+ * for the n pairs of two DEVICE tracks, pairs outside the rows x cols histogram (the reference
+ * uses 200 x 1000) ignored like its IndexError branch; negative or non-finite values are
+ * skipped.  hist_dev: DEVICE uint64[rows*cols], accumulated into (zero it first). */
+int fpt_hist2d_dev(fpt_ctx *ctx, const double *exp_dev, const double *obs_dev, int64_t n, int rows,
+                   int cols, uint64_t *hist_dev);
+
 /* Fill device buffers with the synthetic workload of BASELINE.json configs 1-3:
  * counter-hash generator, element at global position p of stream s is
  * mix(mix(seed+s)+p); counts = U{0..19} as float64, bases uniform ACGT.

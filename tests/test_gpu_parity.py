@@ -657,6 +657,24 @@ def test_deviation_stats_driver(fpt, orc, tmp_path):
     assert np.all(rec["stats"][:, 2:4] == 0.0) and np.all(rec["stats"][:, 4] == 1.0)
 
 
+def test_exp_obs_histogram(fpt, orc):
+    """cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1, out-of-range pairs ignored."""
+    sc, lat, out = _scan_small(orc, 40, 500, 77, bump=slice(0, 20000, 13))
+    e, o = out["exp"].copy(), out["obs"].copy()
+    o[5] = 1500.0   # beyond the 1000 columns
+    e[6] = 250.0    # beyond the 200 rows
+    o[7] = 2.9      # int() truncates
+    got = sc.histogram(e, o)
+    want = np.zeros((200, 1000), dtype=np.int64)
+    for a, b in zip(e, o):
+        try:
+            want[int(a), int(b)] += 1
+        except IndexError:
+            pass
+    assert got.shape == (200, 1000) and np.array_equal(got, want)
+    assert got.sum() < e.size  # the out-of-range pairs were dropped
+
+
 def test_argument_errors(fpt, ctx):
     from footprint_tools_amd.modeling import predict
     from footprint_tools_amd.stats import windowing
