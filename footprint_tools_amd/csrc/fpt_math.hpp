@@ -466,8 +466,20 @@ FPT_HD double ndtr(double a) {
     double z = fabs(x);
     if (z < 1.0) return 0.5 + 0.5 * erf_small(x);
     double y = 0.5 * erfce(z);
-    z = expx2(a, -1);
-    y = y * sqrt(z);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // exp(-a^2/2) for the tail.  The reference takes sqrt(expx2(a, -1)) (two exps and a square
+    // root); away from the underflow of exp(-a^2) the same value to ~1 ulp is one exp of the
+    // rounded product times a first-order correction with the exact rounding residual (fma).
+    if (fabs(a) < 26.0) {
+        const double s = -0.5 * a * a;
+        const double rem = fma(-0.5 * a, a, -s);
+        y = y * (exp(s) * (1.0 + rem));
+    } else
+#endif
+    {
+        z = expx2(a, -1);
+        y = y * sqrt(z);
+    }
     if (x > 0) y = 1.0 - y;
     return y;
 }
