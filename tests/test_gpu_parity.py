@@ -286,6 +286,52 @@ def test_fused_scan_non_integer_counts(fpt, orc, kind):
     assert rel_err(out["pval"], p) < P_TOL and rel_err(out["winp"], wp) < P_TOL
 
 
+@pytest.mark.parametrize("L,hw,shw,clip,scales", [
+    (1, 5, 50, 0.01, (3,)),        # single-base interval: every window is an edge
+    (2, 5, 50, 0.01, (3, 1)),
+    (7, 5, 50, 0.01, (3,)),        # exactly 2*hw+1 bases: one interior window position
+    (90, 0, 2, 0.25, (3,)),        # hw = 0: empty count window, Q = 0 -> NaN expected counts
+    (130, 2, 0, 0.01, (0, 3)),     # scale 0: window of one base
+    (200, 5, 200, 0.01, (3,)),     # wide smoothing window (w = 401, three tiles per window)
+])
+def test_fused_scan_edge_shapes(fpt, orc, L, hw, shw, clip, scales):
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    n_iv = 9
+    l = L + 2 * (hw + shw) + 1
+    cp, cm = orc.synth_counts(6, 0, n_iv * l, 0), orc.synth_counts(6, 0, n_iv * l, 1)
+    sq = orc.synth_bases(6, 0, n_iv * (l + 6))
+    for mode in ("direct", "memo"):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales, nb_mode=mode)
+        out = sc.scan(cp, cm, sq, interval_len=L)
+        e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                       np.array(scales, np.int32))
+        assert np.array_equal(out["obs"], o)
+        assert np.array_equal(out["exp"], e, equal_nan=True)
+        assert rel_err(out["pval"], p) < P_TOL and rel_err(out["winp"], wp) < P_TOL
+
+
+def test_scan_empty_and_partial_outputs(fpt, orc):
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, ())
+    sc.scan_dev(0, None, None, None, interval_len=100)  # nothing to do
+    ctx = sc.ctx
+    n_iv, L = 3, 100
+    l = sc.padded_len(L)
+    cp, cm = orc.synth_counts(1, 0, n_iv * l, 0), orc.synth_counts(1, 0, n_iv * l, 1)
+    sq = orc.synth_bases(1, 0, n_iv * (l + 6))
+    d_cp, d_cm, d_sq = (DeviceArray(ctx, a.nbytes).upload(a) for a in (cp, cm, sq))
+    d_p = DeviceArray(ctx, n_iv * L * 8)
+    sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, pval_out=d_p.ptr, interval_len=L)  # p-values only
+    ctx.synchronize()
+    _, _, p, _ = orc.detect_batch(cp, cm, sq, n_iv, L, 5, 50, 0.01, table, lat["mu_A"], lat["r_A"],
+                                  np.zeros(0, np.int32))
+    assert rel_err(d_p.download(np.float64, n_iv * L), p) < P_TOL
+
+
 def test_fused_scan_ragged(fpt, orc):
     """variable-length intervals (config 4 shape): CSR offsets, tiles binned by size."""
     from footprint_tools_amd.scan import FootprintScanner
