@@ -435,6 +435,135 @@ __device__ __forceinline__ void smooth_expected_fast(const double *wP, const dou
     }
 }
 
+// int32 variant of smooth_expected_fast with the barrier count cut from 7 to 4: all four
+// extrema scans of a strand are int32 and fit in two of the four scratch buffers, so the scans
+// of one strand can be written while the previous stage's results are still being read.
+// Expected counts come out in xA ('+') and xB ('-').
+template <int NT>
+__device__ __forceinline__ void smooth_expected_int(const double *wP, const double *wM, const double *pP,
+                                                    const double *pM, double *cP, double *cM, double *xA,
+                                                    double *xB, int nc, int ncr, int nc_max, int pad,
+                                                    int hw, int shw, bool skip_trim) {
+    constexpr int MAXI = 3;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int w = 2 * shw + 1;
+    const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
+    const int ni = (ncr + NT - 1) / NT;
+    // stage 1 buffers (in cP / cM): prefix sums and change counts of both strands
+    int *psP = reinterpret_cast<int *>(cP), *psM = psP + nc_max;
+    int *chP = reinterpret_cast<int *>(cM), *chM = chP + nc_max;
+    double winS[2][MAXI];
+    int winC[2][MAXI];
+    double eOut[2][MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int v = i * NT + tid;
+        if (i < ni && v < ncr) {
+            int v0 = 0, v1 = 0, c0 = 0, c1 = 0;
+            if (v < nc) {
+                const double d0 = wP[v], d1 = wM[v];
+                v0 = (int)d0;
+                v1 = (int)d1;
+                if (v + 1 < nc) {
+                    c0 = wP[v + 1] != d0;
+                    c1 = wM[v + 1] != d1;
+                }
+            }
+            psP[v] = scan_add(v0);
+            psM[v] = scan_add(v1);
+            chP[v] = scan_add(c0);
+            chM[v] = scan_add(c1);
+        }
+    }
+    __syncthreads();  // (1)
+#pragma unroll
+    for (int strand = 0; strand < 2; ++strand) {
+        const double *ws = strand ? wM : wP;
+        // extrema buffers: strand 0 -> xA / xB, strand 1 -> cP / cM (stage 1 is consumed by then)
+        int *pmn = reinterpret_cast<int *>(strand ? cP : xA), *smn = pmn + nc_max;
+        int *pmx = reinterpret_cast<int *>(strand ? cM : xB), *smx = pmx + nc_max;
+        if (strand == 0) {
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int v = i * NT + tid;
+                winS[0][i] = winS[1][i] = 0.0;
+                winC[0][i] = winC[1][i] = 0;
+                if (i < ni && v >= pad && v < nc - pad) {
+                    const int lo = v - shw, hi = v + shw;
+                    winS[0][i] = (double)tile_range_sum(psP, lo, hi);
+                    winS[1][i] = (double)tile_range_sum(psM, lo, hi);
+                    winC[0][i] = tile_range_sum(chP, lo, hi - 1);
+                    winC[1][i] = tile_range_sum(chM, lo, hi - 1);
+                }
+            }
+        } else {
+            // combine strand 0 (its scans were published before barrier 2)
+            const int *qmn = reinterpret_cast<int *>(xA), *rmn = qmn + nc_max;
+            const int *qmx = reinterpret_cast<int *>(xB), *rmx = qmx + nc_max;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int v = i * NT + tid;
+                eOut[0][i] = 0.0;
+                if (i < ni && v >= pad && v < nc - pad) {
+#pragma clang fp contract(off)
+                    const int lo = v - shw, hi = v + shw;
+                    double t;
+                    const int nchg = winC[0][i];
+                    if (nchg > 4) t = (winS[0][i] - (double)tile_range_min(qmn, rmn, lo, hi)) -
+                                      (double)tile_range_max(qmx, rmx, lo, hi);
+                    else if (nchg == 0) t = (double)(w - 1) * wP[lo];
+                    else t = trimmed_sum_k1(wP + lo, w);
+                    const double wsm = skip_trim ? wP[v] : div_invariant(t, w_div, w_rdiv);
+                    double q = 0.0;
+                    for (int j = -hw; j < hw; ++j) q += pP[v + j];
+                    eOut[0][i] = round((pP[v] / q) * wsm);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            if (i < ni && v < ncr) {
+                const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
+                const bool okf = v < nc, okr = vr < nc;
+                const int xf = okf ? (int)ws[v] : 0;
+                const int xr = okr ? (int)ws[vr] : 0;
+                pmn[v] = scan_min(okf ? xf : 0x7fffffff);
+                pmx[v] = scan_max(okf ? xf : (int)0x80000000);
+                smn[vr] = scan_min(okr ? xr : 0x7fffffff);
+                smx[vr] = scan_max(okr ? xr : (int)0x80000000);
+            }
+        }
+        __syncthreads();  // (2), (3)
+    }
+    {
+        // combine strand 1 (scans in cP / cM), then publish both strands' expected counts in
+        // xA / xB, whose strand-0 scans nobody reads any more
+        const int *qmn = reinterpret_cast<int *>(cP), *rmn = qmn + nc_max;
+        const int *qmx = reinterpret_cast<int *>(cM), *rmx = qmx + nc_max;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int v = i * NT + tid;
+            if (i < ni && v >= pad && v < nc - pad) {
+#pragma clang fp contract(off)
+                const int lo = v - shw, hi = v + shw;
+                double t;
+                const int nchg = winC[1][i];
+                if (nchg > 4) t = (winS[1][i] - (double)tile_range_min(qmn, rmn, lo, hi)) -
+                                  (double)tile_range_max(qmx, rmx, lo, hi);
+                else if (nchg == 0) t = (double)(w - 1) * wM[lo];
+                else t = trimmed_sum_k1(wM + lo, w);
+                const double wsm = skip_trim ? wM[v] : div_invariant(t, w_div, w_rdiv);
+                double q = 0.0;
+                for (int j = -hw; j < hw; ++j) q += pM[v + j];
+                xA[v] = eOut[0][i];
+                xB[v] = round((pM[v] / q) * wsm);
+            }
+        }
+    }
+}
+
 // MO ("memo only"): the instance used first in memo mode.  It has no direct incbet/ndtri body,
 // so it needs 56 instead of 76 VGPRs and 8 wavefronts per SIMD fit; the model parameters are
 // read with scalar loads and the sequence codes share LDS with a scratch array, so a 500-base
@@ -510,6 +639,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     double ob = 0.0;
     if (tid < nt) ob = cP[pad + 1 + tid] + cM[pad + tid];
     int small_int = 1;
+    const double int_lim = fmin(16777216.0, 1073741824.0 / (double)(2 * shw + 65));
     for (int v = tid; v < nc; v += NT) {
         int fi, ri;
         if (ABL(8)) {
@@ -529,8 +659,9 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         }
         wP[v] = sp;
         wM[v] = sm;
-        // small-integer test for the int32 smoothing scans: |W| <= 2^24 and integral
-        small_int &= (int)(fabs(sp) <= 16777216.0) & (int)(fabs(sm) <= 16777216.0) &
+        // small-integer test for the int32 smoothing scans: integral and small enough that a
+        // window of w values (and a 64-position tile prefix) stays below 2^30
+        small_int &= (int)(fabs(sp) <= int_lim) & (int)(fabs(sm) <= int_lim) &
                      (int)((double)(int)sp == sp) & (int)((double)(int)sm == sm);
     }
     const bool all_small_int = __syncthreads_and(small_int) != 0;
@@ -542,7 +673,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // T = int when the whole tile's window sums are small integers (decided block-wide at the
         // barrier that ends phase B), else double
         if (all_small_int)
-            smooth_expected_fast<NT, int>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
+            smooth_expected_int<NT>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
         else
             smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
     } else {
@@ -567,9 +698,13 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     int *nf = reinterpret_cast<int *>(wM);
     double zv = 0.0;
     int zc = 0;
+    // expected counts: the int32 smoothing path leaves them in xA / xB, the others in cP / cM
+    const bool e_in_x = a.fast_trim && all_small_int;
+    const double *eP = e_in_x ? xA : cP, *eM = e_in_x ? xB : cM;
+    double *fA = e_in_x ? cP : xA, *fB = e_in_x ? cM : xB;  // the pair that is free now
     double ex = 0.0, pv = 0.0, z = 0.0;
     bool zd = false;
-    if (tid < nt) ex = cP[pad + 1 + tid] + cM[pad + tid];
+    if (tid < nt) ex = eP[pad + 1 + tid] + eM[pad + tid];
     const int32_t k = fptm::c_int(ob);
     if (!MO && !a.memo && !ABL(2)) {
         // Direct mode: every base evaluates incbet itself.  Lanes are regrouped first so that a
@@ -579,8 +714,8 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // through LDS.  Values are unchanged; only who computes them moves.
         int *bins = reinterpret_cast<int *>(sq);       // 64 counters, then bases (sq is dead)
         int *order = reinterpret_cast<int *>(pP);      // propensities are dead after C
-        double *s_r = pM, *s_mu = xB;
-        int *s_k = reinterpret_cast<int *>(xA);
+        double *s_r = pM, *s_mu = fB;
+        int *s_k = reinterpret_cast<int *>(fA);
         if (tid < 64) bins[tid] = 0;
         __syncthreads();
         int key = 0;
