@@ -39,6 +39,11 @@ class bias_model(object):
 
     def __setitem__(self, key, value):
         self.model[key] = value
+        self._table_cache = None
+
+    def invalidate(self):
+        """Drop the cached device table (call after mutating `self.model` directly)."""
+        self._table_cache = None
 
     def offset(self):
         return max(self.k - self.mid, self.mid)
@@ -60,11 +65,16 @@ class bias_model(object):
     # ---- device table ------------------------------------------------------------------
     def table(self):
         """4096 propensities in 2-bit order; k-mers absent from the model get the default."""
+        fp = (id(self.model), len(self.model), self.default)
+        cached = getattr(self, "_table_cache", None)
+        if cached is not None and cached[0] == fp:
+            return cached[1]
         t = np.full(4096, self.default, dtype=np.float64)
         for kmer, val in self.model.items():
             idx = kmer_index(kmer)
             if idx is not None:
                 t[idx] = val
+        self._table_cache = (fp, t)
         return t
 
     def probs_both(self, seq, ctx=None):
