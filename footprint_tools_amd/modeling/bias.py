@@ -49,18 +49,20 @@ class bias_model(object):
         return max(self.k - self.mid, self.mid)
 
     def shuffle(self):
-        """Randomly shuffle the bias model (bias.py:25-43)"""
-        ret = bias_model()
-        ret.model = {
-            x: y
-            for (x, y) in zip(list(self.model.keys()),
-                              sorted(list(self.model.values()), key=lambda k: random.random()))
-        }
-        ret.offset = self.offset
-        return ret
+        """A copy of the model with the propensities randomly re-assigned to the k-mers
+        (bias.py:25-43; one `random.random()` key per value, like the reference)."""
+        values = list(self.model.values())
+        keys = [random.random() for _ in values]
+        perm = sorted(range(len(values)), key=keys.__getitem__)
+        out = bias_model()
+        out.model = dict(zip(self.model.keys(), (values[i] for i in perm)))
+        out.offset = self.offset
+        return out
 
     def predict(self, probs, n=100):
-        return np.around(probs / np.sum(probs) * n)
+        """Distribute n tags according to relative propensities (bias.py:45-56)."""
+        probs = np.asarray(probs)
+        return np.around(probs / probs.sum() * n)
 
     # ---- device table ------------------------------------------------------------------
     def table(self):
@@ -96,40 +98,40 @@ class bias_model(object):
 
 
 class kmer_model(bias_model):
-    """reference: bias.py:58-111"""
+    """k-mer model read from a two-column text file or URL (bias.py:58-86)."""
 
     def __init__(self, filepath):
         bias_model.__init__(self)
         self.read_model(filepath)
 
     def read_model(self, filepath):
-        import urllib.request as request
-
+        """`KMER<TAB>propensity` per line; k-mers are upper-cased."""
         try:
             if filepath.startswith("http"):
-                file = request.urlopen(filepath)
+                import urllib.request
+                fh = urllib.request.urlopen(filepath)
             else:
-                file = open(filepath, "r")
-            for line in file:
-                if isinstance(line, bytes):
-                    line = line.decode()
-                (seq, prob) = line.strip().split("\t")
-                self.model[seq.upper()] = float(prob)
+                fh = open(filepath, "r")
+            with fh:
+                for raw in fh:
+                    text = raw.decode() if isinstance(raw, bytes) else raw
+                    kmer, value = text.strip().split("\t")
+                    self.model[kmer.upper()] = float(value)
         except IOError:
             raise IOError("Cannot open file: %s" % filepath)
+        self._table_cache = None
 
 
 class uniform_model(bias_model):
-    """reference: bias.py:114-122 (probs returns len(seq) ones, not len(seq)-6)"""
+    """Every 6-mer has propensity 1 (bias.py:114-122).  Like the reference, `probs` returns
+    len(seq) ones rather than len(seq)-6; fast_predict only reads the first l of them."""
 
     def __init__(self):
         bias_model.__init__(self)
-        for seq in itertools.product("ATCG", repeat=self.k):
-            self.model["".join(seq)] = 1.0
+        self.model = dict.fromkeys(("".join(k) for k in itertools.product("ATCG", repeat=self.k)), 1.0)
 
     def probs(self, seq):
         return np.ones(len(seq))
 
     def probs_both(self, seq, ctx=None):
-        n = len(seq)
-        return np.ones(n), np.ones(n)
+        return np.ones(len(seq)), np.ones(len(seq))

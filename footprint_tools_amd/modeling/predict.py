@@ -25,11 +25,15 @@ def predict(obs, probs, half_win_width, smoothing_half_win_width, smoothing_clip
     return exp, win
 
 
+_COMPLEMENT = bytearray(b"N" * 256)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMPLEMENT[_a] = _b
+_COMPLEMENT = bytes(_COMPLEMENT)
+
+
 def reverse_complement(seq):
-    """predict.pyx:47-61"""
-    compl = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N', 'a': 't', 'c': 'g', 'g': 'c',
-             't': 'a', 'n': 'n'}
-    return ''.join([compl.get(base, 'N') for base in seq])[::-1]
+    """Reverse complement; anything but ACGTN (either case) becomes N (predict.pyx:47-61)."""
+    return seq.encode("ascii", "replace").translate(_COMPLEMENT)[::-1].decode("ascii")
 
 
 class prediction(object):

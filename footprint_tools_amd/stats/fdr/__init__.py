@@ -1,13 +1,17 @@
-"""Mirrors footprint_tools/stats/fdr/__init__.py:12-33 (v1.3.7)."""
+"""Empirical FDR: the call surface of footprint_tools/stats/fdr/__init__.py:12-33 (v1.3.7).
+For whole batches on the GPU use `FootprintScanner.fdr` / `fpt_fdr_dev` instead."""
 import numpy as np
 
 from ..utils import bisect
 
 
 def emperical_fdr(pvals_null, pvals):
-    sorted_pvals_null = np.sort(np.ravel(pvals_null))
-    sorted_pvals_idx = np.argsort(pvals)
-    counts = bisect(sorted_pvals_null, np.asarray(pvals)[sorted_pvals_idx])
-    false_positive_rates = counts / len(sorted_pvals_null)
-    false_positive_rates[false_positive_rates > 1] = 1
-    return false_positive_rates[np.argsort(sorted_pvals_idx)]
+    """Fraction of the pooled null p-values that are <= each observed p-value, capped at 1;
+    NaN observations rank above everything (-> 1)."""
+    null = np.sort(np.asarray(pvals_null, dtype=np.float64), axis=None)
+    p = np.asarray(pvals, dtype=np.float64)
+    order = np.argsort(p)
+    rate = bisect(null, p[order]) / null.size
+    out = np.empty(p.shape, dtype=np.float64)
+    out[order] = np.minimum(rate, 1.0)
+    return out

@@ -1,59 +1,62 @@
-"""Posterior footprint probabilities.  Mirrors footprint_tools/stats/posterior.py (v1.3.7);
-the windowed NB log-likelihoods run on the GPU."""
+"""Posterior footprint probabilities: the call surface of footprint_tools/stats/posterior.py
+(v1.3.7).  The windowed negative-binomial log-likelihoods run on the GPU (log-pmf kernel +
+window-sum kernel); the two prior builders are small numpy reductions over datasets, as in the
+reference."""
 import numpy as np
 
 from . import windowing
 
 
 def compute_prior_weighted(fdr, w, cutoff=0.05, pseudocount=0.5):
-    """posterior.py:12-42"""
-    k = np.sum(fdr <= cutoff, axis=0)
-    n = np.sum(w, axis=0)
-    a = n - k + pseudocount
-    b = k + pseudocount
-    pr = a / (a + b)
-    res = np.ones(fdr.shape)
-    res *= pr[np.newaxis, :]
-    res[w == 0] = 1
-    return res
+    """Per-nucleotide occupancy prior (reference: posterior.py:12-42).
+
+    fdr, w : (datasets, bases).  With k = #datasets calling a footprint (fdr <= cutoff) and
+    n = #datasets in which the base lies in a hotspot, the prior is (n-k+c)/(n+2c); bases
+    outside a dataset's hotspots get 1."""
+    fdr = np.asarray(fdr)
+    w = np.asarray(w)
+    called = np.count_nonzero(fdr <= cutoff, axis=0)
+    covered = np.sum(w, axis=0)
+    unocc = covered - called + pseudocount
+    occ = called + pseudocount
+    row = unocc / (unocc + occ)
+    return np.where(w == 0, 1.0, np.ones(fdr.shape) * row[np.newaxis, :])
 
 
 def compute_delta_prior(obs, exp, fdr, beta_prior, cutoff=0.05):
-    """posterior.py:45-90"""
+    """Point estimate of the expected depletion at footprinted bases (posterior.py:45-90):
+    precision-weighted mean over datasets of the Beta posterior mean of obs / max(exp, obs),
+    using only datasets whose fdr passes `cutoff`; bases no dataset supports get 1."""
     import scipy.stats
 
-    (n, w) = obs.shape
-    mus = np.ones((n, w))
-    ws = np.ones((n, w))
-    for i in range(n):
-        k = obs[i, :]
-        nn = np.max(np.vstack([exp[i, :], obs[i, :]]), axis=0)
-        mu, v = scipy.stats.beta.stats(k + beta_prior[i][0], nn - k + beta_prior[i][1], loc=0,
-                                       scale=1, moments="mv")
-        mus[i, :] = mu
-        ws[i, :] = 1 / np.sqrt(v)
-    ws[fdr > cutoff] = 0
+    obs = np.asarray(obs, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    prior = np.asarray(beta_prior, dtype=np.float64)
+    trials = np.maximum(exp, obs)
+    mean, var = scipy.stats.beta.stats(obs + prior[:, 0:1], trials - obs + prior[:, 1:2], moments="mv")
     with np.errstate(all="ignore"):
-        delta = np.sum(ws * mus, axis=0) / np.sum(ws, axis=0)
+        weight = 1.0 / np.sqrt(var)
+        weight[np.asarray(fdr) > cutoff] = 0
+        delta = (weight * mean).sum(axis=0) / weight.sum(axis=0)
     delta[np.isnan(delta)] = 1
     return delta
 
 
 def log_likelihood(obs, exp, dm, delta=1, w=3):
-    """posterior.py:93-121"""
-    res = np.ones((obs.shape[0], obs.shape[1]), order="c")
-    n = obs.shape[0]
-    for i in range(n):
-        res[i, :] = windowing.sum(dm[i].log_pmf_values(exp[i, :] * delta, obs[i, :]), w)
-    return res
+    """Windowed NB log-likelihood per dataset and base (posterior.py:93-121): row i is
+    windowing.sum(dm[i].log_pmf_values(exp[i] * delta, obs[i]), w), edges 1.0."""
+    obs = np.asarray(obs, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    out = np.ones(obs.shape, order="c")
+    for i, model in enumerate(dm[:obs.shape[0]] if hasattr(dm, "__getitem__") else dm):
+        scaled = np.ascontiguousarray(exp[i] * delta)
+        out[i] = windowing.sum(model.log_pmf_values(scaled, np.ascontiguousarray(obs[i])), w)
+    return out
 
 
 def posterior(prior, ll_on, ll_off):
-    """posterior.py:124-149"""
+    """log P(unoccupied | data) (posterior.py:124-149)."""
     with np.errstate(all="ignore"):
-        prior_on = np.log(1 - prior)
-        prior_off = np.log(prior)
-        p_off = prior_off + ll_off
-        p_on = prior_on + ll_on
-        denom = np.logaddexp(p_on, p_off)
-        return p_off - denom
+        occupied = np.log(1 - prior) + ll_on
+        unoccupied = np.log(prior) + ll_off
+        return unoccupied - np.logaddexp(occupied, unoccupied)
