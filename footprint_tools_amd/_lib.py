@@ -39,6 +39,8 @@ class ScanDesc(C.Structure):
         ("n_scales", C.c_int32),
         ("scales", C.c_int32 * MAX_SCALES),
         ("dm_id", C.c_int32),
+        ("dm_ids", C.c_void_p),
+        ("n_dm", C.c_int32),
         ("nb_mode", C.c_int32),
         ("counts_plus", C.c_void_p),
         ("counts_minus", C.c_void_p),
@@ -62,6 +64,8 @@ class FdrDesc(C.Structure):
         ("times", C.c_int32),
         ("seed", C.c_uint64),
         ("dm_id", C.c_int32),
+        ("dm_ids", C.c_void_p),
+        ("n_dm", C.c_int32),
         ("exp", C.c_void_p),
         ("winp", C.c_void_p),
         ("efdr_out", C.c_void_p),
@@ -202,6 +206,24 @@ class Context(object):
                 check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
                 self._dm_slots[key] = slot
             return slot
+
+    def dispersion_slots(self, models):
+        """Upload a list of (mu_params, r_params) into CONSECUTIVE slots (for per-interval
+        models); returns the first slot."""
+        n = len(models)
+        if n < 1 or n > MAX_DM:
+            raise ValueError("need 1..%d models" % MAX_DM)
+        with self._lock:
+            first = 0 if self._dm_next % MAX_DM + n > MAX_DM else self._dm_next % MAX_DM
+            for i, (mu, r) in enumerate(models):
+                mu, r = f64(mu).ravel(), f64(r).ravel()
+                slot = first + i
+                for k in [k for k, v in self._dm_slots.items() if v == slot]:
+                    del self._dm_slots[k]
+                check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
+                self._dm_slots[(mu.tobytes(), r.tobytes())] = slot
+            self._dm_next = first + n
+            return first
 
     def synchronize(self):
         check(self.L.fpt_ctx_synchronize(self.h))

@@ -378,8 +378,12 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     if (int rc = check_ctx(c)) return rc;
     if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
     if (!c->have_table) return fail(FPT_ERR_INVALID, "bias table not set");
-    if (d->dm_id < 0 || d->dm_id >= FPT_MAX_DISPERSION_MODELS || !c->have_model[d->dm_id])
-        return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id);
+    const int n_dm = d->dm_ids ? d->n_dm : 1;
+    if (n_dm < 1 || d->dm_id < 0 || d->dm_id + n_dm > FPT_MAX_DISPERSION_MODELS)
+        return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range", d->dm_id, d->dm_id + n_dm);
+    for (int i = 0; i < n_dm; ++i)
+        if (!c->have_model[d->dm_id + i])
+            return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
     if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
     if (d->n_intervals == 0) return FPT_OK;
     const int hw = d->half_win_width, shw = d->smoothing_half_win_width;
@@ -418,6 +422,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     sl.pval_out = d->pval_out;
     sl.winp_out = d->winp_out;
     sl.status_out = d->status_out;
+    sl.dm_ids = d->dm_ids;
 
     struct launch_t {
         int nt;
@@ -515,7 +520,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
                           (d->nb_mode == FPT_NB_AUTO && sl.total_bases >= 8 * memo_n);
     void *d_memo = nullptr;
     if (use_memo)
-        if (int rc = ws_get(c, 8, (size_t)memo_n * 16, &d_memo)) return rc;
+        if (int rc = ws_get(c, 8, (size_t)memo_n * 16 * n_dm, &d_memo)) return rc;
 #ifdef FPT_ABLATE
     if (const char *e = getenv("FPT_ABLATE")) sl.ablate = atoi(e);
 #endif
@@ -530,7 +535,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
 
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used] : c->ev0, c->stream));
     if (use_memo) {  // rebuilt on every call: part of the timed work, never reused across calls
-        fptk::launch_nb_memo(c->stream, sl.model, c->memo_exp, c->memo_obs, d_memo);
+        fptk::launch_nb_memo(c->stream, sl.model, n_dm, c->memo_exp, c->memo_obs, d_memo);
         if (int rc = launch_ok("k_nb_memo")) return rc;
     }
     // memo mode runs two passes per size class: the light memo-only instance over every tile,
@@ -604,8 +609,12 @@ int fpt_timing_read(fpt_ctx *c, float *ms_out, int cap, int *n_out) {
 int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     if (int rc = check_ctx(c)) return rc;
     if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
-    if (d->dm_id < 0 || d->dm_id >= FPT_MAX_DISPERSION_MODELS || !c->have_model[d->dm_id])
-        return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id);
+    const int n_dm = d->dm_ids ? d->n_dm : 1;
+    if (n_dm < 1 || d->dm_id < 0 || d->dm_id + n_dm > FPT_MAX_DISPERSION_MODELS)
+        return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range", d->dm_id, d->dm_id + n_dm);
+    for (int i = 0; i < n_dm; ++i)
+        if (!c->have_model[d->dm_id + i])
+            return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
     if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
     if (d->n_intervals == 0) return FPT_OK;
     if (d->times < 1 || d->times > 1000000) return fail(FPT_ERR_INVALID, "times %d out of range", d->times);
@@ -633,9 +642,9 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     while (n2 < lmax) n2 <<= 1;
     const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
     void *d_memo;
-    if (int rc = ws_get(c, 8, (size_t)memo_n * 16, &d_memo)) return rc;
+    if (int rc = ws_get(c, 8, (size_t)memo_n * 16 * n_dm, &d_memo)) return rc;
     const double *model = c->d_models + (size_t)d->dm_id * kModelDoubles;
-    fptk::launch_nb_memo(c->stream, model, c->memo_exp, c->memo_obs, d_memo);
+    fptk::launch_nb_memo(c->stream, model, n_dm, c->memo_exp, c->memo_obs, d_memo);
     if (int rc = launch_ok("k_nb_memo")) return rc;
     fptk::fdr_launch fl{};
     fl.n_intervals = d->n_intervals;
@@ -653,6 +662,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.winp = d->winp;
     fl.efdr = d->efdr_out;
     fl.null_uniform = d->null_uniform;
+    fl.dm_ids = d->dm_ids;
     fl.n2_max = n2;
     HIP_TRY(fptk::launch_fdr(c->stream, fl));
     return launch_ok("k_fdr_null");

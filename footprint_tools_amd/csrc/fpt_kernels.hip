@@ -267,6 +267,7 @@ struct scan_args {
     int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
+    const int32_t *dm_ids;       // per interval: dispersion-model slot relative to `model` (or nullptr)
 };
 #ifdef FPT_ABLATE
 #define ABL(bit) (a.ablate & (bit))
@@ -286,9 +287,12 @@ __device__ __forceinline__ double2 nb_pz_direct(double r, double mu, int32_t k) 
 
 // (p, z) for every integer pair (exp, obs) of the table: the same device functions the
 // direct path calls, so a lookup returns bit-identical values.
-__global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ model, int memo_exp,
-                                                    int memo_obs, double2 *__restrict__ memo) {
+__global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ models, int memo_exp,
+                                                    int memo_obs, double2 *__restrict__ memos) {
+    // blockIdx.y = model slot: one table per dispersion model in use
     __shared__ double par[24];
+    const double *model = models + (size_t)blockIdx.y * 24;
+    double2 *memo = memos + (size_t)blockIdx.y * memo_exp * memo_obs;
     if (threadIdx.x < 24) par[threadIdx.x] = model[threadIdx.x];
     __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -578,7 +582,6 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     if (!MO && a.redo && a.redo[a.tile_first + blockIdx.x] == 0) return;  // second pass: flagged tiles only
     const double *tbl = TBLG ? a.table : smem;  // kTable + 1 (+1 pad to keep 16-B alignment)
     double *par_lds = smem + (TBLG ? 0 : (kTable + 2));  // 24 (unused when MO)
-    const double *par = MO ? a.model : par_lds;
     double *cP = par_lds + (MO ? 0 : 24);     // counts '+', scratch in C, expected '+' for D
     double *cM = cP + a.nc_max;
     double *pP = cM + a.nc_max;               // propensities
@@ -624,7 +627,14 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     // ---- A: stage table, model, counts and sequence codes
     if (!TBLG)
         for (int i = tid; i <= kTable; i += NT) smem[i] = a.table[i];
-    if (!MO && tid < 24) par_lds[tid] = a.model[tid];
+    // dispersion model of this interval (dm_ids: one slot index per interval, else slot 0 of
+    // the launch): parameters staged in LDS (scalar loads from the table when MO), memo table
+    // of that model
+    const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
+    const double *model = a.model + (size_t)dm * 24;
+    const double2 *memo = a.memo ? a.memo + (size_t)dm * a.memo_exp * a.memo_obs : nullptr;
+    const double *par = MO ? model : par_lds;
+    if (!MO && tid < 24) par_lds[tid] = model[tid];
     for (int v = tid; v < nc; v += NT) {
         cP[v] = a.counts_plus[cbase + v];
         cM[v] = a.counts_minus[cbase + v];
@@ -706,7 +716,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     bool zd = false;
     if (tid < nt) ex = eP[pad + 1 + tid] + eM[pad + tid];
     const int32_t k = fptm::c_int(ob);
-    if (!MO && !a.memo && !ABL(2)) {
+    if (!MO && !memo && !ABL(2)) {
         // Direct mode: every base evaluates incbet itself.  Lanes are regrouped first so that a
         // wavefront mostly runs ONE of incbet's expansions (power series / continued fraction 1 /
         // continued fraction 2) on similar observed counts: a counting sort of the tile's bases
@@ -762,9 +772,9 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         if (ABL(2)) {
             pv = 0.5;
             z = ob * 0.01;
-        } else if (a.memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
+        } else if (memo && ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex && k >= 0 &&
                    k < a.memo_obs) {
-            const double2 pz = a.memo[ei * a.memo_obs + k];
+            const double2 pz = memo[ei * a.memo_obs + k];
             pv = pz.x;
             z = pz.y;
             zd = fptm::piecewise<5>(par + 9, ex) == 0.0;  // dispersion.pyx:160-161
@@ -852,17 +862,19 @@ struct fdr_args {
     const double *winp;
     double *efdr;
     const double *null_uniform;
+    const int32_t *dm_ids;  // per interval model slot relative to `model`, or nullptr
     int32_t n2_max;      // LDS capacity: power of two >= longest interval
     double inv_sqrt_k;
 };
 
 // smallest k with cdf(k) >= u, returned as (cdf(k), ndtri(1 - cdf(k))): inverse-CDF sampling of
 // the NB count at expected value `ex` together with the p-value of the draw.
-__device__ __forceinline__ double2 nb_inverse_cdf(const fdr_args &a, const double *par, double ex, double u) {
+__device__ __forceinline__ double2 nb_inverse_cdf(const fdr_args &a, const double2 *memo, const double *par,
+                                                  double ex, double u) {
     const int ei = (int)ex;
     int lo = -1;  // largest k known to have cdf(k) < u
     if (ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex) {
-        const double2 *row = a.memo + (size_t)ei * a.memo_obs;
+        const double2 *row = memo + (size_t)ei * a.memo_obs;
         const double2 last = row[a.memo_obs - 1];
         if (!(last.x < u)) {  // the answer is inside the table (also taken for NaN rows)
             int l = 0, h = a.memo_obs - 1;  // invariant: cdf(h) >= u
@@ -929,7 +941,9 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
 
-    if (tid < 24) par[tid] = a.model[tid];
+    const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
+    const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
+    if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
     // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last)
     for (int i = tid; i < np2; i += NT) {
         double v = fptm::kInf;
@@ -986,7 +1000,7 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
                 const uint64_t gbase = (uint64_t)(a.base_index0 + off + t);
                 const double u = a.null_uniform ? a.null_uniform[(size_t)(off + t) * a.times + s]
                                                 : philox_uniform(a.seed, gbase, (uint32_t)s);
-                const double2 pz = nb_inverse_cdf(a, par, a.exp[off + t], u);
+                const double2 pz = nb_inverse_cdf(a, memo, par, a.exp[off + t], u);
                 const bool fin = isfinite(pz.y);
                 zv = fin ? pz.y : 0.0;
                 zc = fin ? 0 : 1;
@@ -1253,14 +1267,16 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo_obs = sl.memo_obs;
     a.ablate = sl.ablate;
     a.redo = sl.redo;
+    a.dm_ids = sl.dm_ids;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
     hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only), dim3(grid), dim3(nt), lds, st, a);
 }
 
-void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo) {
+void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs,
+                    void *memo) {
     int n = memo_exp * memo_obs;
-    hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256), dim3(256), 0, st, model, memo_exp, memo_obs,
-                       (double2 *)memo);
+    hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256, n_models), dim3(256), 0, st, models, memo_exp,
+                       memo_obs, (double2 *)memo);
 }
 
 size_t fdr_lds_bytes(int n2) {
@@ -1284,6 +1300,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.winp = fl.winp;
     a.efdr = fl.efdr;
     a.null_uniform = fl.null_uniform;
+    a.dm_ids = fl.dm_ids;
     a.n2_max = fl.n2_max;
     a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
     size_t lds = fdr_lds_bytes(fl.n2_max);
@@ -1299,6 +1316,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             b.efdr += done * (int64_t)fl.interval_len;
             b.base_index0 += done * (int64_t)fl.interval_len;
             if (b.null_uniform) b.null_uniform += done * (int64_t)fl.interval_len * fl.times;
+            if (b.dm_ids) b.dm_ids += done;
         }
         hipLaunchKernelGGL(k_fdr_null<256>, dim3((unsigned)n), dim3(256), lds, st, b);
     }

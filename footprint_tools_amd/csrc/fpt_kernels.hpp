@@ -33,6 +33,7 @@ struct scan_launch {
     int32_t memo_exp, memo_obs;
     int32_t ablate;
     int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
+    const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
 };
 
@@ -49,6 +50,7 @@ struct fdr_launch {
     const double *exp, *winp;
     double *efdr;
     const double *null_uniform;
+    const int32_t *dm_ids;
     int32_t n2_max;
 };
 
@@ -70,7 +72,7 @@ void launch_window_rows(hipStream_t st, int op, const double *x, const double *w
 size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
 hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
-void launch_nb_memo(hipStream_t st, const double *model, int memo_exp, int memo_obs, void *memo);
+void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo);
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
                    unsigned long long *hist);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

@@ -83,8 +83,10 @@ class FootprintScanner(object):
         self.ctx = ctx or _lib.get_ctx()
         self.table = _lib.f64(bias_table)
         self.dflt = float(default_propensity)
-        self.mu = _lib.f64(dispersion.mu_params).ravel()
-        self.r = _lib.f64(dispersion.r_params).ravel()
+        # one model, or a list of models selected per interval through `dm_ids`
+        self.models = list(dispersion) if isinstance(dispersion, (list, tuple)) else [dispersion]
+        self.mu = _lib.f64(self.models[0].mu_params).ravel()
+        self.r = _lib.f64(self.models[0].r_params).ravel()
         self.hw, self.shw, self.clip = int(half_win_width), int(smoothing_half_win_width), float(smoothing_clip)
         self.scales = tuple(int(s) for s in scales)
         if len(self.scales) > _lib.MAX_SCALES:
@@ -105,8 +107,9 @@ class FootprintScanner(object):
     # ---- device-pointer level ----------------------------------------------------------
     def scan_dev(self, n_intervals, counts_plus, counts_minus, seq, exp_out=None, obs_out=None,
                  pval_out=None, winp_out=None, interval_len=None, interval_off_dev=None,
-                 interval_off_host=None, status_out=None):
-        """Enqueue the fused scan on device pointers (ints); does not synchronise."""
+                 interval_off_host=None, status_out=None, dm_ids_dev=None):
+        """Enqueue the fused scan on device pointers (ints); does not synchronise.
+        dm_ids_dev: device int32[n_intervals] of indices into the scanner's model list."""
         ctx = self.ctx
         ctx.set_bias_table(self.table, self.dflt)
         d = _lib.ScanDesc()
@@ -122,12 +125,19 @@ class FootprintScanner(object):
         d.n_scales = len(self.scales)
         for i, s in enumerate(self.scales):
             d.scales[i] = s
-        d.dm_id = ctx.dispersion_slot(self.mu, self.r)
+        d.dm_id = self._model_slot()
+        d.dm_ids, d.n_dm = dm_ids_dev, len(self.models)
         d.nb_mode = self.nb_mode
         d.counts_plus, d.counts_minus, d.seq = counts_plus, counts_minus, seq
         d.exp_out, d.obs_out, d.pval_out, d.winp_out = exp_out, obs_out, pval_out, winp_out
         d.status_out = status_out
         _lib.check(ctx.L.fpt_scan_dev(ctx.h, C.byref(d)))
+
+    def _model_slot(self):
+        ctx = self.ctx
+        if len(self.models) == 1:
+            return ctx.dispersion_slot(self.mu, self.r)
+        return ctx.dispersion_slots([(m.mu_params, m.r_params) for m in self.models])
 
     def last_kernel_ms(self):
         ms = C.c_float()
@@ -135,8 +145,9 @@ class FootprintScanner(object):
         return ms.value
 
     # ---- numpy level ---------------------------------------------------------------------
-    def scan(self, counts_plus, counts_minus, seq, interval_len=None, interval_off=None):
-        """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status)."""
+    def scan(self, counts_plus, counts_minus, seq, interval_len=None, interval_off=None, dm_ids=None):
+        """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status).
+        dm_ids: optional per-interval index into the scanner's list of dispersion models."""
         ctx = self.ctx
         cp, cm = _lib.f64(counts_plus).ravel(), _lib.f64(counts_minus).ravel()
         if isinstance(seq, str):
@@ -168,11 +179,17 @@ class FootprintScanner(object):
             d_off = None
             if off is not None:
                 d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
+            d_dm = None
+            if dm_ids is not None:
+                ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
+                if ids.size != n_iv or ids.min() < 0 or ids.max() >= len(self.models):
+                    raise ValueError("dm_ids needs one valid model index per interval")
+                d_dm = DeviceArray(ctx, max(ids.nbytes, 16)).upload(ids); bufs.append(d_dm)
             t8 = total * 8
             self.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, exp_out=d_out.ptr, obs_out=d_out.ptr + t8,
                           pval_out=d_out.ptr + 2 * t8, winp_out=(d_out.ptr + 3 * t8) if S else None,
                           interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
-                          interval_off_host=off, status_out=d_st.ptr)
+                          interval_off_host=off, status_out=d_st.ptr, dm_ids_dev=d_dm.ptr if d_dm else None)
             ctx.synchronize()
             flat = d_out.download(np.float64, (3 + S) * total)
             status = d_st.download(np.int32, n_iv)
@@ -184,7 +201,7 @@ class FootprintScanner(object):
 
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
     def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,
-                interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None):
+                interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None, dm_ids_dev=None):
         """Enqueue the null sampling + ranking on device pointers; does not synchronise."""
         ctx = self.ctx
         d = _lib.FdrDesc()
@@ -193,12 +210,13 @@ class FootprintScanner(object):
         d.interval_off = interval_off_dev
         d.base_index0 = int(base_index0)
         d.half_win_width, d.times, d.seed = int(half_win_width), int(times), int(seed)
-        d.dm_id = ctx.dispersion_slot(self.mu, self.r)
+        d.dm_id = self._model_slot()
+        d.dm_ids, d.n_dm = dm_ids_dev, len(self.models)
         d.exp, d.winp, d.efdr_out, d.null_uniform = exp, winp, efdr_out, null_uniform
         _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))
 
     def fdr(self, exp, winp, times=100, seed=0, half_win_width=3, interval_len=None, interval_off=None,
-            base_index0=0, null_uniform=None):
+            base_index0=0, null_uniform=None, dm_ids=None):
         """Empirical FDR of observed window p-values (host arrays in / out)."""
         ctx = self.ctx
         exp, winp = _lib.f64(exp).ravel(), _lib.f64(winp).ravel()
@@ -221,9 +239,14 @@ class FootprintScanner(object):
                 if nu.size != total * times:
                     raise ValueError("null_uniform needs total_bases * times values")
                 d_u = DeviceArray(ctx, nu.nbytes).upload(nu); bufs.append(d_u)
+            d_dm = None
+            if dm_ids is not None:
+                ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
+                d_dm = DeviceArray(ctx, max(ids.nbytes, 16)).upload(ids); bufs.append(d_dm)
             self.fdr_dev(n_iv, d_e.ptr, d_w.ptr, d_o.ptr, times, seed, half_win_width,
                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
-                         base_index0=base_index0, null_uniform=d_u.ptr if d_u else None)
+                         base_index0=base_index0, null_uniform=d_u.ptr if d_u else None,
+                         dm_ids_dev=d_dm.ptr if d_dm else None)
             ctx.synchronize()
             return d_o.download(np.float64, total)
         finally:

@@ -137,7 +137,13 @@ typedef struct fpt_scan_desc {
     double smoothing_clip;            /* prediction(smoothing_clip=0.01)          predict.pyx:85 */
     int32_t n_scales;                 /* number of Stouffer windows (detect uses one, hw=3) */
     int32_t scales[FPT_MAX_SCALES];   /* half window widths                       detect.py:84   */
-    int32_t dm_id;                    /* dispersion model slot */
+    int32_t dm_id;                    /* dispersion model slot (first slot when dm_ids is given) */
+    /* optional per-interval dispersion models: dm_ids (DEVICE int32[n_intervals]) holds, for each
+     * interval, a slot index in [0, n_dm) relative to dm_id; slots dm_id .. dm_id+n_dm-1 must be
+     * set.  The reference has one model per dataset (cli/detect.py:334-336; a list of models in
+     * stats/posterior.py:119); a batch that mixes intervals of several datasets uses this. */
+    const int32_t *dm_ids;
+    int32_t n_dm;
     int32_t nb_mode;                  /* how p = nbinom.cdf(obs; exp) is evaluated per base:
                                        * FPT_NB_AUTO, FPT_NB_DIRECT or FPT_NB_MEMO (see below) */
     /* inputs (DEVICE).  With pad = hw + shw, interval i of length L_i owns
@@ -197,7 +203,9 @@ typedef struct fpt_fdr_desc {
     int32_t half_win_width;           /* Stouffer window of the null tracks (detect: 3) */
     int32_t times;                    /* fdr_shuffle_n (detect default 100) */
     uint64_t seed;
-    int32_t dm_id;
+    int32_t dm_id;                    /* model slot (first slot when dm_ids is given) */
+    const int32_t *dm_ids;            /* optional DEVICE int32[n_intervals], values in [0, n_dm) */
+    int32_t n_dm;
     const double *exp;                /* DEVICE: expected counts track */
     const double *winp;               /* DEVICE: observed window p-values, same window */
     double *efdr_out;                 /* DEVICE: empirical FDR track */

@@ -332,6 +332,38 @@ def test_scan_empty_and_partial_outputs(fpt, orc):
     assert rel_err(d_p.download(np.float64, n_iv * L), p) < P_TOL
 
 
+def test_per_interval_dispersion_models(fpt, orc):
+    """dm_ids: every interval carries its own dispersion model (a batch mixing datasets)."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    keys = ["A", "B", "C"]
+    models = [_DM(lat["mu_" + k], lat["r_" + k]) for k in keys]
+    n_iv, L, hw, shw, clip, scales = 10, 300, 5, 50, 0.01, (3,)
+    l = L + 2 * (hw + shw) + 1
+    cp, cm = orc.synth_counts(12, 0, n_iv * l, 0), orc.synth_counts(12, 0, n_iv * l, 1)
+    sq = orc.synth_bases(12, 0, n_iv * (l + 6))
+    ids = np.array([0, 1, 2, 2, 1, 0, 0, 2, 1, 1], dtype=np.int32)
+    for mode in ("direct", "memo"):
+        sc = FootprintScanner(table, models, hw, shw, clip, scales, nb_mode=mode)
+        out = sc.scan(cp, cm, sq, interval_len=L, dm_ids=ids)
+        for i in range(n_iv):
+            k = keys[ids[i]]
+            e, o, p, wp = orc.detect_batch(cp[i * l:(i + 1) * l], cm[i * l:(i + 1) * l],
+                                           sq[i * (l + 6):(i + 1) * (l + 6)], 1, L, hw, shw, clip, table,
+                                           lat["mu_" + k], lat["r_" + k], np.array(scales, np.int32))
+            sl = slice(i * L, (i + 1) * L)
+            assert np.array_equal(out["exp"][sl], e)
+            assert rel_err(out["pval"][sl], p) < P_TOL and rel_err(out["winp"][0][sl], wp[0]) < P_TOL
+    ef = sc.fdr(out["exp"], out["winp"][0], times=30, seed=4, interval_len=L, dm_ids=ids)
+    for i in (1, 2, 5):
+        k = keys[ids[i]]
+        sl = slice(i * L, (i + 1) * L)
+        want = orc.fdr_null(lat["mu_" + k], lat["r_" + k], out["exp"][sl], out["winp"][0][sl], 3, 30, seed=4,
+                            base0=i * L)
+        assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (L * 30)
+
+
 def test_fused_scan_ragged(fpt, orc):
     """variable-length intervals (config 4 shape): CSR offsets, tiles binned by size."""
     from footprint_tools_amd.scan import FootprintScanner

@@ -42,6 +42,13 @@ def test_scan_desc_layout_matches_header(lib, tmp_path):
     size, o_scales, o_cp, o_st = map(int, subprocess.check_output([str(exe)]).split())
     D = lib.ScanDesc
     assert (C.sizeof(D), D.scales.offset, D.counts_plus.offset, D.status_out.offset) == (size, o_scales, o_cp, o_st)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fpt.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(fpt_fdr_desc), offsetof(fpt_fdr_desc, seed), offsetof(fpt_fdr_desc, exp),'
+                   'offsetof(fpt_fdr_desc, null_uniform));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, o_seed, o_exp, o_nu = map(int, subprocess.check_output([str(exe)]).split())
+    F = lib.FdrDesc
+    assert (C.sizeof(F), F.seed.offset, F.exp.offset, F.null_uniform.offset) == (size, o_seed, o_exp, o_nu)
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device failure path")
