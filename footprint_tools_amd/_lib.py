@@ -70,6 +70,7 @@ class FdrDesc(C.Structure):
         ("winp", C.c_void_p),
         ("efdr_out", C.c_void_p),
         ("null_uniform", C.c_void_p),
+        ("null_winp_out", C.c_void_p),
     ]
 
 

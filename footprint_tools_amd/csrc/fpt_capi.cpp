@@ -59,6 +59,10 @@ struct fpt_ctx {
     int tev_used = 0;
     int n_cu = 0;
     int memo_exp = 256, memo_obs = 256;
+    // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
+    // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
+    // the 1e-4 tail of the widest rows is hit in every batch.
+    int fdr_memo_obs = 2048;
     // tile-table cache of the last ragged batch (reused while the offsets and geometry match)
     std::vector<int64_t> plan_off;
     int plan_H = -1;
@@ -640,12 +644,16 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     if (lmax > 4096) return fail(FPT_ERR_INVALID, "interval of %d bases: fpt_fdr_dev handles at most 4096", lmax);
     int n2 = 64;
     while (n2 < lmax) n2 <<= 1;
-    const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
+    const int64_t memo_n = (int64_t)c->memo_exp * c->fdr_memo_obs;
     void *d_memo;
     if (int rc = ws_get(c, 8, (size_t)memo_n * 16 * n_dm, &d_memo)) return rc;
     const double *model = c->d_models + (size_t)d->dm_id * kModelDoubles;
-    fptk::launch_nb_memo(c->stream, model, n_dm, c->memo_exp, c->memo_obs, d_memo);
+    fptk::launch_nb_memo(c->stream, model, n_dm, c->memo_exp, c->fdr_memo_obs, d_memo);
     if (int rc = launch_ok("k_nb_memo")) return rc;
+    void *d_guide;
+    if (int rc = ws_get(c, 6, fptk::nb_guide_bytes(n_dm, c->memo_exp), &d_guide)) return rc;
+    fptk::launch_nb_guide(c->stream, d_memo, n_dm, c->memo_exp, c->fdr_memo_obs, d_guide);
+    if (int rc = launch_ok("k_nb_guide")) return rc;
     fptk::fdr_launch fl{};
     fl.n_intervals = d->n_intervals;
     fl.interval_len = d->interval_off ? 0 : d->interval_len;
@@ -656,13 +664,18 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.seed = d->seed;
     fl.model = model;
     fl.memo = d_memo;
+    fl.guide = d_guide;
     fl.memo_exp = c->memo_exp;
-    fl.memo_obs = c->memo_obs;
+    fl.memo_obs = c->fdr_memo_obs;
     fl.exp = d->exp;
     fl.winp = d->winp;
     fl.efdr = d->efdr_out;
     fl.null_uniform = d->null_uniform;
+    fl.null_out = d->null_winp_out;
     fl.dm_ids = d->dm_ids;
+#ifdef FPT_ABLATE
+    if (const char *e = getenv("FPT_ABLATE")) fl.ablate = atoi(e);
+#endif
     fl.n2_max = n2;
     HIP_TRY(fptk::launch_fdr(c->stream, fl));
     return launch_ok("k_fdr_null");
@@ -674,6 +687,7 @@ int fpt_set_memo_dims(fpt_ctx *c, int memo_exp, int memo_obs) {
         return fail(FPT_ERR_INVALID, "memo dims out of range");
     c->memo_exp = memo_exp;
     c->memo_obs = memo_obs;
+    c->fdr_memo_obs = memo_obs;
     return FPT_OK;
 }
 

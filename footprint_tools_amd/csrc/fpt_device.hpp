@@ -296,13 +296,24 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// uniform in [0, 1) with 53 random bits for (seed, base, sample)
-__host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
+// Two uniforms in [0, 1) with 53 random bits each from ONE Philox block keyed by
+// (seed, base, pair): words (0,1) are the draw of sample 2*pair, words (2,3) of sample 2*pair+1.
+__host__ __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t base, uint32_t pair,
+                                                         double &u0, double &u1) {
     uint32_t o[4];
-    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), sample, 0x66707464u /* "fptd" */,
+    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), pair, 0x66707464u /* "fptd" */,
                   (uint32_t)seed, (uint32_t)(seed >> 32), o);
     const uint64_t x = ((uint64_t)o[1] << 32) | o[0];
-    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    const uint64_t y = ((uint64_t)o[3] << 32) | o[2];
+    u0 = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    u1 = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// the uniform of one (seed, base, sample)
+__host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
+    double u0, u1;
+    philox_uniform2(seed, base, sample >> 1, u0, u1);
+    return (sample & 1u) ? u1 : u0;
 }
 
 }  // namespace fptd

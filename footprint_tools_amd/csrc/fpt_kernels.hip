@@ -13,6 +13,8 @@
 // Reference citations are paths under vierstralab/footprint-tools v1.3.7.
 #include "fpt_kernels.hpp"
 
+#include <cstdlib>
+
 #include "fpt_device.hpp"
 
 using namespace fptd;
@@ -857,36 +859,48 @@ struct fdr_args {
     uint64_t seed;
     const double *model;
     const double2 *memo;
+    const uint16_t *guide;  // kGuide entries per (model, integer exp) row of the memo
     int32_t memo_exp, memo_obs;
     const double *exp;
     const double *winp;
     double *efdr;
     const double *null_uniform;
+    double *null_out;       // optional [base][times] null window p-values
     const int32_t *dm_ids;  // per interval model slot relative to `model`, or nullptr
+    int32_t ablate;      // timing-only diagnostics (FPT_ABLATE builds)
     int32_t n2_max;      // LDS capacity: power of two >= longest interval
     double inv_sqrt_k;
 };
 
-// smallest k with cdf(k) >= u, returned as (cdf(k), ndtri(1 - cdf(k))): inverse-CDF sampling of
-// the NB count at expected value `ex` together with the p-value of the draw.
-__device__ __forceinline__ double2 nb_inverse_cdf(const fdr_args &a, const double2 *memo, const double *par,
-                                                  double ex, double u) {
-    const int ei = (int)ex;
-    int lo = -1;  // largest k known to have cdf(k) < u
-    if (ex >= 0.0 && ex < (double)a.memo_exp && (double)ei == ex) {
-        const double2 *row = memo + (size_t)ei * a.memo_obs;
-        const double2 last = row[a.memo_obs - 1];
-        if (!(last.x < u)) {  // the answer is inside the table (also taken for NaN rows)
-            int l = 0, h = a.memo_obs - 1;  // invariant: cdf(h) >= u
-            while (l < h) {
-                const int mid = (l + h) >> 1;
-                if (row[mid].x >= u) h = mid; else l = mid + 1;
-            }
-            return row[h];
+// Guide table of the inverse-CDF sampler: guide[row][slot] = smallest k with
+// cdf(k) >= guide_edge(slot) (or the last tabulated k), so a draw u starts its search at
+// guide[row][guide_slot(u)], knows the answer is no later than the next entry, and walks a step
+// or two instead of bisecting the whole row (every step is a divergent gather, and a wavefront
+// waits for its slowest lane).  Each row has kGuide + 1 entries, the last is the table end.
+constexpr int kGuide = fptm::kGuideSlots;
+
+__global__ void __launch_bounds__(256) k_nb_guide(const double2 *__restrict__ memo, int memo_exp, int memo_obs,
+                                                  uint16_t *__restrict__ guide) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= memo_exp * (kGuide + 1)) return;
+    const int ei = i / (kGuide + 1), g = i % (kGuide + 1);
+    const double2 *row = memo + ((size_t)blockIdx.y * memo_exp + ei) * memo_obs;
+    int l = memo_obs - 1;  // entry kGuide: the end of the table
+    if (g < kGuide) {
+        const double t = fptm::guide_edge(g);
+        int h = memo_obs - 1;
+        l = 0;
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (row[mid].x >= t) h = mid; else l = mid + 1;
         }
-        lo = a.memo_obs - 1;
     }
-    // outside the table: gallop, then bisect on the direct evaluation
+    guide[((size_t)blockIdx.y * memo_exp + ei) * (kGuide + 1) + g] = (uint16_t)l;
+}
+
+// Draw beyond the table (or at a non-integer expected value): gallop, then bisect on the direct
+// evaluation.  lo = largest k known to have cdf(k) < u.
+__device__ __forceinline__ double2 nb_inverse_cdf_direct(const double *par, double ex, double u, int lo) {
     bool zd = false;
     const double r = fptm::fit_r(par + 9, ex, &zd);
     const double mu = fptm::fit_mu(par, ex);
@@ -912,17 +926,90 @@ __device__ __forceinline__ double2 nb_inverse_cdf(const fdr_args &a, const doubl
     return make_double2(chi, fptm::ndtri(1.0 - chi));
 }
 
+// Two inverse-CDF NB draws at the same expected value: for each u the z = ndtri(1 - cdf(k)) of the
+// smallest k with cdf(k) >= u.  The guide brackets the answer between two table positions, the
+// first probe interpolates between them, and the walk from there (up while cdf < u, down while
+// the entry below is still >= u) is a step or two.  Every probe after the first falls into the
+// cache line of the first; both draws run interleaved so their gathers overlap.
+__device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_exp, int memo_obs,
+                                           const double *par, double ex, double u0, double u1, double &z0,
+                                           double &z1) {
+    const int ei = (int)ex;
+    int lo0 = -1, lo1 = -1;
+    bool d0 = true, d1 = true;  // still to be evaluated directly
+    if (ex >= 0.0 && ex < (double)memo_exp && (double)ei == ex) {
+        const double2 *row = memo + (size_t)ei * memo_obs;
+        const uint16_t *gr = guide + (size_t)ei * (kGuide + 1);
+        const int kl = memo_obs - 1;
+        double f0, f1;
+        const int s0 = fptm::guide_locate(u0, f0), s1 = fptm::guide_locate(u1, f1);
+        const int a0 = gr[s0], b0 = gr[s0 + 1], a1 = gr[s1], b1 = gr[s1 + 1];  // answer in [a, b]
+        int k0 = a0 + (int)(f0 * (double)(b0 - a0)), k1 = a1 + (int)(f1 * (double)(b1 - a1));
+        double2 e0 = row[k0], e1 = row[k1];
+        // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
+        // below has to be looked at unless the guide already says it is < u (k == a).
+        const bool up0 = e0.x < u0, up1 = e1.x < u1;
+        bool m0 = up0 ? k0 < kl : k0 > a0, m1 = up1 ? k1 < kl : k1 > a1;
+        while (m0 || m1) {
+            const int n0 = k0 + (m0 ? (up0 ? 1 : -1) : 0), n1 = k1 + (m1 ? (up1 ? 1 : -1) : 0);
+            const double2 c0 = row[n0], c1 = row[n1];
+            if (m0) {
+                if (up0) {  // stop at the first entry >= u
+                    k0 = n0;
+                    e0 = c0;
+                    m0 = c0.x < u0 && k0 < kl;
+                } else if (c0.x >= u0) {  // the entry below qualifies too: keep going down
+                    k0 = n0;
+                    e0 = c0;
+                    m0 = k0 > a0;
+                } else {
+                    m0 = false;
+                }
+            }
+            if (m1) {
+                if (up1) {
+                    k1 = n1;
+                    e1 = c1;
+                    m1 = c1.x < u1 && k1 < kl;
+                } else if (c1.x >= u1) {
+                    k1 = n1;
+                    e1 = c1;
+                    m1 = k1 > a1;
+                } else {
+                    m1 = false;
+                }
+            }
+        }
+        z0 = e0.y;
+        z1 = e1.y;
+        d0 = e0.x < u0;  // ran off the table; false for NaN rows: those return the NaN entry
+        d1 = e1.x < u1;
+        lo0 = lo1 = kl;
+    }
+    if (d0 || d1) {  // rare: beyond the table or a non-integer expected value
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < 2; ++j) {
+            if (j ? d1 : d0) {
+                const double z = nb_inverse_cdf_direct(par, ex, j ? u1 : u0, j ? lo1 : lo0).y;
+                if (j) z1 = z; else z0 = z;
+            }
+        }
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
     double *par = smem;                              // 24
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
-    double *zb = skey + n2;                          // n2 tile prefix sums of z
-    int *sidx = reinterpret_cast<int *>(zb + n2);    // n2 original positions
-    int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z
+    double *zb = skey + n2;                          // n2 tile prefix sums of z, even sample
+    double *zb1 = zb + n2;                           // n2 same for the odd sample of the pair
+    int *sidx = reinterpret_cast<int *>(zb1 + n2);   // n2 original positions
+    int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
     int *hist = nf + n2;                             // n2 + 2 histogram / prefix
     int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
+    int *rguide = misc + 8;                          // min(n2, 2048) + 1: #{sorted observed < b / nb}
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -943,6 +1030,7 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
 
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
+    const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * (kGuide + 1);
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
     // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last)
     for (int i = tid; i < np2; i += NT) {
@@ -989,44 +1077,94 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
     }
     __syncthreads();
     const int m = misc[1];
+    // rank guide: null window p-values are close to uniform, so cutting [0, 1] into nb slices
+    // leaves about one observed value per slice and a rank needs a probe or two, not log2(L)
+    const int nb = np2 < 2048 ? np2 : 2048;
+    const double fnp2 = (double)nb;
+    for (int b = tid; b <= nb; b += NT) {
+        const double edge = (double)b / fnp2;
+        int l = 0, h = m;
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (skey[mid] < edge) l = mid + 1; else h = mid;
+        }
+        rguide[b] = l;
+    }
+    __syncthreads();
 
-    // ---- 2. null tracks
+    // ---- 2. null tracks, two samples per pass (one Philox block feeds both)
     const int hs = a.hw;
-    for (int s = 0; s < a.times; ++s) {
+    for (int s = 0; s < a.times; s += 2) {
+        const bool two = s + 1 < a.times;
         for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
-            double zv = 0.0;
+            double z0 = 0.0, z1 = 0.0;
             int zc = 0;
             if (t < L) {
-                const uint64_t gbase = (uint64_t)(a.base_index0 + off + t);
-                const double u = a.null_uniform ? a.null_uniform[(size_t)(off + t) * a.times + s]
-                                                : philox_uniform(a.seed, gbase, (uint32_t)s);
-                const double2 pz = nb_inverse_cdf(a, memo, par, a.exp[off + t], u);
-                const bool fin = isfinite(pz.y);
-                zv = fin ? pz.y : 0.0;
-                zc = fin ? 0 : 1;
+                double u0, u1 = 0.5;
+                if (ABL(512)) {
+                    u0 = 0.37 + 1e-3 * s;
+                    u1 = 0.63 - 1e-3 * s;
+                } else if (a.null_uniform) {
+                    const double *up = a.null_uniform + (size_t)(off + t) * a.times + s;
+                    u0 = up[0];
+                    if (two) u1 = up[1];
+                } else {
+                    philox_uniform2(a.seed, (uint64_t)(a.base_index0 + off + t), (uint32_t)(s >> 1), u0, u1);
+                }
+                if (ABL(1024)) {
+                    z0 = u0 - 0.5;
+                    z1 = u1 - 0.5;
+                } else {
+                    nb_draw_z2(memo, guide, a.memo_exp, a.memo_obs, par, a.exp[off + t], u0, u1, z0, z1);
+                }
+                const bool f0 = isfinite(z0), f1 = isfinite(z1);
+                z0 = f0 ? z0 : 0.0;
+                z1 = f1 ? z1 : 0.0;
+                zc = (f0 ? 0 : 1) | (f1 ? 0 : 1 << 16);
             }
-            wave_scan(zv, zc, lane);
-            zb[t] = zv;
-            nf[t] = zc;
+            zb[t] = scan_add(z0);
+            zb1[t] = scan_add(z1);
+            nf[t] = scan_add(zc);
         }
         __syncthreads();
         for (int t = tid; t < L; t += NT) {
-            double x = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
+            double x0 = 1.0, x1 = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
             if (t >= hs && t < L - hs) {
-                const double sv = tile_range_sum(zb, t - hs, t + hs);
+                const double s0 = tile_range_sum(zb, t - hs, t + hs);
+                const double s1 = tile_range_sum(zb1, t - hs, t + hs);
                 const int sc = tile_range_sum(nf, t - hs, t + hs);
-                x = (sc > 0) ? NAN : fptm::ndtr(-(sv * a.inv_sqrt_k));
+                x0 = (sc & 0xffff) ? NAN : (ABL(2048) ? 0.5 * s0 : fptm::ndtr(-(s0 * a.inv_sqrt_k)));
+                x1 = (sc >> 16) ? NAN : (ABL(2048) ? 0.5 * s1 : fptm::ndtr(-(s1 * a.inv_sqrt_k)));
             }
-            if (isnan(x)) {
-                atomicAdd(&misc[0], 1);
-            } else {
-                int l = 0, h = m;  // first sorted observed value >= x
-                while (l < h) {
-                    const int mid = (l + h) >> 1;
-                    if (skey[mid] >= x) h = mid; else l = mid + 1;
+            if (a.null_out) {
+                double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
+                np_[0] = x0;
+                if (two) np_[1] = x1;
+            }
+            if (ABL(4096)) {
+                if (x0 == 12345.0 || x1 == 12345.0) atomicAdd(&misc[0], 1);
+                continue;
+            }
+            // rank = number of sorted observed values < x: bisect inside the guide's bracket,
+            // both samples in step (NaN ends up anywhere and is not counted)
+            int b0 = (x0 >= 0.0) ? (int)(x0 * fnp2) : 0, b1 = (x1 >= 0.0) ? (int)(x1 * fnp2) : 0;
+            b0 = b0 < nb ? b0 : nb - 1;
+            b1 = b1 < nb ? b1 : nb - 1;
+            int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
+            while (l0 < h0 || l1 < h1) {
+                const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;  // < m whenever that side is live
+                const bool g0 = skey[m0] < x0, g1 = skey[m1] < x1;
+                if (l0 < h0) {
+                    l0 = g0 ? m0 + 1 : l0;
+                    h0 = g0 ? h0 : m0;
                 }
-                atomicAdd(&hist[l], 1);
+                if (l1 < h1) {
+                    l1 = g1 ? m1 + 1 : l1;
+                    h1 = g1 ? h1 : m1;
+                }
             }
+            atomicAdd(isnan(x0) ? &misc[0] : &hist[l0], 1);
+            if (two) atomicAdd(isnan(x1) ? &misc[0] : &hist[l1], 1);
         }
         __syncthreads();
     }
@@ -1279,8 +1417,17 @@ void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo
                        memo_obs, (double2 *)memo);
 }
 
+void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {
+    hipLaunchKernelGGL(k_nb_guide, dim3((memo_exp * (kGuide + 1) + 255) / 256, n_models), dim3(256), 0, st,
+                       (const double2 *)memo, memo_exp, memo_obs, (uint16_t *)guide);
+}
+
+size_t nb_guide_bytes(int n_models, int memo_exp) {
+    return (size_t)n_models * memo_exp * (kGuide + 1) * sizeof(uint16_t);
+}
+
 size_t fdr_lds_bytes(int n2) {
-    return (size_t)(24 + 2 * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8) * sizeof(int);
+    return (size_t)(24 + 3 * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
 }
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
@@ -1294,13 +1441,16 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.seed = fl.seed;
     a.model = fl.model;
     a.memo = (const double2 *)fl.memo;
+    a.guide = (const uint16_t *)fl.guide;
     a.memo_exp = fl.memo_exp;
     a.memo_obs = fl.memo_obs;
     a.exp = fl.exp;
     a.winp = fl.winp;
     a.efdr = fl.efdr;
     a.null_uniform = fl.null_uniform;
+    a.null_out = fl.null_out;
     a.dm_ids = fl.dm_ids;
+    a.ablate = fl.ablate;
     a.n2_max = fl.n2_max;
     a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
     size_t lds = fdr_lds_bytes(fl.n2_max);
@@ -1316,6 +1466,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             b.efdr += done * (int64_t)fl.interval_len;
             b.base_index0 += done * (int64_t)fl.interval_len;
             if (b.null_uniform) b.null_uniform += done * (int64_t)fl.interval_len * fl.times;
+            if (b.null_out) b.null_out += done * (int64_t)fl.interval_len * fl.times;
             if (b.dm_ids) b.dm_ids += done;
         }
         hipLaunchKernelGGL(k_fdr_null<256>, dim3((unsigned)n), dim3(256), lds, st, b);

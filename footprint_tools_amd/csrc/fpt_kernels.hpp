@@ -46,16 +46,21 @@ struct fdr_launch {
     uint64_t seed;
     const double *model;
     const void *memo;
+    const void *guide;  // nb_guide_bytes(), filled by launch_nb_guide after launch_nb_memo
     int32_t memo_exp, memo_obs;
     const double *exp, *winp;
     double *efdr;
     const double *null_uniform;
+    double *null_out;
     const int32_t *dm_ids;
+    int32_t ablate;
     int32_t n2_max;
 };
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl);
 size_t fdr_lds_bytes(int n2);
+void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide);
+size_t nb_guide_bytes(int n_models, int memo_exp);
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
                        double *fwd, double *rev);

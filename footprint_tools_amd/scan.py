@@ -201,7 +201,8 @@ class FootprintScanner(object):
 
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
     def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,
-                interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None, dm_ids_dev=None):
+                interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None, dm_ids_dev=None,
+                null_winp_out=None):
         """Enqueue the null sampling + ranking on device pointers; does not synchronise."""
         ctx = self.ctx
         d = _lib.FdrDesc()
@@ -213,11 +214,13 @@ class FootprintScanner(object):
         d.dm_id = self._model_slot()
         d.dm_ids, d.n_dm = dm_ids_dev, len(self.models)
         d.exp, d.winp, d.efdr_out, d.null_uniform = exp, winp, efdr_out, null_uniform
+        d.null_winp_out = null_winp_out
         _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))
 
     def fdr(self, exp, winp, times=100, seed=0, half_win_width=3, interval_len=None, interval_off=None,
-            base_index0=0, null_uniform=None, dm_ids=None):
-        """Empirical FDR of observed window p-values (host arrays in / out)."""
+            base_index0=0, null_uniform=None, dm_ids=None, return_null=False):
+        """Empirical FDR of observed window p-values (host arrays in / out).  return_null=True
+        also returns the (total_bases, times) null window p-values (detect.py:133)."""
         ctx = self.ctx
         exp, winp = _lib.f64(exp).ravel(), _lib.f64(winp).ravel()
         total = exp.size
@@ -239,16 +242,21 @@ class FootprintScanner(object):
                 if nu.size != total * times:
                     raise ValueError("null_uniform needs total_bases * times values")
                 d_u = DeviceArray(ctx, nu.nbytes).upload(nu); bufs.append(d_u)
-            d_dm = None
+            d_dm = d_n = None
             if dm_ids is not None:
                 ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
                 d_dm = DeviceArray(ctx, max(ids.nbytes, 16)).upload(ids); bufs.append(d_dm)
+            if return_null:
+                d_n = DeviceArray(ctx, max(total * times * 8, 16)); bufs.append(d_n)
             self.fdr_dev(n_iv, d_e.ptr, d_w.ptr, d_o.ptr, times, seed, half_win_width,
                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
                          base_index0=base_index0, null_uniform=d_u.ptr if d_u else None,
-                         dm_ids_dev=d_dm.ptr if d_dm else None)
+                         dm_ids_dev=d_dm.ptr if d_dm else None, null_winp_out=d_n.ptr if d_n else None)
             ctx.synchronize()
-            return d_o.download(np.float64, total)
+            ef = d_o.download(np.float64, total)
+            if d_n:
+                return ef, d_n.download(np.float64, total * times).reshape(total, times)
+            return ef
         finally:
             for b in bufs:
                 b.free()

@@ -174,7 +174,8 @@ typedef struct fpt_scan_desc {
  *   AUTO    MEMO when the batch has at least 8x more bases than the table has entries. */
 enum fpt_nb_mode { FPT_NB_AUTO = 0, FPT_NB_DIRECT = 1, FPT_NB_MEMO = 2 };
 
-/* table extent for FPT_NB_MEMO (defaults 256 x 256; each in [1, 4096]) */
+/* table extent for FPT_NB_MEMO (defaults 256 x 256; each in [1, 4096]).  fpt_fdr_dev's sampling
+ * table has the same rows and by default 2048 obs columns; this call sets its columns too. */
 int fpt_set_memo_dims(fpt_ctx *ctx, int memo_exp, int memo_obs);
 
 /* Enqueue the fused scan on the context's stream (no synchronisation). */
@@ -211,6 +212,8 @@ typedef struct fpt_fdr_desc {
     double *efdr_out;                 /* DEVICE: empirical FDR track */
     const double *null_uniform;       /* optional DEVICE [sum(L) * times] uniforms replacing Philox
                                        * (row-major base x sample): deterministic tests */
+    double *null_winp_out;            /* optional DEVICE [sum(L) * times]: the null window p-values
+                                       * (detect.py:133 win_pvals_null, row-major base x sample) */
 } fpt_fdr_desc;
 
 /* Enqueue the null sampling + ranking on the context's stream (no synchronisation).

@@ -1080,10 +1080,12 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 void orc_philox_raw(uint32_t *c4, uint32_t k0, uint32_t k1) { philox4x32_10(c4, k0, k1); }
 
+/* sample 2j uses words (0,1), sample 2j+1 words (2,3) of the Philox block with counter word 2 = j */
 double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
-    uint32_t c[4] = {(uint32_t)base, (uint32_t)(base >> 32), sample, 0x66707464u};
+    uint32_t c[4] = {(uint32_t)base, (uint32_t)(base >> 32), sample >> 1, 0x66707464u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    uint64_t x = ((uint64_t)c[1] << 32) | c[0];
+    int w = (sample & 1u) ? 2 : 0;
+    uint64_t x = ((uint64_t)c[w + 1] << 32) | c[w];
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 

@@ -22,6 +22,10 @@ void hm_incbet(const double *a, const double *b, const double *x, long n, double
 void hm_chdtrc(const double *df, const double *x, long n, double *out) {
     for (long i = 0; i < n; i++) out[i] = fptm::chdtrc(df[i], x[i]);
 }
+int hm_guide_slots() { return fptm::kGuideSlots; }
+int hm_guide_slot(double u) { return fptm::guide_slot(u); }
+double hm_guide_edge(int slot) { return fptm::guide_edge(slot); }
+int hm_guide_locate(double u, double *frac) { return fptm::guide_locate(u, *frac); }
 // what: 0 cdf, 1 logpmf, 2 pmf; returns 1 if a zero division was flagged
 int hm_nb_values(int what, const double *mu9, const double *r15, const double *e, const double *o,
                  long n, double *out) {

@@ -638,6 +638,52 @@ def test_fdr_null_given_uniforms_and_ragged(fpt, orc):
         assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times)
 
 
+def test_fdr_null_draws_exact(fpt, orc):
+    """every draw of the null sampler is the smallest k with cdf(k) >= u of the device's own
+    table, also for uniforms chosen to sit ON the decision boundaries (table cdf values, their
+    neighbours, both ends of a row, slot edges of the guide); odd `times`; and the Philox draws
+    equal the oracle's."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.scan import FootprintScanner
+    from footprint_tools_amd.stats import windowing
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,))
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+    rs = np.random.RandomState(12)
+    L, times = 333, 9
+    exp = rs.choice([0, 1, 2, 3, 5, 8, 13, 19, 19, 19, 30, 44, 60, 90, 150, 255], L).astype(np.float64)
+    ks = np.arange(256, dtype=np.float64)
+    u = rs.uniform(0, 1, (L, times))
+    pn = np.empty((L, times))
+    rows = {}
+    for t in range(L):
+        if exp[t] not in rows:
+            rows[exp[t]] = dm.p_values(np.full(256, exp[t]), ks)  # the bits the device table holds
+        cdf = rows[exp[t]]
+        c = cdf[rs.randint(0, 256, times)]
+        pick = rs.randint(0, 9, times)
+        e2 = 2.0 ** -rs.randint(1, 21, times)
+        cand = np.stack([c, np.nextafter(c, 1.0), np.nextafter(c, 0.0), e2, 1.0 - e2, np.nextafter(e2, 0.0),
+                         np.zeros(times), np.full(times, cdf[255]), u[t]])
+        u[t] = np.minimum(np.clip(cand[pick, np.arange(times)], 0.0, 1.0 - 2.0 ** -53), cdf[255])
+        pn[t] = cdf[np.searchsorted(cdf, u[t], side="left")]
+    winp = rs.uniform(0, 1, L)
+    ef, nul = sc.fdr(exp, winp, times=times, interval_len=L, null_uniform=u, return_null=True)
+    want = np.stack([windowing.stouffers_z(np.ascontiguousarray(pn[:, s]), 3) for s in range(times)], axis=1)
+    assert rel_err(nul, want) < 1e-9
+    # Philox path: same draws as the oracle's generator (expected values beyond the table and a
+    # non-integer one included)
+    exp[::17] = 300.0
+    exp[5::29] = 2.5
+    ef, nul = sc.fdr(exp, winp, times=times, seed=77, interval_len=L, base_index0=12345, return_null=True)
+    want_ef, want_null = orc.fdr_null(lat["mu_A"], lat["r_A"], exp, winp, 3, times, seed=77, base0=12345,
+                                      return_null=True)
+    assert rel_err(nul, want_null) < 1e-9
+    assert np.max(np.abs(ef - want_ef)) <= 2.5 / (L * times)
+
+
 def test_fdr_null_vs_reference_sampler(fpt, orc):
     """statistical agreement with the reference procedure (numpy negative_binomial draws through
     dm.sample, windows, emperical_fdr): Monte-Carlo noise only."""

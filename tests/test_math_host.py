@@ -64,3 +64,42 @@ def test_nb_lattice_host(hm):
             assert rel_err(out, g["%s_%s" % (name, key)]) < TOL, (key, name)
     out = np.empty(3)
     assert hm.hm_nb_values(0, g["mu_D"], g["r_D"], np.array([1., 2.5, 3.]), np.ones(3), 3, out) == 1
+
+
+def test_guide_index_of_null_sampler(hm, orc):
+    """guide_slot is monotone, guide_edge(slot) never exceeds a u of that slot, and a walk that
+    starts at the guide entry is short for every expected value of the NB lattice."""
+    hm.hm_guide_slot.argtypes = [C.c_double]
+    hm.hm_guide_edge.argtypes = [C.c_int]
+    hm.hm_guide_edge.restype = C.c_double
+    n = hm.hm_guide_slots()
+    rs = np.random.RandomState(4)
+    u = np.concatenate([rs.random_sample(20000), 2.0 ** -rs.uniform(1, 40, 5000),
+                        1.0 - 2.0 ** -rs.uniform(1, 40, 5000), [0.0, 0.5, 1.0 - 2.0 ** -53, 2.0 ** -53]])
+    u.sort()
+    slot = np.array([hm.hm_guide_slot(float(x)) for x in u])
+    assert slot.min() == 0 and slot.max() == n - 1
+    assert np.all(np.diff(slot) >= 0)
+    edge = np.array([hm.hm_guide_edge(int(s)) for s in range(n)])
+    assert np.all(np.diff(edge) >= 0) and edge[0] == 0.0
+    assert np.all(edge[slot] <= u)
+    hm.hm_guide_locate.argtypes = [C.c_double, C.POINTER(C.c_double)]
+    fr = C.c_double()
+    loc = np.array([(hm.hm_guide_locate(float(x), C.byref(fr)), fr.value) for x in u])
+    assert np.array_equal(loc[:, 0], slot) and loc[:, 1].min() >= 0.0 and loc[:, 1].max() <= 1.0
+    same = np.diff(slot) == 0
+    assert np.all(np.diff(loc[:, 1])[same] >= 0)  # position inside a slot grows with u
+    # out-of-range / NaN draws (caller-supplied uniforms) still index inside the table
+    for bad in (-1.0, 1.0, 7.0, float("nan")):
+        assert 0 <= hm.hm_guide_slot(bad) < n
+    # walk length from the guide entry: number of k with edge <= cdf(k) < u
+    lat = golden("nb_lattice.npz")
+    ks = np.arange(256, dtype=np.float64)
+    worst = 0
+    for ex in (0.0, 1.0, 5.0, 19.0, 60.0):
+        cdf = orc.nb_values("cdf", lat["mu_A"], lat["r_A"], np.full(256, ex), ks)
+        start = np.searchsorted(cdf, edge[slot], side="left")
+        stop = np.searchsorted(cdf, u, side="left")
+        inside = stop < 256
+        worst = max(worst, int((stop - start)[inside & (u < 1 - 2.0 ** -20) & (u > 2.0 ** -20)].max()))
+    assert worst <= 4
