@@ -211,6 +211,29 @@ __device__ __forceinline__ int wave_scan_i32_op(int x, int ident, Op op) {
     return x;
 }
 
+// Extrema scans of NON-NEGATIVE int32 values: an unsigned max whose identity is 0 folds the DPP
+// move into the v_max_u32 itself (zero fill for lanes without a source), one instruction per
+// step instead of three; the minimum is the same scan on kNonnegTop - x.
+constexpr int kNonnegTop = 0x3fffffff;
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ unsigned dpp_u32_zero(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, BANK_MASK, true);
+}
+__device__ __forceinline__ unsigned wave_scan_umax(unsigned x) {
+#define FPT_UMAX_STEP(C, R) { const unsigned y_ = dpp_u32_zero<C, R, 0xf>(x); x = y_ > x ? y_ : x; }
+    FPT_UMAX_STEP(0x111, 0xf) FPT_UMAX_STEP(0x112, 0xf) FPT_UMAX_STEP(0x114, 0xf)
+    FPT_UMAX_STEP(0x118, 0xf) FPT_UMAX_STEP(0x142, 0xa) FPT_UMAX_STEP(0x143, 0xc)
+#undef FPT_UMAX_STEP
+    return x;
+}
+// x in [0, kNonnegTop], or `absent` for positions beyond the data (identity of the scan)
+__device__ __forceinline__ int scan_max_nonneg(int x, bool present) {
+    return (int)wave_scan_umax(present ? (unsigned)x : 0u);
+}
+__device__ __forceinline__ int scan_min_nonneg(int x, bool present) {
+    return kNonnegTop - (int)wave_scan_umax(present ? (unsigned)(kNonnegTop - x) : 0u);
+}
+
 // typed front-ends: the smoothing phase runs its scans either on doubles or, when every window
 // sum of the tile is a small integer (cut counts are), on int32, where a DPP scan step is one
 // v_add/v_min/v_max with a DPP operand instead of 5-7 instructions for a 64-bit value
@@ -270,6 +293,39 @@ __device__ __forceinline__ T tile_range_max(const T *p, const T *s, int lo, int 
     T m = scan_lim<T>::pick_max(s[lo], p[hi]);
     for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = scan_lim<T>::pick_max(m, p[(q << 6) + 63]);
     return m;
+}
+
+// Branch-free forms for windows that span at most three tiles (hi - lo <= 128) and start in a
+// different tile than they end in or not: every operand is read (from a clamped, always valid
+// index) and selected, so a wavefront whose lanes straddle different tile counts does not
+// serialise the cases.  Same association order as the loops above.
+template <typename T>
+__device__ __forceinline__ T tile_range_sum3(const T *ps, int lo, int hi) {
+    const int qlo = lo >> 6, nq = (hi >> 6) - qlo;
+    const int last = hi | 63;  // end of the tile hi is in: inside the padded array
+    const int i1 = (qlo << 6) + 63, i2 = i1 + 64;
+    const T s_hi = ps[hi];
+    const T below = ps[(lo & 63) ? lo - 1 : lo];
+    const T e1 = ps[i1 < last ? i1 : last], e2 = ps[i2 < last ? i2 : last];
+    const T sub = (lo & 63) ? below : (T)0;
+    const T s = nq == 2 ? s_hi + e2 : s_hi;
+    return nq == 0 ? s_hi - sub : (e1 - sub) + s;
+}
+
+template <typename T>
+__device__ __forceinline__ T tile_range_min3(const T *p, const T *s, int lo, int hi) {
+    const int qlo = lo >> 6, nq = (hi >> 6) - qlo;  // 1 or 2
+    const T m = scan_lim<T>::pick_min(s[lo], p[hi]);
+    const T mid = p[(qlo << 6) + 127 < (hi | 63) ? (qlo << 6) + 127 : (hi | 63)];
+    return nq == 2 ? scan_lim<T>::pick_min(m, mid) : m;
+}
+
+template <typename T>
+__device__ __forceinline__ T tile_range_max3(const T *p, const T *s, int lo, int hi) {
+    const int qlo = lo >> 6, nq = (hi >> 6) - qlo;
+    const T m = scan_lim<T>::pick_max(s[lo], p[hi]);
+    const T mid = p[(qlo << 6) + 127 < (hi | 63) ? (qlo << 6) + 127 : (hi | 63)];
+    return nq == 2 ? scan_lim<T>::pick_max(m, mid) : m;
 }
 
 }  // namespace fptd

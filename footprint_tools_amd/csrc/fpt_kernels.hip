@@ -456,9 +456,10 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
     const int w = 2 * shw + 1;
     const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
     const int ni = (ncr + NT - 1) / NT;
+    const bool le3 = shw <= 64;  // windows of at most 129 positions span at most three tiles
     // stage 1 buffers (in cP / cM): prefix sums and change counts of both strands
     int *psP = reinterpret_cast<int *>(cP), *psM = psP + nc_max;
-    int *chP = reinterpret_cast<int *>(cM), *chM = chP + nc_max;
+    int *chB = reinterpret_cast<int *>(cM);  // change counts of both strands, 16 bits each
     double winS[2][MAXI];
     int winC[2][MAXI];
     double eOut[2][MAXI];
@@ -478,8 +479,7 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
             }
             psP[v] = scan_add(v0);
             psM[v] = scan_add(v1);
-            chP[v] = scan_add(c0);
-            chM[v] = scan_add(c1);
+            chB[v] = scan_add(c0 | (c1 << 16));
         }
     }
     __syncthreads();  // (1)
@@ -497,10 +497,11 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
                 winC[0][i] = winC[1][i] = 0;
                 if (i < ni && v >= pad && v < nc - pad) {
                     const int lo = v - shw, hi = v + shw;
-                    winS[0][i] = (double)tile_range_sum(psP, lo, hi);
-                    winS[1][i] = (double)tile_range_sum(psM, lo, hi);
-                    winC[0][i] = tile_range_sum(chP, lo, hi - 1);
-                    winC[1][i] = tile_range_sum(chM, lo, hi - 1);
+                    winS[0][i] = (double)(le3 ? tile_range_sum3(psP, lo, hi) : tile_range_sum(psP, lo, hi));
+                    winS[1][i] = (double)(le3 ? tile_range_sum3(psM, lo, hi) : tile_range_sum(psM, lo, hi));
+                    const int wc = le3 ? tile_range_sum3(chB, lo, hi - 1) : tile_range_sum(chB, lo, hi - 1);
+                    winC[0][i] = wc & 0xffff;
+                    winC[1][i] = wc >> 16;
                 }
             }
         } else {
@@ -516,8 +517,8 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
                     const int lo = v - shw, hi = v + shw;
                     double t;
                     const int nchg = winC[0][i];
-                    if (nchg > 4) t = (winS[0][i] - (double)tile_range_min(qmn, rmn, lo, hi)) -
-                                      (double)tile_range_max(qmx, rmx, lo, hi);
+                    if (nchg > 4) t = (winS[0][i] - (double)(le3 ? tile_range_min3(qmn, rmn, lo, hi) : tile_range_min(qmn, rmn, lo, hi))) -
+                                      (double)(le3 ? tile_range_max3(qmx, rmx, lo, hi) : tile_range_max(qmx, rmx, lo, hi));
                     else if (nchg == 0) t = (double)(w - 1) * wP[lo];
                     else t = trimmed_sum_k1(wP + lo, w);
                     const double wsm = skip_trim ? wP[v] : div_invariant(t, w_div, w_rdiv);
@@ -535,10 +536,10 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
                 const bool okf = v < nc, okr = vr < nc;
                 const int xf = okf ? (int)ws[v] : 0;
                 const int xr = okr ? (int)ws[vr] : 0;
-                pmn[v] = scan_min(okf ? xf : 0x7fffffff);
-                pmx[v] = scan_max(okf ? xf : (int)0x80000000);
-                smn[vr] = scan_min(okr ? xr : 0x7fffffff);
-                smx[vr] = scan_max(okr ? xr : (int)0x80000000);
+                pmn[v] = scan_min_nonneg(xf, okf);
+                pmx[v] = scan_max_nonneg(xf, okf);
+                smn[vr] = scan_min_nonneg(xr, okr);
+                smx[vr] = scan_max_nonneg(xr, okr);
             }
         }
         __syncthreads();  // (2), (3)
@@ -556,8 +557,8 @@ __device__ __forceinline__ void smooth_expected_int(const double *wP, const doub
                 const int lo = v - shw, hi = v + shw;
                 double t;
                 const int nchg = winC[1][i];
-                if (nchg > 4) t = (winS[1][i] - (double)tile_range_min(qmn, rmn, lo, hi)) -
-                                  (double)tile_range_max(qmx, rmx, lo, hi);
+                if (nchg > 4) t = (winS[1][i] - (double)(le3 ? tile_range_min3(qmn, rmn, lo, hi) : tile_range_min(qmn, rmn, lo, hi))) -
+                                  (double)(le3 ? tile_range_max3(qmx, rmx, lo, hi) : tile_range_max(qmx, rmx, lo, hi));
                 else if (nchg == 0) t = (double)(w - 1) * wM[lo];
                 else t = trimmed_sum_k1(wM + lo, w);
                 const double wsm = skip_trim ? wM[v] : div_invariant(t, w_div, w_rdiv);
@@ -673,7 +674,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         wM[v] = sm;
         // small-integer test for the int32 smoothing scans: integral and small enough that a
         // window of w values (and a 64-position tile prefix) stays below 2^30
-        small_int &= (int)(fabs(sp) <= int_lim) & (int)(fabs(sm) <= int_lim) &
+        small_int &= (int)(sp >= 0.0) & (int)(sm >= 0.0) & (int)(sp <= int_lim) & (int)(sm <= int_lim) &
                      (int)((double)(int)sp == sp) & (int)((double)(int)sm == sm);
     }
     const bool all_small_int = __syncthreads_and(small_int) != 0;
@@ -824,8 +825,8 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
             double res = 1.0;  // edges are 1.0 (windowing.pyx:51)
             if (t >= hs && t < L - hs) {
                 const int lo = t - ta - hs, hi = t - ta + hs;
-                const double sv = tile_range_sum(zb, lo, hi);
-                const int sc = tile_range_sum(nf, lo, hi);
+                const double sv = hs <= 64 ? tile_range_sum3(zb, lo, hi) : tile_range_sum(zb, lo, hi);
+                const int sc = hs <= 64 ? tile_range_sum3(nf, lo, hi) : tile_range_sum(nf, lo, hi);
                 res = (sc > 0) ? NAN : (ABL(4) ? sv : fptm::ndtr(-(sv * rk)));
             }
             dst[t] = res;
@@ -1130,9 +1131,10 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
         for (int t = tid; t < L; t += NT) {
             double x0 = 1.0, x1 = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
             if (t >= hs && t < L - hs) {
-                const double s0 = tile_range_sum(zb, t - hs, t + hs);
-                const double s1 = tile_range_sum(zb1, t - hs, t + hs);
-                const int sc = tile_range_sum(nf, t - hs, t + hs);
+                const bool le3 = hs <= 64;
+                const double s0 = le3 ? tile_range_sum3(zb, t - hs, t + hs) : tile_range_sum(zb, t - hs, t + hs);
+                const double s1 = le3 ? tile_range_sum3(zb1, t - hs, t + hs) : tile_range_sum(zb1, t - hs, t + hs);
+                const int sc = le3 ? tile_range_sum3(nf, t - hs, t + hs) : tile_range_sum(nf, t - hs, t + hs);
                 x0 = (sc & 0xffff) ? NAN : (ABL(2048) ? 0.5 * s0 : fptm::ndtr(-(s0 * a.inv_sqrt_k)));
                 x1 = (sc >> 16) ? NAN : (ABL(2048) ? 0.5 * s1 : fptm::ndtr(-(s1 * a.inv_sqrt_k)));
             }

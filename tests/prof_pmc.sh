@@ -13,13 +13,17 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
   rocprofv3 --pmc $grp --output-format csv -d $OUT/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1
 done
 python3 - <<PY
-import csv, glob, collections
-agg = collections.defaultdict(list)
+import csv, glob, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "scan_fused" in row["Kernel_Name"]:
-            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k in sorted(agg):
-    v = agg[k]
-    print("%-24s n=%d mean=%.4g min=%.4g" % (k, len(v), sum(v)/len(v), min(v)))
+        kn = row["Kernel_Name"]
+        if "scan_fused" in kn or "fdr_null" in kn:
+            m = re.search(r"<(.*?)>", kn)
+            agg[kn.split("<")[0].split("(")[0] + "<" + (m.group(1) if m else "") + ">"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for kn in sorted(agg):
+    print(kn)
+    for k in sorted(agg[kn]):
+        v = agg[kn][k]
+        print("   %-24s n=%d mean=%.4g" % (k, len(v), sum(v)/len(v)))
 PY
