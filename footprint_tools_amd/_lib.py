@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("FPT_LIB_PATH") or os.path.join(HERE, "libfpt_hip.so")
 FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
 NB_CDF, NB_LOGPMF, NB_PMF = range(3)
-NB_AUTO, NB_DIRECT, NB_MEMO = range(3)
+NB_AUTO, NB_DIRECT, NB_MEMO, NB_NONE = range(4)
 FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8)
 MAX_SCALES = 8
 MAX_DM = 64

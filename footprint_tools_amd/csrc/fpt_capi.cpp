@@ -385,7 +385,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     const int n_dm = d->dm_ids ? d->n_dm : 1;
     if (n_dm < 1 || d->dm_id < 0 || d->dm_id + n_dm > FPT_MAX_DISPERSION_MODELS)
         return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range", d->dm_id, d->dm_id + n_dm);
-    for (int i = 0; i < n_dm; ++i)
+    for (int i = 0; i < n_dm && d->nb_mode != FPT_NB_NONE; ++i)
         if (!c->have_model[d->dm_id + i])
             return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
     if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
@@ -518,7 +518,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     }
 
     const bool rec = c->tev_used + 4 <= (int)c->tev.size();
-    if (d->nb_mode < 0 || d->nb_mode > 2) return fail(FPT_ERR_INVALID, "bad nb_mode %d", d->nb_mode);
+    if (d->nb_mode < 0 || d->nb_mode > 3) return fail(FPT_ERR_INVALID, "bad nb_mode %d", d->nb_mode);
+    if (d->nb_mode == FPT_NB_NONE && d->n_scales != 0)
+        return fail(FPT_ERR_INVALID, "FPT_NB_NONE computes no p-values: n_scales must be 0");
+    sl.counts_only = d->nb_mode == FPT_NB_NONE ? 1 : 0;
     const int64_t memo_n = (int64_t)c->memo_exp * c->memo_obs;
     const bool use_memo = d->nb_mode == FPT_NB_MEMO ||
                           (d->nb_mode == FPT_NB_AUTO && sl.total_bases >= 8 * memo_n);

@@ -267,6 +267,7 @@ struct scan_args {
     const double2 *memo;         // (p, z) per (exp, obs) pair, or nullptr = direct evaluation
     int32_t memo_exp, memo_obs;
     int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
+    int32_t counts_only;         // FPT_NB_NONE: stop after the expected counts
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
     const int32_t *dm_ids;       // per interval: dispersion-model slot relative to `model` (or nullptr)
@@ -718,6 +719,14 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     double ex = 0.0, pv = 0.0, z = 0.0;
     bool zd = false;
     if (tid < nt) ex = eP[pad + 1 + tid] + eM[pad + tid];
+    if (!MO && a.counts_only) {  // expected / observed tracks only (learn_dm)
+        const int t = ta + tid;
+        if (tid < nt && t >= t0 && t < t0 + tl) {
+            if (a.exp_out) a.exp_out[out_off + t] = ex;
+            if (a.obs_out) a.obs_out[out_off + t] = ob;
+        }
+        return;
+    }
     const int32_t k = fptm::c_int(ob);
     if (!MO && !memo && !ABL(2)) {
         // Direct mode: every base evaluates incbet itself.  Lanes are regrouped first so that a
@@ -1406,6 +1415,7 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo_exp = sl.memo_exp;
     a.memo_obs = sl.memo_obs;
     a.ablate = sl.ablate;
+    a.counts_only = sl.counts_only;
     a.redo = sl.redo;
     a.dm_ids = sl.dm_ids;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;

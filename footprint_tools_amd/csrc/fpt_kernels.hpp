@@ -31,6 +31,7 @@ struct scan_launch {
     int32_t *status_out;
     const void *memo;  // double2[memo_exp * memo_obs] or nullptr
     int32_t memo_exp, memo_obs;
+    int32_t counts_only;
     int32_t ablate;
     int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
     const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr

@@ -152,7 +152,63 @@ class dispersion_model(object):
 
 
 def learn_dispersion_model(h, cutoff=250, trim=(2.5, 97.5)):
-    raise NotImplementedError("model fitting is outside the scan path (SURVEY.md 2, row 5)")
+    """Dispersion model from the (expected, observed) histogram `h` (rows = expected count),
+    following modeling/dispersion.pyx:357-469: a maximum-likelihood NB fit of every row with at
+    least `cutoff` observations (after trimming `trim` percent off both ends), then continuous
+    piecewise-linear fits of mu(x) (3 segments, forced through the first fitted row) and of
+    1/r(x) (5 segments whose breakpoints are optimised, forced through row 1).
+
+    The histogram comes from `FootprintScanner.histogram` (device) or the reference's loop
+    (cli/learn_dm.py:276-287).  The piecewise fits use `modeling.piecewise` in place of pwlf."""
+    from scipy import optimize
+
+    from ..stats.distributions import nbinom
+    from .piecewise import PiecewiseLinFit
+    h = np.asarray(h)
+    size = int(h.shape[0])
+    p, r = np.zeros(size), np.zeros(size)
+    values = np.arange(h.shape[1], dtype=np.float64)
+    for i in range(size):
+        counts = h[i, :].astype(np.int64)
+        x = np.repeat(values, counts)  # the row unpacked, ascending
+        if len(x) > 1e5:  # downsample to keep the root finding tractable (global numpy RNG)
+            x = np.sort(np.random.choice(x, size=int(1e5)))
+        if len(x) < cutoff:
+            p[i] = r[i] = np.nan  # too few points: left out of the curve fits
+            continue
+        lower = int(np.floor(x.shape[0] * (trim[0] / 100.0)))
+        upper = int(np.ceil(x.shape[0] * (trim[1] / 100.0)))
+        core = x[lower:upper]
+        m, v = np.mean(core), np.var(core)
+        r0 = (m * m) / (v - m) if v != m else np.inf
+        if not (r0 > 0.0) or not np.isfinite(r0):
+            r0 = 10.0
+        p[i], r[i] = nbinom.fit(core, p=r0 / (r0 + m), r=r0)
+    with np.errstate(all="ignore"):
+        mus = p * r / (1 - p)
+    r[r > 200] = 200.0  # the reference's guard against runaway fits
+
+    x = np.arange(size)
+    ok = np.isfinite(mus)
+    if ok.sum() < 2:
+        raise ValueError("not enough rows with >= %d observations to fit a dispersion model" % cutoff)
+    first_x, last_x = np.min(x[ok]), np.max(x[ok]) * 0.75
+
+    fit_mu = PiecewiseLinFit(x[ok], mus[ok])
+    fit_mu.fit_with_breaks_force_points(np.linspace(first_x, last_x, 4), [x[ok][0]], [mus[ok][0]])
+
+    fit_r = PiecewiseLinFit(x[ok], 1.0 / r[ok])
+    best = optimize.minimize(fit_r.fit_with_breaks_opt, [3.0, 7.0, 15.0, 25.0])
+    breaks = np.zeros(6)
+    breaks[0], breaks[-1] = first_x, last_x
+    breaks[1:-1] = best.x
+    fit_r.fit_with_breaks_force_points(breaks, [1], [1.0 / r[1]])
+
+    model = dispersion_model()
+    model.h, model.p, model.r = h, p, r
+    model.mu_params = list(fit_mu.fit_breaks[1:]) + list(fit_mu.intercepts) + list(fit_mu.slopes)
+    model.r_params = list(fit_r.fit_breaks[1:]) + list(fit_r.intercepts) + list(fit_r.slopes)
+    return model
 
 
 def base64encode(x):

@@ -85,15 +85,21 @@ class FootprintScanner(object):
         self.dflt = float(default_propensity)
         # one model, or a list of models selected per interval through `dm_ids`
         self.models = list(dispersion) if isinstance(dispersion, (list, tuple)) else [dispersion]
-        self.mu = _lib.f64(self.models[0].mu_params).ravel()
-        self.r = _lib.f64(self.models[0].r_params).ravel()
+        if dispersion is None:  # expected / observed counts only (learn_dm has no model yet)
+            if nb_mode != "none" or len(scales):
+                raise ValueError('a scanner without a dispersion model needs nb_mode="none" and scales=()')
+            self.mu = self.r = None
+        else:
+            self.mu = _lib.f64(self.models[0].mu_params).ravel()
+            self.r = _lib.f64(self.models[0].r_params).ravel()
         self.hw, self.shw, self.clip = int(half_win_width), int(smoothing_half_win_width), float(smoothing_clip)
         self.scales = tuple(int(s) for s in scales)
         if len(self.scales) > _lib.MAX_SCALES:
             raise ValueError("at most %d scales" % _lib.MAX_SCALES)
         self.pad = self.hw + self.shw
         # how the per-base NB p-value is evaluated (fpt_nb_mode of include/fpt.h)
-        self.nb_mode = {"auto": _lib.NB_AUTO, "direct": _lib.NB_DIRECT, "memo": _lib.NB_MEMO}[nb_mode]
+        self.nb_mode = {"auto": _lib.NB_AUTO, "direct": _lib.NB_DIRECT, "memo": _lib.NB_MEMO,
+                        "none": _lib.NB_NONE}[nb_mode]
 
     # ---- geometry ------------------------------------------------------------------------
     def padded_len(self, L):
@@ -135,6 +141,8 @@ class FootprintScanner(object):
 
     def _model_slot(self):
         ctx = self.ctx
+        if self.mu is None:
+            return 0
         if len(self.models) == 1:
             return ctx.dispersion_slot(self.mu, self.r)
         return ctx.dispersion_slots([(m.mu_params, m.r_params) for m in self.models])

@@ -37,3 +37,35 @@ def mean(p, r):
 
 def var(p, r):
     return (p * r) / ((1 - p) * (1 - p))
+
+
+# ---- maximum-likelihood fit (host side, like the reference: nbinom.pyx:25-80) ----------------
+
+def mle(par, data, sm):
+    """Score equations of the NB likelihood in (p, r) for `data` with mean `sm`; both are zero at
+    the maximum-likelihood estimate."""
+    import scipy.special
+    p, r = par[0], par[1]
+    data = np.asarray(data, dtype=np.float64)
+    n = data.shape[0]
+    dig = scipy.special.psi(data + r)
+    return np.array([sm / (r + sm) - p,
+                     np.sum(dig) - n * scipy.special.psi(r) + n * np.log(r / (r + sm))])
+
+
+def fit(data, p=None, r=None):
+    """Maximum-likelihood (p, r) of a negative binomial for the 1-D array `data`; p, r are the
+    starting point of the root finder (moment estimates when not given)."""
+    import warnings
+
+    import scipy.optimize
+    data = np.asarray(data, dtype=np.float64)
+    if p is None or r is None:
+        m1, m2 = np.average(data), np.var(data)
+        r = (m1 * m1) / (m2 - m1)
+        p = (m2 - m1) / m2
+    sm = np.sum(data) / len(data)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        root = scipy.optimize.fsolve(mle, np.array([p, r]), args=(data, sm))
+    return (root[0], root[1])

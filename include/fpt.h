@@ -145,7 +145,7 @@ typedef struct fpt_scan_desc {
     const int32_t *dm_ids;
     int32_t n_dm;
     int32_t nb_mode;                  /* how p = nbinom.cdf(obs; exp) is evaluated per base:
-                                       * FPT_NB_AUTO, FPT_NB_DIRECT or FPT_NB_MEMO (see below) */
+                                       * FPT_NB_AUTO, FPT_NB_DIRECT, FPT_NB_MEMO or FPT_NB_NONE (below) */
     /* inputs (DEVICE).  With pad = hw + shw, interval i of length L_i owns
      *   counts_*[ off_i + i*(2*pad+1) .. +L_i+2*pad+1 )   padded cut counts, genomic order
      *   seq     [ off_i + i*(2*pad+7) .. +L_i+2*pad+7 )   ASCII bases, 3 extra on each side
@@ -171,8 +171,11 @@ typedef struct fpt_scan_desc {
  *           same device incbet/ndtri (one small launch on the same stream, so it is part of the
  *           timed work), the scan kernel looks pairs up and falls back to DIRECT evaluation for
  *           pairs outside the table or non-integer / non-finite exp.
- *   AUTO    MEMO when the batch has at least 8x more bases than the table has entries. */
-enum fpt_nb_mode { FPT_NB_AUTO = 0, FPT_NB_DIRECT = 1, FPT_NB_MEMO = 2 };
+ *   AUTO    MEMO when the batch has at least 8x more bases than the table has entries.
+ *   NONE    no p-values at all: only exp_out / obs_out are written (what `ftd learn_dm` needs
+ *           before a dispersion model exists, cli/learn_dm.py:102-107); n_scales must be 0 and
+ *           no dispersion slot has to be set. */
+enum fpt_nb_mode { FPT_NB_AUTO = 0, FPT_NB_DIRECT = 1, FPT_NB_MEMO = 2, FPT_NB_NONE = 3 };
 
 /* table extent for FPT_NB_MEMO (defaults 256 x 256; each in [1, 4096]).  fpt_fdr_dev's sampling
  * table has the same rows and by default 2048 obs columns; this call sets its columns too. */

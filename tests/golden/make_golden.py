@@ -430,8 +430,36 @@ def g7():
          prior=prior, delta=delta, ll_on=ll_on, ll_off=ll_off, post=post)
 
 
+# ---------------------------------------------------------------- G8: NB maximum-likelihood fit (learn_dm)
+def g8():
+    """nbinom.mle / nbinom.fit (stats/distributions/nbinom.pyx:25-80), the per-row fit of
+    learn_dispersion_model (dispersion.pyx:391-430).  The piecewise-linear half of that function
+    needs pwlf, which is not installed here, so it has no golden vector."""
+    rs = np.random.RandomState(88)
+    out = {}
+    n_case = 0
+    for (mu, r, n) in [(3.0, 2.0, 400), (12.0, 5.0, 3000), (30.0, 1.2, 5000), (0.7, 8.0, 800), (55.0, 20.0, 2500)]:
+        data = np.sort(rs.negative_binomial(r, r / (r + mu), n).astype(np.float64))
+        lower = int(np.floor(data.shape[0] * (2.5 / 100.0)))
+        upper = int(np.ceil(data.shape[0] * (97.5 / 100.0)))
+        x = data[lower:upper]
+        m, v = np.mean(x), np.var(x)
+        est_r = (m * m) / (v - m)
+        if est_r <= 0.0:
+            est_r = 10.0
+        est_p = est_r / (est_r + m)
+        out["data%d" % n_case] = x
+        out["guess%d" % n_case] = np.array([est_p, est_r])
+        out["fit%d" % n_case] = np.array(nbinom.fit(x, p=est_p, r=est_r))
+        out["fit_noguess%d" % n_case] = np.array(nbinom.fit(x))
+        out["mle%d" % n_case] = np.asarray(nbinom.mle(np.array([est_p, est_r]), x, np.sum(x) / len(x)))
+        n_case += 1
+    out["n_case"] = np.array(n_case)
+    save("nbfit.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -445,3 +473,5 @@ if __name__ == "__main__":
         g6()
     if "7" in which:
         g7()
+    if "8" in which:
+        g8()

@@ -808,3 +808,61 @@ def test_argument_errors(fpt, ctx):
         windowing.stouffers_z(np.ones(10), -1)
     assert np.array_equal(windowing.sum(np.ones(4), 3), np.ones(4))
     assert windowing.stouffers_z(np.zeros(0), 3).shape == (0,)
+
+
+def test_learn_dm_driver(fpt, orc):
+    """the batched stand-in of cli/learn_dm.py: expected / observed counts with the predictor's
+    class defaults (no smoothing) equal the oracle's, the device histogram equals the reference's
+    Python loop, and the model learned from it is usable."""
+    import itertools
+    from footprint_tools_amd import learn
+    from footprint_tools_amd.modeling import bias
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    bm = bias.bias_model()
+    for j, kk in enumerate(itertools.product("ACGT", repeat=6)):
+        bm["".join(kk)] = float(table[j])
+    hw, pad = 5, 5
+    genome_len = 40000
+    rs = np.random.RandomState(4)
+    gp, gm = rs.poisson(1.5, genome_len).astype(np.float64), rs.poisson(1.5, genome_len).astype(np.float64)
+    gseq = orc.synth_bases(32, 0, genome_len).tobytes().decode()
+
+    class Interval(object):
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end = c, s, e
+
+        def widen(self, w):
+            return Interval(self.chrom, self.start - w, self.end + w)
+
+    class Reads(object):
+        def __getitem__(self, iv):
+            return {"+": gp[iv.start:iv.end], "-": gm[iv.start:iv.end]}
+
+    class Fasta(object):
+        def fetch(self, chrom, s, e):
+            return gseq[s:e]
+
+    starts = np.arange(100, genome_len - 1400, 1300)
+    ivs = [Interval("chr1", int(s), int(s) + int(l)) for s, l in zip(starts, rs.randint(60, 1250, starts.size))]
+    ds = learn.expected_counts(ivs, Reads(), Fasta(), bm, half_win_width=hw, batch_size=7)
+    recs = ds.compute(range(len(ivs)))
+    want_hist = np.zeros((200, 1000), dtype=np.int64)
+    dummy_mu, dummy_r = lat["mu_A"], lat["r_A"]
+    for iv, rec in zip(ivs, recs):
+        L = iv.end - iv.start
+        lo, hi = iv.start - pad - 1, iv.end + pad
+        e, o, _, _ = orc.detect_batch(gp[lo:hi], gm[lo:hi], orc.seq_bytes(gseq[lo - 3:hi + 3]), 1, L, hw, 0,
+                                      0.01, table, dummy_mu, dummy_r, np.array([3], np.int32))
+        assert rec.shape == (L, 2)
+        assert np.array_equal(rec[:, 0], e) and np.array_equal(rec[:, 1], o)
+        for a, b in rec:  # cli/learn_dm.py:281-287
+            if 0 <= int(a) < 200 and 0 <= int(b) < 1000:
+                want_hist[int(a), int(b)] += 1
+    assert np.array_equal(ds[3], recs[3])
+    hist = ds.histogram()
+    assert np.array_equal(hist, want_hist)
+    dm = learn.learn_dm(ivs, Reads(), Fasta(), bm, half_win_width=hw, seed=1, batch_size=16, cutoff=100)
+    assert np.array_equal(dm.h, want_hist) and dm.mu_params.shape == (9,) and dm.r_params.shape == (15,)
+    assert 1.0 < dm.fit_mu(3.0) < 5.0  # Poisson(1.5) counts per strand around an expectation of 3
+    assert np.all(np.isfinite(dm.p_values(np.array([2.0, 3.0, 4.0]), np.array([0.0, 3.0, 9.0]))))

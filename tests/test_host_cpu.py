@@ -166,3 +166,83 @@ def test_output_writers_text_format():
     buf = io.StringIO()
     detect.write_output_header(["exp", "obs"], file=buf, include_name=False, extra=["a", "b"])
     assert buf.getvalue().splitlines()[1:] == ["# a", "# b", "# chrom\tstart\tend\texp\tobs"]
+
+
+# ---------------------------------------------------------------- learn_dm: NB fit, piecewise fit, model
+def test_nbinom_fit_golden():
+    """nbinom.mle / nbinom.fit against the reference's (stats/distributions/nbinom.pyx:25-80)."""
+    from footprint_tools_amd.stats.distributions import nbinom
+    g = golden("nbfit.npz")
+    for c in range(int(g["n_case"])):
+        x, guess = g["data%d" % c], g["guess%d" % c]
+        assert np.allclose(nbinom.mle(guess, x, np.sum(x) / len(x)), g["mle%d" % c], rtol=1e-12, atol=1e-9)
+        assert np.allclose(nbinom.fit(x, p=guess[0], r=guess[1]), g["fit%d" % c], rtol=1e-9)
+        assert np.allclose(nbinom.fit(x), g["fit_noguess%d" % c], rtol=1e-9)
+
+
+def test_piecewise_fit():
+    from footprint_tools_amd.modeling.piecewise import PiecewiseLinFit
+    rs = np.random.RandomState(5)
+    breaks = np.array([0.0, 10.0, 25.0, 60.0])
+    slopes = np.array([2.0, -0.5, 0.25])
+    x = np.sort(rs.uniform(0, 60, 400))
+    x[0], x[-1] = 0.0, 60.0
+    knots = np.concatenate([[1.0], 1.0 + np.cumsum(slopes * np.diff(breaks))])
+    y = np.interp(x, breaks, knots)
+    f = PiecewiseLinFit(x, y)
+    f.fit_with_breaks(breaks)
+    assert np.allclose(f.slopes, slopes) and np.allclose(f.intercepts, knots[:-1] - slopes * breaks[:-1])
+    assert f.ssr < 1e-18 and np.allclose(f.predict(x), y)
+    assert f.fit_with_breaks_opt(breaks[1:-1]) < 1e-18 < f.fit_with_breaks_opt([12.0, 30.0])
+    # the design matrix is the hinge basis: same solution as a hand-built least squares
+    noisy = y + rs.normal(0, 0.3, x.size)
+    f = PiecewiseLinFit(x, noisy)
+    f.fit_with_breaks(breaks)
+    A = np.column_stack([np.ones_like(x), x - breaks[0], np.maximum(x - breaks[1], 0), np.maximum(x - breaks[2], 0)])
+    beta = np.linalg.lstsq(A, noisy, rcond=None)[0]
+    assert np.allclose(f.beta, beta)
+    # forced point: the curve passes through it and is the best such curve
+    f.fit_with_breaks_force_points(breaks, [5.0], [4.0])
+    assert abs(f.predict([5.0])[0] - 4.0) < 1e-9
+    base = f.ssr
+    for _ in range(20):
+        b = f.beta + rs.normal(0, 1e-3, f.beta.size)
+        b[0] += 4.0 - PiecewiseLinFit.predict(f, [5.0], beta=b, breaks=breaks)[0]  # restore the constraint
+        resid = f.assemble_regression_matrix(breaks, f.x_data).dot(b) - f.y_data
+        assert resid.dot(resid) >= base - 1e-9
+    # unsorted input is sorted; extrapolation beyond the last breakpoint continues the last segment
+    g = PiecewiseLinFit(x[::-1], y[::-1])
+    g.fit_with_breaks(np.array([0.0, 10.0, 25.0, 45.0]))
+    assert g.x_data[0] == 0.0 and g.n_segments == 3
+
+
+def test_learn_dispersion_model_recovers_truth():
+    """histogram simulated from a known mu(x), r(x) -> learn_dispersion_model -> the model
+    reproduces them (dispersion.pyx:357-469 flow with the pwlf-free fitter)."""
+    from footprint_tools_amd.modeling import dispersion
+    rs = np.random.RandomState(3)
+    rows, cols = 80, 400
+    h = np.zeros((rows, cols), dtype=np.int64)
+    mu_true = lambda e: 0.5 + 0.9 * e
+    invr_true = lambda e: 0.05 + 0.004 * e
+    for e in range(rows):
+        n = int(40000 / (1 + 0.08 * e))
+        r = 1.0 / invr_true(e)
+        k = rs.negative_binomial(r, r / (r + mu_true(e)), n)
+        np.add.at(h[e], k[k < cols], 1)
+    np.random.seed(0)
+    dm = dispersion.learn_dispersion_model(h)  # default 2.5 % trimming: biases r upwards, as in the reference
+    assert dm.mu_params.shape == (9,) and dm.r_params.shape == (15,)
+    assert np.sum(np.isfinite(dm.p)) == rows and dm.r.max() <= 200.0
+    for e in (1, 5, 20, 40):
+        assert abs(dm.fit_mu(e) - mu_true(e)) / mu_true(e) < 0.08, e
+    dm = dispersion.learn_dispersion_model(h, trim=(0, 100))  # untrimmed: the fit is consistent
+    for e in (1, 5, 20, 40):
+        assert abs(dm.fit_mu(e) - mu_true(e)) / mu_true(e) < 0.05, e
+        assert abs(1.0 / dm.fit_r(e) - invr_true(e)) / invr_true(e) < 0.12, e
+    # a histogram with too little data
+    with pytest.raises(ValueError):
+        dispersion.learn_dispersion_model(np.ones((5, 10), dtype=np.int64))
+    # round trip through the JSON writer / loader
+    txt = dispersion.write_dispersion_model(dm)
+    assert "mu_params" in txt
