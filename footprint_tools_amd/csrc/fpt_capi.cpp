@@ -628,25 +628,37 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     if (d->half_win_width < 0 || d->half_win_width > 200)
         return fail(FPT_ERR_INVALID, "half window %d out of range", d->half_win_width);
     if (!d->exp || !d->winp || !d->efdr_out) return fail(FPT_ERR_INVALID, "null track");
-    int lmax = d->interval_len;
+    // Intervals of up to kLdsMax bases keep their buffers in LDS; longer ones (up to kLongMax)
+    // run the same kernel over buffers in global memory.
+    constexpr int kLdsMax = 4096, kLongMax = 1 << 22;
+    int lmax = d->interval_len, lmax_short = 0;
+    std::vector<int32_t> shorts, longs;  // ragged batches with long intervals: who goes where
     if (d->interval_off) {
         if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
-        // longest interval: the offsets live on the device, so take them back once
+        // interval lengths: the offsets live on the device, so take them back once
         std::vector<int64_t> off((size_t)d->n_intervals + 1);
         HIP_TRY(hipMemcpyAsync(off.data(), d->interval_off, off.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         lmax = 0;
+        int64_t n_long = 0;
         for (int64_t i = 0; i < d->n_intervals; ++i) {
             int64_t L = off[i + 1] - off[i];
             if (L < 0) return fail(FPT_ERR_INVALID, "bad interval offsets");
-            if (L > lmax) lmax = (int)std::min<int64_t>(L, 1 << 30);
+            if (L > kLongMax)
+                return fail(FPT_ERR_INVALID, "interval of %lld bases: fpt_fdr_dev handles at most %d", (long long)L, kLongMax);
+            if (L > lmax) lmax = (int)L;
+            if (L > kLdsMax) ++n_long; else if (L > lmax_short) lmax_short = (int)L;
+        }
+        if (n_long) {
+            for (int64_t i = 0; i < d->n_intervals; ++i)
+                (off[i + 1] - off[i] > kLdsMax ? longs : shorts).push_back((int32_t)i);
         }
     } else if (lmax <= 0) {
         return fail(FPT_ERR_INVALID, "interval_len must be positive");
+    } else if (lmax > kLongMax) {
+        return fail(FPT_ERR_INVALID, "interval of %d bases: fpt_fdr_dev handles at most %d", lmax, kLongMax);
     }
-    if (lmax > 4096) return fail(FPT_ERR_INVALID, "interval of %d bases: fpt_fdr_dev handles at most 4096", lmax);
-    int n2 = 64;
-    while (n2 < lmax) n2 <<= 1;
+    auto pow2 = [](int n) { int p = 64; while (p < n) p <<= 1; return p; };
     const int64_t memo_n = (int64_t)c->memo_exp * c->fdr_memo_obs;
     void *d_memo;
     if (int rc = ws_get(c, 8, (size_t)memo_n * 16 * n_dm, &d_memo)) return rc;
@@ -679,9 +691,40 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
 #ifdef FPT_ABLATE
     if (const char *e = getenv("FPT_ABLATE")) fl.ablate = atoi(e);
 #endif
-    fl.n2_max = n2;
-    HIP_TRY(fptk::launch_fdr(c->stream, fl));
-    return launch_ok("k_fdr_null");
+    // long intervals: per-workgroup buffers in a global workspace of at most 1 GiB
+    auto launch_long = [&](const int32_t *list, int64_t n_list) -> int {
+        fl.n2_max = pow2(lmax);
+        fl.gws_stride = (int64_t)((fptk::fdr_lds_bytes(fl.n2_max) + 255) & ~(size_t)255);
+        const int64_t n_blocks = list ? n_list : d->n_intervals;
+        fl.gws_blocks = std::max<int64_t>(1, std::min<int64_t>(n_blocks, ((int64_t)1 << 30) / fl.gws_stride));
+        if (int rc = ws_get(c, 4, (size_t)(fl.gws_stride * fl.gws_blocks), &fl.gws)) return rc;
+        fl.iv_list = list;
+        fl.n_list = n_list;
+        HIP_TRY(fptk::launch_fdr(c->stream, fl));
+        return launch_ok("k_fdr_null (global buffers)");
+    };
+    if (longs.empty()) {
+        if (lmax > kLdsMax) return launch_long(nullptr, 0);  // uniform batch of long intervals
+        fl.n2_max = pow2(lmax);
+        HIP_TRY(fptk::launch_fdr(c->stream, fl));
+        return launch_ok("k_fdr_null");
+    }
+    // mixed ragged batch: two interval lists on the device
+    void *d_list;
+    if (int rc = ws_get(c, 5, (shorts.size() + longs.size()) * sizeof(int32_t), &d_list)) return rc;
+    int32_t *d_short = (int32_t *)d_list, *d_long = d_short + shorts.size();
+    if (!shorts.empty())
+        HIP_TRY(hipMemcpyAsync(d_short, shorts.data(), shorts.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_long, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the lists are pageable host memory
+    if (!shorts.empty()) {
+        fl.n2_max = pow2(lmax_short);
+        fl.iv_list = d_short;
+        fl.n_list = (int64_t)shorts.size();
+        HIP_TRY(fptk::launch_fdr(c->stream, fl));
+        if (int rc = launch_ok("k_fdr_null")) return rc;
+    }
+    return launch_long(d_long, (int64_t)longs.size());
 }
 
 int fpt_set_memo_dims(fpt_ctx *c, int memo_exp, int memo_obs) {

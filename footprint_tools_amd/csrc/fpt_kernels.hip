@@ -878,8 +878,12 @@ struct fdr_args {
     double *null_out;       // optional [base][times] null window p-values
     const int32_t *dm_ids;  // per interval model slot relative to `model`, or nullptr
     int32_t ablate;      // timing-only diagnostics (FPT_ABLATE builds)
-    int32_t n2_max;      // LDS capacity: power of two >= longest interval
+    int32_t n2_max;      // buffer capacity: power of two >= longest interval of the launch
     double inv_sqrt_k;
+    const int32_t *iv_list;  // interval of workgroup b is iv_list[b], or iv_first + b when null
+    int64_t iv_first;
+    char *gws;               // GWS instances: per-workgroup buffers in global memory
+    int64_t gws_stride;
 };
 
 // Guide table of the inverse-CDF sampler: guide[row][slot] = smallest k with
@@ -1007,11 +1011,14 @@ __device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *
     }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
+// GWS: the per-interval buffers live in global memory instead of LDS -- the same code for
+// intervals too long for the 160 KB of a CU (one workgroup still owns one interval, and a
+// workgroup's own global writes are visible to it after __syncthreads()).
+template <int NT, bool GWS>
+__global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
-    double *par = smem;                              // 24
+    double *par = GWS ? reinterpret_cast<double *>(a.gws + (size_t)blockIdx.x * a.gws_stride) : smem;  // 24
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
     double *zb = skey + n2;                          // n2 tile prefix sums of z, even sample
     double *zb1 = zb + n2;                           // n2 same for the odd sample of the pair
@@ -1023,7 +1030,7 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int64_t iv = blockIdx.x;
+    const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
     int64_t off;
     int L;
     if (a.interval_off) {
@@ -1209,7 +1216,8 @@ __global__ void __launch_bounds__(NT, 4) k_fdr_null(const fdr_args a) {
     }
 }
 
-template __global__ void k_fdr_null<256>(const fdr_args);
+template __global__ void k_fdr_null<256, false>(const fdr_args);
+template __global__ void k_fdr_null<256, true>(const fdr_args);
 
 // ===========================================================================
 // k_hist2d: hist[int(exp), int(obs)] += 1 (cli/learn_dm.py:276-287), pairs outside the
@@ -1465,23 +1473,29 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.ablate = fl.ablate;
     a.n2_max = fl.n2_max;
     a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
+    a.iv_list = fl.iv_list;
+    a.gws = (char *)fl.gws;
+    a.gws_stride = fl.gws_stride;
+    const int64_t n_blocks = fl.iv_list ? fl.n_list : fl.n_intervals;
+    if (fl.gws) {  // long intervals: buffers in global memory, as many workgroups at a time as fit
+        const int64_t per = fl.gws_blocks < 1 ? 1 : fl.gws_blocks;
+        for (int64_t done = 0; done < n_blocks; done += per) {
+            fdr_args b = a;
+            if (b.iv_list) b.iv_list += done; else b.iv_first = done;
+            const int64_t n = n_blocks - done < per ? n_blocks - done : per;
+            hipLaunchKernelGGL((k_fdr_null<256, true>), dim3((unsigned)n), dim3(256), 0, st, b);
+        }
+        return hipSuccess;
+    }
     size_t lds = fdr_lds_bytes(fl.n2_max);
-    hipError_t e = hipFuncSetAttribute((const void *)k_fdr_null<256>,
+    hipError_t e = hipFuncSetAttribute((const void *)k_fdr_null<256, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    for (int64_t done = 0; done < fl.n_intervals; done += 0x7fffff00) {
+    for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
         fdr_args b = a;
-        int64_t n = fl.n_intervals - done < 0x7fffff00 ? fl.n_intervals - done : 0x7fffff00;
-        if (done) {  // later chunks: shift the interval base (uniform batches only reach this)
-            b.exp += done * (int64_t)fl.interval_len;
-            b.winp += done * (int64_t)fl.interval_len;
-            b.efdr += done * (int64_t)fl.interval_len;
-            b.base_index0 += done * (int64_t)fl.interval_len;
-            if (b.null_uniform) b.null_uniform += done * (int64_t)fl.interval_len * fl.times;
-            if (b.null_out) b.null_out += done * (int64_t)fl.interval_len * fl.times;
-            if (b.dm_ids) b.dm_ids += done;
-        }
-        hipLaunchKernelGGL(k_fdr_null<256>, dim3((unsigned)n), dim3(256), lds, st, b);
+        if (b.iv_list) b.iv_list += done; else b.iv_first = done;
+        const int64_t n = n_blocks - done < 0x7fffff00 ? n_blocks - done : 0x7fffff00;
+        hipLaunchKernelGGL((k_fdr_null<256, false>), dim3((unsigned)n), dim3(256), lds, st, b);
     }
     return hipSuccess;
 }

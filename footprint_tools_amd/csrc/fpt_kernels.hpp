@@ -56,6 +56,11 @@ struct fdr_launch {
     const int32_t *dm_ids;
     int32_t ablate;
     int32_t n2_max;
+    const int32_t *iv_list;  // optional DEVICE list of the intervals to process (n_list of them)
+    int64_t n_list;
+    void *gws;               // non-null: global-memory buffers, gws_stride bytes per workgroup,
+    int64_t gws_stride;      //           room for gws_blocks workgroups at a time
+    int64_t gws_blocks;
 };
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl);

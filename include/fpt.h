@@ -220,7 +220,8 @@ typedef struct fpt_fdr_desc {
 } fpt_fdr_desc;
 
 /* Enqueue the null sampling + ranking on the context's stream (no synchronisation).
- * Intervals longer than 4096 bases are rejected (FPT_ERR_INVALID). */
+ * Intervals of up to 4096 bases are processed out of LDS; longer ones (up to 2^22 bases) by the
+ * same kernel over buffers in global memory, which is slower per base. */
 int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
 
 /* (exp, obs) histogram of `ftd learn_dm` (cli/learn_dm.py:276-287): hist[int(exp), int(obs)] += 1

@@ -866,3 +866,32 @@ def test_learn_dm_driver(fpt, orc):
     assert np.array_equal(dm.h, want_hist) and dm.mu_params.shape == (9,) and dm.r_params.shape == (15,)
     assert 1.0 < dm.fit_mu(3.0) < 5.0  # Poisson(1.5) counts per strand around an expectation of 3
     assert np.all(np.isfinite(dm.p_values(np.array([2.0, 3.0, 4.0]), np.array([0.0, 3.0, 9.0]))))
+
+
+def test_fdr_long_intervals(fpt, orc):
+    """intervals longer than the 4096 bases that fit in LDS run over buffers in global memory:
+    same null draws and the same empirical FDR as the oracle, alone and mixed with short ones."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,))
+    rs = np.random.RandomState(21)
+    times = 7
+    lens = np.array([300, 5000, 100, 9001, 4096, 4097])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp = np.round(rs.gamma(2.0, 6.0, off[-1]))
+    winp = rs.uniform(0, 1, off[-1]) ** 2
+    winp[off[1] + 17] = np.nan
+    ef, nul = sc.fdr(exp, winp, times=times, seed=5, interval_off=off, base_index0=77, return_null=True)
+    for a, b in zip(off[:-1], off[1:]):
+        want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[a:b], winp[a:b], 3, times, seed=5, base0=77 + a,
+                                return_null=True)
+        assert rel_err(nul[a:b], wn) < 1e-9, (a, b)
+        assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times), (a, b)
+    # uniform batch of long intervals
+    L, n_iv = 6000, 3
+    ef = sc.fdr(exp[:L * n_iv], winp[:L * n_iv], times=times, seed=9, interval_len=L)
+    for i in range(n_iv):
+        sl = slice(i * L, (i + 1) * L)
+        want = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[sl], winp[sl], 3, times, seed=9, base0=i * L)
+        assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (L * times), i
