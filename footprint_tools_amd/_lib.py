@@ -22,7 +22,7 @@ EXPORTS = [
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
-    "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev",
+    "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
 
@@ -74,6 +74,19 @@ class FdrDesc(C.Structure):
     ]
 
 
+class SegmentDesc(C.Structure):
+    """struct fpt_segment_desc of include/fpt.h"""
+    _fields_ = [
+        ("n_intervals", C.c_int64),
+        ("interval_len", C.c_int32),
+        ("interval_off", C.c_void_p),
+        ("track", C.c_void_p),
+        ("threshold", C.c_double),
+        ("w", C.c_int32),
+        ("decreasing", C.c_int32),
+    ]
+
+
 _lib = None
 _lock = threading.RLock()
 
@@ -111,6 +124,8 @@ def load():
         L.fpt_scan_dev.argtypes = [vp, C.POINTER(ScanDesc)]
         L.fpt_fdr_dev.argtypes = [vp, C.POINTER(FdrDesc)]
         L.fpt_hist2d_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+        L.fpt_segment_count_dev.argtypes = [vp, C.POINTER(SegmentDesc), C.POINTER(C.c_int64)]
+        L.fpt_segment_fill_dev.argtypes = [vp, C.POINTER(SegmentDesc), i64, vp, vp, vp, vp]
         L.fpt_synth_dev.argtypes = [vp, C.c_uint64, i64, i64, vp, vp, i64, i64, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
         L.fpt_dev_alloc.argtypes = [vp, i64, C.POINTER(vp)]

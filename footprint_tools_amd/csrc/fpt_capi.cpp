@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-constexpr int kSlots = 10;
+constexpr int kSlots = 12;
 constexpr int kModelDoubles = 24;
 
 }  // namespace
@@ -63,6 +63,9 @@ struct fpt_ctx {
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
     // the 1e-4 tail of the widest rows is hit in every batch.
     int fdr_memo_obs = 2048;
+    // fpt_segment_count_dev -> fpt_segment_fill_dev hand-over
+    int64_t seg_n_intervals = -1, seg_total = 0;
+    const double *seg_track = nullptr;
     // tile-table cache of the last ragged batch (reused while the offsets and geometry match)
     std::vector<int64_t> plan_off;
     int plan_H = -1;
@@ -754,6 +757,72 @@ int fpt_hist2d_dev(fpt_ctx *c, const double *exp_dev, const double *obs_dev, int
     if (!hist_dev || ((!exp_dev || !obs_dev) && n > 0)) return fail(FPT_ERR_INVALID, "null buffer");
     fptk::launch_hist2d(c->stream, exp_dev, obs_dev, n, rows, cols, (unsigned long long *)hist_dev);
     return launch_ok("k_hist2d");
+}
+
+static int segment_setup(fpt_ctx *c, const fpt_segment_desc *d, fptk::segment_launch *sl) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
+    if (d->n_intervals < 0 || d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "bad interval count");
+    if (!d->track && d->n_intervals > 0) return fail(FPT_ERR_INVALID, "null track");
+    if (!d->interval_off && d->interval_len <= 0) return fail(FPT_ERR_INVALID, "interval_len must be positive");
+    if (d->w < 1 || d->w > (1 << 20)) return fail(FPT_ERR_INVALID, "w %d out of range", d->w);
+    sl->n_intervals = d->n_intervals;
+    sl->interval_len = d->interval_off ? 0 : d->interval_len;
+    sl->interval_off = d->interval_off;
+    sl->track = d->track;
+    sl->threshold = d->threshold;
+    sl->w = d->w;
+    sl->decreasing = d->decreasing ? 1 : 0;
+    return FPT_OK;
+}
+
+int fpt_segment_count_dev(fpt_ctx *c, const fpt_segment_desc *d, int64_t *total_out) {
+    fptk::segment_launch sl{};
+    if (int rc = segment_setup(c, d, &sl)) return rc;
+    if (!total_out) return fail(FPT_ERR_INVALID, "null output");
+    c->seg_n_intervals = -1;
+    *total_out = 0;
+    const size_t n = (size_t)d->n_intervals;
+    void *d_counts, *d_offsets;
+    if (int rc = ws_get(c, 10, std::max<size_t>(n, 1) * sizeof(int32_t), &d_counts)) return rc;
+    if (int rc = ws_get(c, 11, (n + 1) * sizeof(int64_t), &d_offsets)) return rc;
+    std::vector<int32_t> counts(n);
+    std::vector<int64_t> offsets(n + 1, 0);
+    if (n) {
+        sl.counts = (int32_t *)d_counts;
+        fptk::launch_segment(c->stream, sl, false);
+        if (int rc = launch_ok("k_segment (count)")) return rc;
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + counts[i];
+    }
+    HIP_TRY(hipMemcpyAsync(d_offsets, offsets.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `offsets` is pageable host memory
+    c->seg_n_intervals = d->n_intervals;
+    c->seg_total = offsets[n];
+    c->seg_track = d->track;
+    *total_out = offsets[n];
+    return FPT_OK;
+}
+
+int fpt_segment_fill_dev(fpt_ctx *c, const fpt_segment_desc *d, int64_t capacity, int32_t *seg_interval,
+                         int32_t *seg_start, int32_t *seg_end, double *seg_score) {
+    fptk::segment_launch sl{};
+    if (int rc = segment_setup(c, d, &sl)) return rc;
+    if (c->seg_n_intervals != d->n_intervals || c->seg_track != d->track)
+        return fail(FPT_ERR_INVALID, "fpt_segment_fill_dev must follow fpt_segment_count_dev of the same batch");
+    if (capacity < c->seg_total)
+        return fail(FPT_ERR_INVALID, "capacity %lld below the %lld segments counted", (long long)capacity,
+                    (long long)c->seg_total);
+    if (c->seg_total == 0) return FPT_OK;
+    if (!seg_interval || !seg_start || !seg_end || !seg_score) return fail(FPT_ERR_INVALID, "null output");
+    sl.offsets = (const int64_t *)c->ws[11];
+    sl.seg_iv = seg_interval;
+    sl.seg_start = seg_start;
+    sl.seg_end = seg_end;
+    sl.seg_score = seg_score;
+    fptk::launch_segment(c->stream, sl, true);
+    return launch_ok("k_segment (fill)");
 }
 
 int fpt_synth_dev(fpt_ctx *c, uint64_t seed, int64_t pos0_counts, int64_t n_counts, double *cp,

@@ -1250,6 +1250,103 @@ __global__ void __launch_bounds__(256) k_hist2d(const double *__restrict__ ex, c
 }
 
 // ===========================================================================
+// k_segment: utils.segment (stats/utils.pyx:15-50) of every interval of a track, one wavefront
+// per interval.  64 positions at a time are turned into two ballot masks (passing / failing the
+// threshold; NaN is in neither) and the open/close state machine runs on the masks in scalar
+// code, so its cost follows the number of runs, not of bases.  FILL = false counts the merged
+// segments, FILL = true writes them at the offsets computed from the counts.
+// ===========================================================================
+struct seg_args {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    const double *x;
+    double thr;
+    int32_t w, decreasing;
+    int32_t *counts;
+    const int64_t *offsets;
+    int32_t *seg_iv, *seg_start, *seg_end;
+    double *seg_score;
+};
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_segment(const seg_args a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t iv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iv >= a.n_intervals) return;
+    int64_t off;
+    int L;
+    if (a.interval_off) {
+        off = a.interval_off[iv];
+        L = (int)(a.interval_off[iv + 1] - off);
+    } else {
+        L = a.interval_len;
+        off = iv * (int64_t)L;
+    }
+    const double d = a.decreasing ? -1.0 : 1.0, thr = d * a.thr;
+    bool open = false, have = false;
+    int cs = 0, ps = 0, pe = 0, n_out = 0;
+    const int64_t o = FILL ? a.offsets[iv] : 0;
+    auto emit = [&](int s, int e) {
+        if (FILL) {
+            const int lo = s < 0 ? 0 : s, hi = e > L ? L : e;
+            double m = fptm::kInf;
+            bool bad = lo >= hi;  // empty slice: numpy's min raises, here the score is NaN
+            for (int j = lo + lane; j < hi; j += kWave) {
+                const double v = a.x[off + j];
+                bad |= isnan(v);
+                m = fmin(m, v);
+            }
+            for (int sft = kWave / 2; sft > 0; sft >>= 1) m = fmin(m, __shfl_xor(m, sft, kWave));
+            if (__ballot(bad)) m = NAN;
+            if (lane == 0) {
+                a.seg_iv[o + n_out] = (int32_t)iv;
+                a.seg_start[o + n_out] = s;
+                a.seg_end[o + n_out] = e;
+                a.seg_score[o + n_out] = m;
+            }
+        }
+        ++n_out;
+    };
+    for (int base = 0; base < L; base += kWave) {
+        const int i = base + lane;
+        const double dv = (i < L) ? d * a.x[off + i] : NAN;
+        const unsigned long long P = __ballot(dv >= thr), F = __ballot(dv < thr);
+        unsigned long long rem = ~0ull;  // positions of this block not consumed yet
+        // the reference keeps "no open run" as curr_start < 0, so a passing element whose
+        // curr_start = i - w + 1 would be negative does not open one: only positions >= w - 1 can
+        const int first_ok = a.w - 1 - base;
+        const unsigned long long can_open = first_ok <= 0 ? ~0ull : (first_ok >= 64 ? 0ull : (~0ull << first_ok));
+        for (;;) {
+            const unsigned long long m = (open ? F : (P & can_open)) & rem;
+            if (!m) break;
+            const int b = __ffsll((long long)m) - 1;
+            rem = b == 63 ? 0ull : (~0ull << (b + 1));
+            if (!open) {
+                cs = base + b - a.w + 1;
+                open = true;
+            } else {
+                const int e = base + b - 1 + a.w;
+                open = false;
+                if (have && cs <= pe) {
+                    pe = e;  // overlaps the previous segment: extend it
+                } else {
+                    if (have) emit(ps, pe);
+                    ps = cs;
+                    pe = e;
+                    have = true;
+                }
+            }
+        }
+    }
+    if (have) emit(ps, pe);
+    if (!FILL && lane == 0) a.counts[iv] = n_out;
+}
+
+template __global__ void k_segment<false>(const seg_args);
+template __global__ void k_segment<true>(const seg_args);
+
+// ===========================================================================
 // synthetic workload + checksum
 // ===========================================================================
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -1498,6 +1595,26 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         hipLaunchKernelGGL((k_fdr_null<256, false>), dim3((unsigned)n), dim3(256), lds, st, b);
     }
     return hipSuccess;
+}
+
+void launch_segment(hipStream_t st, const segment_launch &sl, bool fill) {
+    seg_args a;
+    a.n_intervals = sl.n_intervals;
+    a.interval_len = sl.interval_len;
+    a.interval_off = sl.interval_off;
+    a.x = sl.track;
+    a.thr = sl.threshold;
+    a.w = sl.w;
+    a.decreasing = sl.decreasing;
+    a.counts = sl.counts;
+    a.offsets = sl.offsets;
+    a.seg_iv = sl.seg_iv;
+    a.seg_start = sl.seg_start;
+    a.seg_end = sl.seg_end;
+    a.seg_score = sl.seg_score;
+    const unsigned grid = (unsigned)((sl.n_intervals + 3) / 4);
+    if (fill) hipLaunchKernelGGL(k_segment<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_segment<false>, dim3(grid), dim3(256), 0, st, a);
 }
 
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,

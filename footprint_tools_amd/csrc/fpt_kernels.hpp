@@ -64,6 +64,20 @@ struct fdr_launch {
 };
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl);
+
+struct segment_launch {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    const double *track;
+    double threshold;
+    int32_t w, decreasing;
+    int32_t *counts;          // pass 1 output, one per interval
+    const int64_t *offsets;   // pass 2 input: exclusive prefix of counts
+    int32_t *seg_iv, *seg_start, *seg_end;
+    double *seg_score;
+};
+void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
 size_t fdr_lds_bytes(int n2);
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide);
 size_t nb_guide_bytes(int n_models, int memo_exp);

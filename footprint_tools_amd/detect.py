@@ -155,6 +155,16 @@ def write_stats_to_output(interval, stats, file=sys.stdout, delim="\t", filter_f
         + "\n" for i in rows))
 
 
+def write_segment_batch_to_output(intervals, segments, name=".", file=sys.stdout, delim="\t", fmt_string="0.4f"):
+    """BED lines of `FootprintScanner.segment` output (one device pass over the whole FDR track)
+    in the format of write_segments_to_output; `intervals` are the batch's interval objects."""
+    fmt = "{0:" + fmt_string + "}"
+    file.write("".join(
+        delim.join([str(intervals[i].chrom), str(intervals[i].start + s), str(intervals[i].start + e), name,
+                    fmt.format(sc)]) + "\n"
+        for i, s, e, sc in zip(segments["interval"], segments["start"], segments["end"], segments["score"])))
+
+
 def write_segments_to_output(interval, stats, threshold, name=".", file=sys.stdout, delim="\t",
                              score_fn=np.min, decreasing=False, fmt_string="0.4f"):
     assert stats.ndim == 1

@@ -289,6 +289,55 @@ class FootprintScanner(object):
             for b in bufs:
                 b.free()
 
+    # ---- footprint calling: utils.segment over a whole track (cli/utils.py:204) -----------
+    def segment_dev(self, track, n_intervals, threshold, w=3, decreasing=True, interval_len=None,
+                    interval_off_dev=None):
+        """Segments of a DEVICE track (pointer) -> dict of host arrays interval / start / end /
+        score, ordered by interval and position; start / end are relative to the interval."""
+        ctx = self.ctx
+        d = _lib.SegmentDesc()
+        d.n_intervals, d.interval_len, d.interval_off = int(n_intervals), int(interval_len or 0), interval_off_dev
+        d.track, d.threshold, d.w, d.decreasing = track, float(threshold), int(w), int(bool(decreasing))
+        total = C.c_int64()
+        _lib.check(ctx.L.fpt_segment_count_dev(ctx.h, C.byref(d), C.byref(total)))
+        n = total.value
+        out = dict(interval=np.empty(0, np.int32), start=np.empty(0, np.int32), end=np.empty(0, np.int32),
+                   score=np.empty(0, np.float64))
+        if n == 0:
+            return out
+        buf = DeviceArray(ctx, n * 20)
+        try:
+            _lib.check(ctx.L.fpt_segment_fill_dev(ctx.h, C.byref(d), n, buf.ptr + 8 * n, buf.ptr + 12 * n,
+                                                  buf.ptr + 16 * n, buf.ptr))
+            ctx.synchronize()
+            out["score"] = buf.download(np.float64, n)
+            out["interval"] = buf.download(np.int32, n, 8 * n)
+            out["start"] = buf.download(np.int32, n, 12 * n)
+            out["end"] = buf.download(np.int32, n, 16 * n)
+        finally:
+            buf.free()
+        return out
+
+    def segment(self, track, threshold, w=3, decreasing=True, interval_len=None, interval_off=None):
+        """`utils.segment` of every interval of a host track in one launch pair."""
+        ctx = self.ctx
+        track = _lib.f64(track).ravel()
+        bufs = [DeviceArray(ctx, max(track.nbytes, 16)).upload(track)]
+        try:
+            d_off = None
+            if interval_off is not None:
+                off = np.ascontiguousarray(interval_off, dtype=np.int64)
+                d_off = DeviceArray(ctx, off.nbytes).upload(off)
+                bufs.append(d_off)
+                n_iv = off.size - 1
+            else:
+                n_iv = track.size // int(interval_len)
+            return self.segment_dev(bufs[0].ptr, n_iv, threshold, w, decreasing, interval_len=interval_len,
+                                    interval_off_dev=d_off.ptr if d_off else None)
+        finally:
+            for b in bufs:
+                b.free()
+
     # ---- synthetic workload (BASELINE.json configs 1-3) ---------------------------------
     def synth_dev(self, seed, n_intervals, interval_len, counts_plus, counts_minus, seq,
                   first_interval=0):

@@ -231,6 +231,33 @@ int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
 int fpt_hist2d_dev(fpt_ctx *ctx, const double *exp_dev, const double *obs_dev, int64_t n, int rows,
                    int cols, uint64_t *hist_dev);
 
+/* Footprint calling on a whole track: `utils.segment(x, threshold, w, decreasing)`
+ * (stats/utils.pyx:15-50) of every interval, as `write_segments_to_output` applies it to the FDR
+ * column with w = 3, decreasing = 1 (cli/utils.py:204).  A run opens at the first element with
+ * dir*x >= dir*threshold and closes at the first with dir*x < dir*threshold (NaN does neither; a
+ * run still open at the end of its interval is dropped, and a passing element at a position
+ * below w - 1 does not open one, both as in the reference, whose "no open run" state is
+ * curr_start < 0); it is reported as [first - w + 1, closing - 1 + w) and merged with the
+ * previous one when it starts at or before that one's end.  score = min(x[start:end]) clipped to the interval (NaN if any NaN),
+ * the reference's default score_fn.  Two calls: count, then fill buffers of at least that size. */
+typedef struct fpt_segment_desc {
+    int64_t n_intervals;
+    int32_t interval_len;             /* uniform batches (interval_off == NULL) */
+    const int64_t *interval_off;      /* ragged: DEVICE offsets into the track (n_intervals+1) */
+    const double *track;              /* DEVICE */
+    double threshold;
+    int32_t w;
+    int32_t decreasing;
+} fpt_segment_desc;
+
+/* pass 1: number of segments of the whole batch -> *total_out (synchronises the stream) */
+int fpt_segment_count_dev(fpt_ctx *ctx, const fpt_segment_desc *desc, int64_t *total_out);
+/* pass 2 (same desc as the preceding count call): segments ordered by interval, then position.
+ * DEVICE outputs of `capacity` >= total entries: interval index, start, end (relative to the
+ * interval, end exclusive and possibly past the interval's end like the reference's), score. */
+int fpt_segment_fill_dev(fpt_ctx *ctx, const fpt_segment_desc *desc, int64_t capacity,
+                         int32_t *seg_interval, int32_t *seg_start, int32_t *seg_end, double *seg_score);
+
 /* Fill device buffers with the synthetic workload of BASELINE.json configs 1-3:
  * counter-hash generator, element at global position p of stream s is
  * mix(mix(seed+s)+p); counts = U{0..19} as float64, bases uniform ACGT.
