@@ -945,3 +945,87 @@ def test_segment_device(fpt):
         detect.write_segments_to_output(ivs[i], t[lo:hi], 0.05, file=b, decreasing=True)
     assert a.getvalue() == b.getvalue() and a.getvalue().count("\n") > 5
     assert sc.segment(np.ones(10), 0.5, 3, True, interval_len=10)["start"].size == 0
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "12"))))
+def test_fused_scan_fuzz(fpt, orc, seed):
+    """random geometry (ragged lengths incl. multi-tile ones), window widths, clip, scales, count
+    distributions (sparse / dense / constant runs / fractional / huge / negative), N and
+    lower-case bases, dispersion model and p-value mode -- against the oracle, interval by interval."""
+    from footprint_tools_amd.scan import FootprintScanner
+    rs = np.random.RandomState(1000 + seed)
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    hw = int(rs.choice([1, 2, 3, 5, 5, 8]))
+    shw = int(rs.choice([0, 1, 7, 31, 32, 50, 50, 64, 65, 120]))
+    clip = float(rs.choice([0.0, 0.005, 0.01, 0.01, 0.02, 0.05, 0.2]))
+    if shw and int((2 * shw + 1) * clip) * 2 >= 2 * shw + 1:
+        clip = 0.01
+    n_sc = int(rs.randint(0, 4))
+    scales = tuple(int(x) for x in rs.choice([0, 1, 3, 3, 5, 10, 33, 70], n_sc, replace=False))
+    dm = str(rs.choice(["A", "B", "C"]))
+    mode = str(rs.choice(["direct", "memo", "auto"]))
+    pad = hw + shw
+    n_iv = int(rs.randint(3, 14))
+    lens = rs.choice([1, 2, 5, 17, 63, 64, 65, 200, 500, 700, 1024, 1025, 1500, 2300], n_iv)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n_c = int(off[-1] + n_iv * (2 * pad + 1))
+    kind = str(rs.choice(["dense", "sparse", "runs", "float", "huge", "neg"]))
+    if kind == "dense":
+        cp, cm = rs.randint(0, 20, n_c).astype(float), rs.randint(0, 20, n_c).astype(float)
+    elif kind == "sparse":
+        cp, cm = rs.poisson(0.05, n_c).astype(float), rs.poisson(0.3, n_c).astype(float)
+    elif kind == "runs":  # long constant stretches: near-constant smoothing windows
+        cp = np.repeat(rs.randint(0, 4, n_c // 37 + 1), 37)[:n_c].astype(float)
+        cm = np.repeat(rs.randint(0, 2, n_c // 150 + 1), 150)[:n_c].astype(float)
+    elif kind == "float":
+        # generic fractions: with decimal fractions P/Q*W' can sit EXACTLY on a half-integer, where
+        # the last bit of the smoothed sum decides round() (DESIGN.md 2, "fractional counts")
+        cp, cm = rs.gamma(1.5, 2.0, n_c), rs.gamma(0.5, 3.0, n_c)
+    elif kind == "huge":
+        cp, cm = rs.randint(0, 20, n_c).astype(float), rs.randint(0, 5, n_c).astype(float)
+        # window sums beyond 2^24 leave the int32 smoothing path.  Counts are kept below 2^26: at
+        # obs ~ 1e9 incbet's exponent (~1e10) is only good to ~1e-6 in ANY double implementation,
+        # so reference and device then differ by a few 1e-6 -- conditioning, not a defect
+        cp[rs.randint(0, n_c, 5)] = 2.0 ** rs.randint(20, 26, 5)
+    else:
+        cp, cm = rs.randint(-2, 6, n_c).astype(float), rs.randint(0, 6, n_c).astype(float)
+    sq = rs.choice(np.frombuffer(b"ACGTACGTACGTacgtN", np.uint8), int(off[-1] + n_iv * (2 * pad + 7)))
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales, nb_mode=mode)
+    out = sc.scan(cp, cm, sq, interval_off=off)
+    tag = (hw, shw, clip, scales, dm, mode, kind, lens.tolist())
+    for i, L in enumerate(lens):
+        a, b = off[i] + i * (2 * pad + 1), off[i + 1] + (i + 1) * (2 * pad + 1)
+        sa, sb = off[i] + i * (2 * pad + 7), off[i + 1] + (i + 1) * (2 * pad + 7)
+        e, o, p, wp = orc.detect_batch(cp[a:b], cm[a:b], sq[sa:sb], 1, int(L), hw, shw, clip, table,
+                                       lat["mu_" + dm], lat["r_" + dm], np.array(scales, np.int32))
+        sl = slice(off[i], off[i + 1])
+        assert np.array_equal(out["obs"][sl], o), tag
+        got_e = out["exp"][sl]
+        bad = np.flatnonzero(~((got_e == e) | (np.isnan(got_e) & np.isnan(e))))
+        ok = np.ones(int(L), bool)
+        if bad.size:
+            # the only admissible difference: P/Q*W' of a strand sits on a half-integer to the last
+            # bits, where the reference's own rounding noise decides round() (DESIGN.md 2)
+            assert bad.size <= max(3, L // 200), tag
+            fwd, rev = orc.kmer_probs(sq[sa:sb], table)[:2]
+            l = b - a
+            tie = np.zeros(int(L), bool)
+            for c, pr, shift in ((cp[a:b], fwd[:l], pad + 1), (cm[a:b], rev[:l], pad)):
+                _, w = orc.fast_predict(c, pr, hw, shw, clip)
+                for t in bad:
+                    v = shift + t
+                    q = sum(pr[v + j] for j in range(-hw, hw))
+                    prod = pr[v] / q * w[v]
+                    tie[t] |= abs(abs(prod - np.floor(prod)) - 0.5) < 1e-9
+            assert tie[bad].all(), tag
+            assert np.all(np.abs(got_e[bad] - e[bad]) == 1.0), tag
+            ok[bad] = False
+        assert rel_err(out["pval"][sl][ok], p[ok]) < P_TOL, tag
+        for s_i, hs in enumerate(scales):
+            okw = ok.copy()
+            for t in bad:
+                okw[max(0, t - hs):t + hs + 1] = False
+            # z = ndtri(1 - p) amplifies an error of p by 1/(1 - p); with the ill-conditioned p of
+            # counts in the millions next to p ~ 0.9998 that reaches a few 1e-6 on the window
+            assert rel_err(out["winp"][s_i, sl][okw], wp[s_i][okw]) < (1e-4 if kind == "huge" else P_TOL), tag
