@@ -1029,3 +1029,37 @@ def test_fused_scan_fuzz(fpt, orc, seed):
             # z = ndtri(1 - p) amplifies an error of p by 1/(1 - p); with the ill-conditioned p of
             # counts in the millions next to p ~ 0.9998 that reaches a few 1e-6 on the window
             assert rel_err(out["winp"][s_i, sl][okw], wp[s_i][okw]) < (1e-4 if kind == "huge" else P_TOL), tag
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
+def test_fdr_fuzz(fpt, orc, seed):
+    """random interval lengths (LDS and global-buffer sizes), window widths, draw counts, expected
+    value ranges (inside / beyond the table, non-integer), observed tracks with NaN, ties, 0 and 1:
+    every null window p-value and the empirical FDR against the oracle."""
+    from footprint_tools_amd.scan import FootprintScanner
+    rs = np.random.RandomState(5000 + seed)
+    lat = golden("nb_lattice.npz")
+    dm = str(rs.choice(["A", "B", "C"]))
+    sc = FootprintScanner(golden("kmer_probs.npz")["table"], _DM(lat["mu_" + dm], lat["r_" + dm]), 5, 50, 0.01, (3,))
+    hw = int(rs.choice([0, 1, 3, 3, 10, 40]))
+    times = int(rs.choice([1, 2, 3, 8, 13]))
+    n_iv = int(rs.randint(1, 7))
+    lens = rs.choice([1, 2, 7, 64, 65, 300, 511, 512, 1000, 4096, 4097, 6000], n_iv)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    scale = float(rs.choice([0.3, 3.0, 12.0, 60.0]))
+    exp = np.round(rs.gamma(2.0, scale, off[-1]))
+    if rs.uniform() < 0.5:
+        exp[rs.randint(0, exp.size, max(1, exp.size // 50))] += 0.5      # non-integer
+        exp[rs.randint(0, exp.size, max(1, exp.size // 100))] = 400.0    # beyond the table rows
+    winp = rs.uniform(0, 1, off[-1]) ** float(rs.choice([1, 3]))
+    winp[rs.randint(0, winp.size, max(1, winp.size // 30))] = np.nan
+    winp[rs.randint(0, winp.size, max(1, winp.size // 30))] = rs.choice([0.0, 1.0, 0.25])
+    base0 = int(rs.randint(0, 2 ** 40))
+    ef, nul = sc.fdr(exp, winp, times=times, seed=seed, half_win_width=hw, interval_off=off, base_index0=base0,
+                     return_null=True)
+    tag = (dm, hw, times, lens.tolist(), scale)
+    for a, b in zip(off[:-1], off[1:]):
+        want, wn = orc.fdr_null(lat["mu_" + dm], lat["r_" + dm], exp[a:b], winp[a:b], hw, times, seed=seed,
+                                base0=base0 + a, return_null=True)
+        assert rel_err(nul[a:b], wn) < 1e-9, tag
+        assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times), tag
