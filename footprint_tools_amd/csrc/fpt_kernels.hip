@@ -614,8 +614,17 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         out_off = a.interval_off[iv];
         L = (int)(a.interval_off[iv + 1] - out_off);
     } else {
-        iv = tile / a.tiles_per_interval;
-        t0 = (int)(tile % a.tiles_per_interval) * a.tile_len;
+        if (a.tiles_per_interval == 1) {  // the common case; a 64-bit scalar division costs ~150 instructions
+            iv = tile;
+            t0 = 0;
+        } else if ((tile >> 32) == 0) {
+            const uint32_t q = (uint32_t)tile / (uint32_t)a.tiles_per_interval;
+            iv = q;
+            t0 = (int)((uint32_t)tile - q * (uint32_t)a.tiles_per_interval) * a.tile_len;
+        } else {
+            iv = tile / a.tiles_per_interval;
+            t0 = (int)(tile % a.tiles_per_interval) * a.tile_len;
+        }
         L = a.interval_len;
         out_off = iv * (int64_t)L;
         tl = min(a.tile_len, L - t0);
