@@ -49,10 +49,15 @@ class deviation_stats(object):
         return len(self.intervals)
 
     def _scanner(self):
-        if self._sc is None and self.dm:
-            self._sc = FootprintScanner(self.bm.table(), self.dm, self.half_win_width,
-                                        self.smoothing_half_win_width, self.smoothing_clip,
-                                        scales=(3,), default_propensity=self.bm.default, ctx=self._ctx)
+        if self._sc is None:
+            if self.dm:
+                self._sc = FootprintScanner(self.bm.table(), self.dm, self.half_win_width,
+                                            self.smoothing_half_win_width, self.smoothing_clip,
+                                            scales=(3,), default_propensity=self.bm.default, ctx=self._ctx)
+            else:  # no dispersion model: expected and observed counts only (detect.py:145-146)
+                self._sc = FootprintScanner(self.bm.table(), None, self.half_win_width,
+                                            self.smoothing_half_win_width, self.smoothing_clip, scales=(),
+                                            default_propensity=self.bm.default, ctx=self._ctx, nb_mode="none")
         return self._sc
 
     def _fetch(self, interval):
@@ -81,19 +86,10 @@ class deviation_stats(object):
             if cp.size != L + 2 * self.padding + 1 or sq.size != cp.size + 6:
                 raise ValueError("read_func / fasta_func returned arrays of the wrong length")
         sc = self._scanner()
-        if sc is None:  # no dispersion model: expected and observed counts only (detect.py:145-146)
-            from .modeling import predict as _p
-            out = []
-            for iv, cp, cm, sq in zip(ivs, cps, cms, sqs):
-                fwd, rev = self.bm.probs_both(bytes(sq).upper())
-                e, _ = _p.predict(np.stack([cp, cm]), np.stack([fwd[:cp.size], rev[:cp.size]]),
-                                  self.half_win_width, self.smoothing_half_win_width, self.smoothing_clip)
-                p = self.padding
-                exp = e[0][p + 1:cp.size - p] + e[1][p:cp.size - p - 1]
-                obs = cp[p + 1:cp.size - p] + cm[p:cp.size - p - 1]
-                out.append({"interval": iv, "stats": np.column_stack((exp, obs))})
-            return out
         res = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
+        if not self.dm:
+            return [{"interval": iv, "stats": np.column_stack((res["exp"][a:b], res["obs"][a:b]))}
+                    for iv, a, b in zip(ivs, off[:-1], off[1:])]
         # global base index of each interval = bases of all intervals before it in the full list,
         # so the null draws do not depend on how the list is batched or sharded
         if self._bases_before is None:

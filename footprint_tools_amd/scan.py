@@ -204,7 +204,10 @@ class FootprintScanner(object):
         finally:
             for b in bufs:
                 b.free()
-        return dict(exp=flat[:total], obs=flat[total:2 * total], pval=flat[2 * total:3 * total],
+        pval = flat[2 * total:3 * total]
+        if self.nb_mode == _lib.NB_NONE:  # counts only: no p-values were computed
+            pval = np.full(total, np.nan)
+        return dict(exp=flat[:total], obs=flat[total:2 * total], pval=pval,
                     winp=flat[3 * total:].reshape(S, total), status=status)
 
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------

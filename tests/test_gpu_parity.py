@@ -757,6 +757,10 @@ def test_deviation_stats_driver(fpt, orc, tmp_path):
         assert np.max(np.abs(st[:, 4] - ef)) <= 2.5 / (L * times)
         assert np.array_equal(st, rec2["stats"], equal_nan=True)  # batching does not change results
         base += L
+    # without a dispersion model: expected and observed counts only (detect.py:145-146)
+    nodm = detect.deviation_stats(ivs, Reads(), Fasta(), bm, None, hw, shw, 0.01).compute(range(len(ivs)))
+    for rec, rec0 in zip(nodm, whole):
+        assert rec["stats"].shape[1] == 2 and np.array_equal(rec["stats"], rec0["stats"][:, :2])
     # writers: the reference's text format (cli/utils.py:119-210)
     buf = io.StringIO()
     detect.write_stats_to_output(ivs[3], whole[3]["stats"][:2], file=buf)
