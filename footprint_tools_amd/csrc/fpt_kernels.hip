@@ -648,11 +648,19 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     const double2 *memo = a.memo ? a.memo + (size_t)dm * a.memo_exp * a.memo_obs : nullptr;
     const double *par = MO ? model : par_lds;
     if (!MO && tid < 24) par_lds[tid] = model[tid];
-    for (int v = tid; v < nc; v += NT) {
-        cP[v] = a.counts_plus[cbase + v];
-        cM[v] = a.counts_minus[cbase + v];
+    if (ABL(16384)) {  // inputs made up in registers: what the kernel costs without its HBM reads
+        for (int v = tid; v < nc; v += NT) {
+            cP[v] = (double)((v * 7 + (int)tile) % 20);
+            cM[v] = (double)((v * 13 + (int)tile) % 20);
+        }
+        for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)((v * 5 + (int)tile) & 3);
+    } else {
+        for (int v = tid; v < nc; v += NT) {
+            cP[v] = a.counts_plus[cbase + v];
+            cM[v] = a.counts_minus[cbase + v];
+        }
+        for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
     }
-    for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
     __syncthreads();
     if (ABL(32)) return;
 
