@@ -255,6 +255,7 @@ struct scan_args {
     int32_t scales[FPT_MAX_SCALES];
     double scale_sqrt[FPT_MAX_SCALES];
     int32_t max_scale;
+    int32_t min_scale;
     int32_t nc_max;              // LDS capacity per array (padded positions)
     int64_t total_bases;
     const double *counts_plus;
@@ -834,18 +835,39 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     }
     if (a.n_scales == 0 || ABL(256)) return;
 
-    // ---- E: tile prefix sums of (z, non-finite count); a Stouffer window is assembled from the
-    //         tiles it touches like the smoothing windows above (windowing.h:53-84)
-    wave_scan(zv, zc, lane);
-    if (tid < ((nt + kWave - 1) & ~(kWave - 1))) {
-        zb[tid] = zv;
-        nf[tid] = zc;
+    // ---- E: Stouffer windows (windowing.h:53-84).  Narrow ones (the reference's hw = 3) are
+    //         summed directly from the raw z in LDS, left to right like the reference; a
+    //         non-finite z makes the sum non-finite, which is the NaN rule.  Wider ones are
+    //         assembled from per-tile prefix sums of (z, non-finite count) like the smoothing
+    //         windows above, so their cost does not grow with the width.
+    constexpr int kDirectWin = 8;
+    double *zraw = pP;  // propensities are dead after C
+    if (a.min_scale <= kDirectWin && tid < nt) zraw[tid] = z;
+    if (a.max_scale > kDirectWin) {
+        wave_scan(zv, zc, lane);
+        if (tid < ((nt + kWave - 1) & ~(kWave - 1))) {
+            zb[tid] = zv;
+            nf[tid] = zc;
+        }
     }
     __syncthreads();
     for (int s = 0; s < a.n_scales; ++s) {
         const int hs = a.scales[s];
         const double rk = a.scale_sqrt[s];
         double *dst = a.winp_out + (int64_t)s * a.total_bases + out_off;
+        if (hs <= kDirectWin) {
+            for (int v = tid; v < tl; v += NT) {
+                const int t = t0 + v;
+                double res = 1.0;  // edges are 1.0 (windowing.pyx:51)
+                if (t >= hs && t < L - hs) {
+                    double sv = 0.0;
+                    for (int j = t - ta - hs; j <= t - ta + hs; ++j) sv += zraw[j];
+                    res = !isfinite(sv) ? NAN : (ABL(4) ? sv : fptm::ndtr(-(sv * rk)));
+                }
+                dst[t] = res;
+            }
+            continue;
+        }
         for (int v = tid; v < tl; v += NT) {
             int t = t0 + v;
             double res = 1.0;  // edges are 1.0 (windowing.pyx:51)
@@ -1128,6 +1150,11 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 
     // ---- 2. null tracks, two samples per pass (one Philox block feeds both)
     const int hs = a.hw;
+    // Narrow windows (the reference only ever uses hw = 3) are summed directly from the raw z in
+    // LDS, left to right like windowing.h:53-67: 2*hs+1 reads and adds are fewer instructions than
+    // three prefix scans plus three tile-range sums, and a non-finite z shows up as a non-finite
+    // sum, so no separate count is needed.  Wider windows take the prefix-scan path.
+    const bool direct = hs <= 8;
     for (int s = 0; s < a.times; s += 2) {
         const bool two = s + 1 < a.times;
         for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
@@ -1151,19 +1178,38 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 } else {
                     nb_draw_z2(memo, guide, a.memo_exp, a.memo_obs, par, a.exp[off + t], u0, u1, z0, z1);
                 }
-                const bool f0 = isfinite(z0), f1 = isfinite(z1);
-                z0 = f0 ? z0 : 0.0;
-                z1 = f1 ? z1 : 0.0;
-                zc = (f0 ? 0 : 1) | (f1 ? 0 : 1 << 16);
+                if (!direct) {
+                    const bool f0 = isfinite(z0), f1 = isfinite(z1);
+                    z0 = f0 ? z0 : 0.0;
+                    z1 = f1 ? z1 : 0.0;
+                    zc = (f0 ? 0 : 1) | (f1 ? 0 : 1 << 16);
+                }
             }
-            zb[t] = scan_add(z0);
-            zb1[t] = scan_add(z1);
-            nf[t] = scan_add(zc);
+            if (direct) {
+                if (t < L) {
+                    zb[t] = z0;
+                    zb1[t] = z1;
+                }
+            } else {
+                zb[t] = scan_add(z0);
+                zb1[t] = scan_add(z1);
+                nf[t] = scan_add(zc);
+            }
         }
         __syncthreads();
         for (int t = tid; t < L; t += NT) {
             double x0 = 1.0, x1 = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
-            if (t >= hs && t < L - hs) {
+            if (direct) {
+                if (t >= hs && t < L - hs) {
+                    double s0 = 0.0, s1 = 0.0;
+                    for (int j = t - hs; j <= t + hs; ++j) {
+                        s0 += zb[j];
+                        s1 += zb1[j];
+                    }
+                    x0 = !isfinite(s0) ? NAN : (ABL(2048) ? 0.5 * s0 : fptm::ndtr(-(s0 * a.inv_sqrt_k)));
+                    x1 = !isfinite(s1) ? NAN : (ABL(2048) ? 0.5 * s1 : fptm::ndtr(-(s1 * a.inv_sqrt_k)));
+                }
+            } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
                 const double s0 = le3 ? tile_range_sum3(zb, t - hs, t + hs) : tile_range_sum(zb, t - hs, t + hs);
                 const double s1 = le3 ? tile_range_sum3(zb1, t - hs, t + hs) : tile_range_sum(zb1, t - hs, t + hs);
@@ -1514,6 +1560,8 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.k_trim = sl.k_trim;
     a.n_scales = sl.n_scales;
     a.max_scale = 0;
+    a.min_scale = 1 << 30;
+    for (int i = 0; i < sl.n_scales; ++i) a.min_scale = sl.scales[i] < a.min_scale ? sl.scales[i] : a.min_scale;
     for (int i = 0; i < FPT_MAX_SCALES; ++i) {
         a.scales[i] = i < sl.n_scales ? sl.scales[i] : 0;
         // 1/sqrt(K): the reference divides by sqrt(K) (windowing.h:64); multiplying by the
