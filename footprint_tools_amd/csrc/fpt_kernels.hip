@@ -1050,6 +1050,56 @@ __device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *
     }
 }
 
+// A null window p-value is ndtr(y), y = -(sum of z) / sqrt(K), and only its RANK among the
+// interval's observed values is needed.  ndtr is monotone, so "observed P < ndtr(y)" is
+// "T(P) <= y" with T(P) the smallest double y whose ndtr(y) exceeds P.  Translating the L observed
+// values once (a few ndtr evaluations each: start at ndtri(P), gallop and bisect over the
+// ordered-integer image of the doubles) replaces `times` ndtr evaluations per base by comparisons
+// of y.  Where the device ndtr is not monotone to the last bit, a null value within rounding of
+// an observed one may land on the other side -- the tolerance ranks already have.
+__device__ __forceinline__ long long ordered_bits(double y) {
+    const long long b = __double_as_longlong(y);
+    return b < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)b) : b;
+}
+__device__ __forceinline__ double from_ordered_bits(long long k) {
+    const long long b = k < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)k) : k;
+    return __longlong_as_double(b);
+}
+__device__ __forceinline__ double ndtr_threshold(double P) {
+    if (!(P < 1.0)) return fptm::kInf;  // ndtr never exceeds 1
+    if (P < 0.0) return -fptm::kInf;
+    const double y0 = P > 0.0 ? fptm::ndtri(P) : -39.0;
+    long long lo, hi, step = 1;  // ndtr(lo) <= P < ndtr(hi)
+    if (fptm::ndtr(y0) > P) {
+        hi = ordered_bits(y0);
+        for (;;) {
+            const long long c = hi - step;
+            if (!(fptm::ndtr(from_ordered_bits(c)) > P)) {
+                lo = c;
+                break;
+            }
+            hi = c;
+            step <<= 1;
+        }
+    } else {
+        lo = ordered_bits(y0);
+        for (;;) {
+            const long long c = lo + step;
+            if (fptm::ndtr(from_ordered_bits(c)) > P) {
+                hi = c;
+                break;
+            }
+            lo = c;
+            step <<= 1;
+        }
+    }
+    while (hi - lo > 1) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (fptm::ndtr(from_ordered_bits(mid)) > P) hi = mid; else lo = mid;
+    }
+    return from_ordered_bits(hi);
+}
+
 // GWS: the per-interval buffers live in global memory instead of LDS -- the same code for
 // intervals too long for the 160 KB of a CU (one workgroup still owns one interval, and a
 // workgroup's own global writes are visible to it after __syncthreads()).
@@ -1133,16 +1183,36 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     __syncthreads();
     const int m = misc[1];
-    // rank guide: null window p-values are close to uniform, so cutting [0, 1] into nb slices
-    // leaves about one observed value per slice and a rank needs a probe or two, not log2(L)
-    const int nb = np2 < 2048 ? np2 : 2048;
-    const double fnp2 = (double)nb;
-    for (int b = tid; b <= nb; b += NT) {
-        const double edge = (double)b / fnp2;
+    // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold); the rank of
+    // the edge positions' constant 1.0 is the number of observed values below 1
+    if (tid == 0) {
         int l = 0, h = m;
         while (l < h) {
             const int mid = (l + h) >> 1;
-            if (skey[mid] < edge) l = mid + 1; else h = mid;
+            if (skey[mid] < 1.0) l = mid + 1; else h = mid;
+        }
+        misc[2] = l;
+    }
+    __syncthreads();
+    const int rank_one = misc[2];
+    for (int i = tid; i < m; i += NT) skey[i] = ndtr_threshold(skey[i]);
+    __syncthreads();
+    // rank guide: y of a null window is about standard normal; nb slices of [-kYR, kYR) (the first
+    // and last reach to infinity) bracket #{T <= y}, so a rank needs a probe or two, not log2(L)
+    constexpr double kYR = 4.5;
+    const int nb = np2 < 2048 ? np2 : 2048;
+    const double yscale = (double)nb / (2.0 * kYR);
+    for (int b = tid; b <= nb; b += NT) {
+        int l = 0;
+        if (b == nb) {
+            l = rank_one;  // thresholds below +inf
+        } else if (b > 0) {
+            const double edge = (double)b / yscale - kYR;
+            int h = m;
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (skey[mid] <= edge) l = mid + 1; else h = mid;
+            }
         }
         rguide[b] = l;
     }
@@ -1198,7 +1268,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         }
         __syncthreads();
         for (int t = tid; t < L; t += NT) {
-            double x0 = 1.0, x1 = 1.0;  // edges are 1.0 and are part of the pooled null (windowing.pyx:51)
+            // y of the two null windows: NaN when a z in the window is not finite, +inf stands for
+            // the edges, whose window p-value is the constant 1.0 (windowing.pyx:51) and which are
+            // part of the pooled null
+            double y0 = fptm::kInf, y1 = fptm::kInf;
             if (direct) {
                 if (t >= hs && t < L - hs) {
                     double s0 = 0.0, s1 = 0.0;
@@ -1206,35 +1279,35 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                         s0 += zb[j];
                         s1 += zb1[j];
                     }
-                    x0 = !isfinite(s0) ? NAN : (ABL(2048) ? 0.5 * s0 : fptm::ndtr(-(s0 * a.inv_sqrt_k)));
-                    x1 = !isfinite(s1) ? NAN : (ABL(2048) ? 0.5 * s1 : fptm::ndtr(-(s1 * a.inv_sqrt_k)));
+                    y0 = isfinite(s0) ? -(s0 * a.inv_sqrt_k) : NAN;
+                    y1 = isfinite(s1) ? -(s1 * a.inv_sqrt_k) : NAN;
                 }
             } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
                 const double s0 = le3 ? tile_range_sum3(zb, t - hs, t + hs) : tile_range_sum(zb, t - hs, t + hs);
                 const double s1 = le3 ? tile_range_sum3(zb1, t - hs, t + hs) : tile_range_sum(zb1, t - hs, t + hs);
                 const int sc = le3 ? tile_range_sum3(nf, t - hs, t + hs) : tile_range_sum(nf, t - hs, t + hs);
-                x0 = (sc & 0xffff) ? NAN : (ABL(2048) ? 0.5 * s0 : fptm::ndtr(-(s0 * a.inv_sqrt_k)));
-                x1 = (sc >> 16) ? NAN : (ABL(2048) ? 0.5 * s1 : fptm::ndtr(-(s1 * a.inv_sqrt_k)));
+                y0 = (sc & 0xffff) ? NAN : -(s0 * a.inv_sqrt_k);
+                y1 = (sc >> 16) ? NAN : -(s1 * a.inv_sqrt_k);
             }
-            if (a.null_out) {
+            if (a.null_out) {  // the p-values themselves only when somebody wants them
                 double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
-                np_[0] = x0;
-                if (two) np_[1] = x1;
+                np_[0] = y0 == fptm::kInf ? 1.0 : fptm::ndtr(y0);
+                if (two) np_[1] = y1 == fptm::kInf ? 1.0 : fptm::ndtr(y1);
             }
             if (ABL(4096)) {
-                if (x0 == 12345.0 || x1 == 12345.0) atomicAdd(&misc[0], 1);
+                if (y0 == 12345.0 || y1 == 12345.0) atomicAdd(&misc[0], 1);
                 continue;
             }
-            // rank = number of sorted observed values < x: bisect inside the guide's bracket,
-            // both samples in step (NaN ends up anywhere and is not counted)
-            int b0 = (x0 >= 0.0) ? (int)(x0 * fnp2) : 0, b1 = (x1 >= 0.0) ? (int)(x1 * fnp2) : 0;
-            b0 = b0 < nb ? b0 : nb - 1;
-            b1 = b1 < nb ? b1 : nb - 1;
+            // rank = #{thresholds <= y}: bisect inside the guide's bracket, both samples in step
+            // (for NaN the result is unused; +inf gets the precomputed rank of 1.0)
+            int b0 = (y0 > -kYR) ? (int)((y0 + kYR) * yscale) : 0, b1 = (y1 > -kYR) ? (int)((y1 + kYR) * yscale) : 0;
+            b0 = (b0 < nb && y0 < kYR) ? b0 : nb - 1;
+            b1 = (b1 < nb && y1 < kYR) ? b1 : nb - 1;
             int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
             while (l0 < h0 || l1 < h1) {
                 const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;  // < m whenever that side is live
-                const bool g0 = skey[m0] < x0, g1 = skey[m1] < x1;
+                const bool g0 = skey[m0] <= y0, g1 = skey[m1] <= y1;
                 if (l0 < h0) {
                     l0 = g0 ? m0 + 1 : l0;
                     h0 = g0 ? h0 : m0;
@@ -1244,8 +1317,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                     h1 = g1 ? h1 : m1;
                 }
             }
-            atomicAdd(isnan(x0) ? &misc[0] : &hist[l0], 1);
-            if (two) atomicAdd(isnan(x1) ? &misc[0] : &hist[l1], 1);
+            l0 = y0 == fptm::kInf ? rank_one : l0;
+            l1 = y1 == fptm::kInf ? rank_one : l1;
+            atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
+            if (two) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
         }
         __syncthreads();
     }
