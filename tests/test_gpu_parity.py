@@ -1067,3 +1067,61 @@ def test_fdr_fuzz(fpt, orc, seed):
                                 base0=base0 + a, return_null=True)
         assert rel_err(nul[a:b], wn) < 1e-9, tag
         assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times), tag
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
+def test_host_api_fuzz(fpt, orc, seed):
+    """the host-buffer entry points one reference call each (predict, the five window reducers,
+    NB values, k-mer lookup) on random shapes and parameters against the oracle."""
+    from footprint_tools_amd.modeling import dispersion, predict
+    from footprint_tools_amd.stats import windowing
+    rs = np.random.RandomState(9000 + seed)
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    # fast_predict on one row and on a matrix of rows
+    l = int(rs.choice([1, 9, 23, 64, 65, 611, 1111, 3000]))
+    hw = int(rs.choice([1, 3, 5, 8]))
+    shw = int(rs.choice([0, 2, 10, 50, 70]))
+    clip = float(rs.choice([0.0, 0.01, 0.05, 0.3]))
+    if shw and 2 * int((2 * shw + 1) * clip) >= 2 * shw + 1:
+        clip = 0.01
+    rows = int(rs.randint(1, 4))
+    obs = rs.poisson(rs.choice([0.1, 2.0, 9.0]), (rows, l)).astype(np.float64)
+    probs = rs.uniform(1e-4, 0.3, (rows, l))
+    e, w = predict.predict(obs, probs, hw, shw, clip)
+    for r in range(rows):
+        e0, w0 = orc.fast_predict(obs[r], probs[r], hw, shw, clip)
+        assert np.array_equal(e[r], e0, equal_nan=True), (l, hw, shw, clip)
+        assert np.allclose(w[r], w0, rtol=1e-12, atol=0, equal_nan=True), (l, hw, shw, clip)
+    # window reducers
+    n = int(rs.choice([1, 5, 8, 64, 200, 1500]))
+    whw = int(rs.choice([0, 1, 3, 10, 40]))
+    x = rs.uniform(0, 1, n) ** float(rs.choice([1, 4]))
+    if n > 4:
+        x[rs.randint(0, n, 2)] = rs.choice([0.0, 1.0, np.nan, 1e-300], 2)
+    wts = rs.uniform(0.1, 2.0, n)
+    for name, fn in (("sum", windowing.sum), ("product", windowing.product),
+                     ("fishers_combined", windowing.fishers_combined), ("stouffers_z", windowing.stouffers_z)):
+        got = fn(np.ascontiguousarray(x), whw)
+        want = orc.window(name, x, whw)
+        assert rel_err(got, want) < P_TOL, (name, n, whw)
+    assert rel_err(windowing.weighted_stouffers_z(x, wts, whw), orc.window("weighted_stouffers_z", x, whw, w=wts)) < P_TOL
+    # NB values of a model
+    key = str(rs.choice(["A", "B", "C"]))
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_" + key], lat["r_" + key]
+    m = int(rs.choice([1, 100, 5000]))
+    ex = np.round(rs.gamma(2.0, rs.choice([1.0, 10.0, 80.0]), m))
+    ob = np.round(rs.gamma(2.0, rs.choice([1.0, 10.0, 80.0]), m))
+    for what, fn in (("cdf", dm.p_values), ("logpmf", dm.log_pmf_values), ("pmf", dm.pmf_values)):
+        assert rel_err(fn(ex, ob), orc.nb_values(what, dm.mu_params, dm.r_params, ex, ob)) < P_TOL, (what, key)
+    # k-mer lookup
+    sq = rs.choice(np.frombuffer(b"ACGTacgtNn-", np.uint8), int(rs.choice([6, 7, 30, 1000]))).tobytes()
+    fwd0, rev0 = orc.kmer_probs(np.frombuffer(sq, np.uint8), table)[:2]
+    ctx = fpt.get_ctx()
+    ctx.set_bias_table(table, 1e-6)
+    s8 = np.frombuffer(sq, np.uint8)
+    nout = max(s8.size - 6, 0)
+    fwd, rev = np.empty(nout), np.empty(nout)
+    fpt.check(ctx.L.fpt_kmer_probs(ctx.h, fpt.ptr(np.ascontiguousarray(s8)), s8.size, fpt.ptr(fwd), fpt.ptr(rev)))
+    assert np.array_equal(fwd, fwd0) and np.array_equal(rev, rev0)
