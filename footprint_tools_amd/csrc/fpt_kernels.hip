@@ -289,6 +289,11 @@ __device__ __forceinline__ double2 nb_pz_direct(double r, double mu, int32_t k) 
     return make_double2(pv, z);
 }
 
+// z of a table row whose dispersion fit divides by zero (dispersion.pyx:160-161): a quiet NaN
+// with a payload, so that a lookup learns about the ZeroDivisionError from the entry itself
+// instead of re-evaluating the five-segment fit per base (p of such a row is NaN as before)
+constexpr long long kZeroDivZBits = 0x7ff800005a440000ll;
+
 // (p, z) for every integer pair (exp, obs) of the table: the same device functions the
 // direct path calls, so a lookup returns bit-identical values.
 __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ models, int memo_exp,
@@ -308,6 +313,7 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
         double mu = fptm::fit_mu(par, ex);
         double pv = fptm::nb_cdf(k, r / (r + mu), r);
         double z = fptm::ndtri(1.0 - pv);
+        if (zd) z = __longlong_as_double(kZeroDivZBits);
         memo[idx] = make_double2(pv, z);
     }
 }
@@ -807,7 +813,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
             const double2 pz = memo[ei * a.memo_obs + k];
             pv = pz.x;
             z = pz.y;
-            zd = fptm::piecewise<5>(par + 9, ex) == 0.0;  // dispersion.pyx:160-161
+            zd = __double_as_longlong(z) == kZeroDivZBits;
         } else if (MO) {
             pv = z = NAN;
             a.redo[tile] = 1;  // the full instance recomputes this tile
