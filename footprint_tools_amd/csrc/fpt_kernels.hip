@@ -686,8 +686,9 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         } else {
             kmer_indices(sq + v, fi, ri);
         }
-        pP[v] = tbl[fi];
-        pM[v] = tbl[ri];
+        // the two table gathers are issued first and stored last, so the window sums below run
+        // while they are in flight
+        const double tf = tbl[fi], tr = tbl[ri];
         double sp = 0.0, sm = 0.0;
         if (v >= hw && v < nc - hw) {
             for (int j = -hw; j < hw; ++j) {
@@ -701,6 +702,8 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // window of w values (and a 64-position tile prefix) stays below 2^30
         small_int &= (int)(sp >= 0.0) & (int)(sm >= 0.0) & (int)(sp <= int_lim) & (int)(sm <= int_lim) &
                      (int)((double)(int)sp == sp) & (int)((double)(int)sm == sm);
+        pP[v] = tf;
+        pM[v] = tr;
     }
     const bool all_small_int = __syncthreads_and(small_int) != 0;
     if (ABL(64)) return;
