@@ -662,11 +662,34 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         }
         for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)((v * 5 + (int)tile) & 3);
     } else {
-        for (int v = tid; v < nc; v += NT) {
+        // all loads of a lane are issued before the first one is consumed: a lane that owns two or
+        // three staged positions pays the HBM latency once, not once per position
+        constexpr int kStage = 3;
+        double ldp[kStage], ldm[kStage];
+        uint8_t lds_[kStage];
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int v = tid + i * NT;
+            if (v < nc) {
+                ldp[i] = a.counts_plus[cbase + v];
+                ldm[i] = a.counts_minus[cbase + v];
+            }
+            if (v < nc + 6) lds_[i] = a.seq[sbase + v];
+        }
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int v = tid + i * NT;
+            if (v < nc) {
+                cP[v] = ldp[i];
+                cM[v] = ldm[i];
+            }
+            if (v < nc + 6) sq[v] = (uint8_t)base_code(lds_[i]);
+        }
+        for (int v = tid + kStage * NT; v < nc; v += NT) {  // very wide padding only
             cP[v] = a.counts_plus[cbase + v];
             cM[v] = a.counts_minus[cbase + v];
         }
-        for (int v = tid; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
+        for (int v = tid + kStage * NT; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
     }
     __syncthreads();
     if (ABL(32)) return;
