@@ -701,16 +701,47 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     if (tid < nt) ob = cP[pad + 1 + tid] + cM[pad + tid];
     int small_int = 1;
     const double int_lim = fmin(16777216.0, 1073741824.0 / (double)(2 * shw + 65));
-    for (int v = tid; v < nc; v += NT) {
-        int fi, ri;
-        if (ABL(8)) {
-            fi = v & 4095;
-            ri = (v * 7) & 4095;
-        } else {
-            kmer_indices(sq + v, fi, ri);
+    // The two table gathers of every staged position of a lane are issued first and stored last,
+    // so the window sums run while they are in flight (a lane owns up to kStageB positions in
+    // the common geometries; more only with very wide padding).
+    constexpr int kStageB = 3;
+    double tfs[kStageB], trs[kStageB];
+#pragma unroll
+    for (int i = 0; i < kStageB; ++i) {
+        const int v = tid + i * NT;
+        if (v < nc) {
+            int fi, ri;
+            if (ABL(8)) {
+                fi = v & 4095;
+                ri = (v * 7) & 4095;
+            } else {
+                kmer_indices(sq + v, fi, ri);
+            }
+            tfs[i] = tbl[fi];
+            trs[i] = tbl[ri];
         }
-        // the two table gathers are issued first and stored last, so the window sums below run
-        // while they are in flight
+    }
+#pragma unroll
+    for (int i = 0; i < kStageB; ++i) {
+        const int v = tid + i * NT;
+        if (v >= nc) break;
+        double sp = 0.0, sm = 0.0;
+        if (v >= hw && v < nc - hw) {
+            for (int j = -hw; j < hw; ++j) {
+                sp += cP[v + j];
+                sm += cM[v + j];
+            }
+        }
+        wP[v] = sp;
+        wM[v] = sm;
+        small_int &= (int)(sp >= 0.0) & (int)(sm >= 0.0) & (int)(sp <= int_lim) & (int)(sm <= int_lim) &
+                     (int)((double)(int)sp == sp) & (int)((double)(int)sm == sm);
+        pP[v] = tfs[i];
+        pM[v] = trs[i];
+    }
+    for (int v = tid + kStageB * NT; v < nc; v += NT) {
+        int fi, ri;
+        kmer_indices(sq + v, fi, ri);
         const double tf = tbl[fi], tr = tbl[ri];
         double sp = 0.0, sm = 0.0;
         if (v >= hw && v < nc - hw) {
