@@ -1047,13 +1047,19 @@ __device__ __forceinline__ double2 nb_inverse_cdf_direct(const double *par, doub
 // first probe interpolates between them, and the walk from there (up while cdf < u, down while
 // the entry below is still >= u) is a step or two.  Every probe after the first falls into the
 // cache line of the first; both draws run interleaved so their gathers overlap.
-__device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_exp, int memo_obs,
-                                           const double *par, double ex, double u0, double u1, double &z0,
-                                           double &z1) {
+// ei: table row of the position's expected value, or -1 when it is not an integer inside the
+// table (then *exp_ptr is read and the draw is evaluated directly).
+__device__ __forceinline__ int table_row_of(double ex, int memo_exp) {
     const int ei = (int)ex;
+    return (ex >= 0.0 && ex < (double)memo_exp && (double)ei == ex) ? ei : -1;
+}
+
+__device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_obs,
+                                           const double *par, int ei, const double *exp_ptr, double u0, double u1,
+                                           double &z0, double &z1) {
     int lo0 = -1, lo1 = -1;
     bool d0 = true, d1 = true;  // still to be evaluated directly
-    if (ex >= 0.0 && ex < (double)memo_exp && (double)ei == ex) {
+    if (ei >= 0) {
         const double2 *row = memo + (size_t)ei * memo_obs;
         const uint16_t *gr = guide + (size_t)ei * (kGuide + 1);
         const int kl = memo_obs - 1;
@@ -1103,6 +1109,7 @@ __device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *
         lo0 = lo1 = kl;
     }
     if (d0 || d1) {  // rare: beyond the table or a non-integer expected value
+        const double ex = ei >= 0 ? (double)ei : *exp_ptr;
 #pragma clang loop unroll(disable)
         for (int j = 0; j < 2; ++j) {
             if (j ? d1 : d0) {
@@ -1288,6 +1295,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     // three prefix scans plus three tile-range sums, and a non-finite z shows up as a non-finite
     // sum, so no separate count is needed.  Wider windows take the prefix-scan path.
     const bool direct = hs <= 8;
+    if (direct) {
+        for (int t = tid; t < L; t += NT) nf[t] = table_row_of(a.exp[off + t], a.memo_exp);
+        // (each lane reads back only the entries it wrote: no barrier needed)
+    }
     for (int s = 0; s < a.times; s += 2) {
         const bool two = s + 1 < a.times;
         for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
@@ -1309,7 +1320,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                     z0 = u0 - 0.5;
                     z1 = u1 - 0.5;
                 } else {
-                    nb_draw_z2(memo, guide, a.memo_exp, a.memo_obs, par, a.exp[off + t], u0, u1, z0, z1);
+                    // the table row of a position does not change from pass to pass: with direct
+                    // windows `nf` is free and holds it (filled below, before the first pass)
+                    const int ei = direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp);
+                    nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, u0, u1, z0, z1);
                 }
                 if (!direct) {
                     const bool f0 = isfinite(z0), f1 = isfinite(z1);
