@@ -18,6 +18,9 @@
  *   - all floating-point data is float64, C-contiguous, like the reference's
  *     typed memoryviews; lengths that the reference types as C int stay int.
  *   - there is no CPU fallback: without a HIP device fpt_ctx_create fails.
+ *   - a context owns its device tables, a workspace and a stream binding: calls on ONE context
+ *     must not overlap (serialise them, as the Python layer does with a lock); different
+ *     contexts -- one per GPU, or several on one GPU -- are independent.
  */
 #ifndef FPT_H
 #define FPT_H
