@@ -49,6 +49,14 @@ def test_scan_desc_layout_matches_header(lib, tmp_path):
     size, o_seed, o_exp, o_nu = map(int, subprocess.check_output([str(exe)]).split())
     F = lib.FdrDesc
     assert (C.sizeof(F), F.seed.offset, F.exp.offset, F.null_uniform.offset) == (size, o_seed, o_exp, o_nu)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fpt.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   'offsetof(fpt_fdr_desc, null_winp_out), sizeof(fpt_segment_desc), offsetof(fpt_segment_desc, track),'
+                   'offsetof(fpt_segment_desc, threshold), offsetof(fpt_segment_desc, decreasing));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    o_nw, size, o_tr, o_th, o_dec = map(int, subprocess.check_output([str(exe)]).split())
+    S = lib.SegmentDesc
+    assert F.null_winp_out.offset == o_nw
+    assert (C.sizeof(S), S.track.offset, S.threshold.offset, S.decreasing.offset) == (size, o_tr, o_th, o_dec)
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device failure path")
