@@ -449,133 +449,95 @@ __device__ __forceinline__ void smooth_expected_fast(const double *wP, const dou
     }
 }
 
-// int32 variant of smooth_expected_fast with the barrier count cut from 7 to 4: all four
-// extrema scans of a strand are int32 and fit in two of the four scratch buffers, so the scans
-// of one strand can be written while the previous stage's results are still being read.
-// Expected counts come out in xA ('+') and xB ('-').
+// Integer smoothing with ONE barrier inside: every scan of both strands (prefix sums of W,
+// packed change counts, prefix / suffix minima and maxima) is published at once -- the extrema as
+// uint16, which is what makes them fit next to the prefix sums in the four scratch arrays and
+// limits this path to window sums <= 65535 -- and after the barrier each lane combines the two
+// windows of ITS OWN output base (strand '+' at padded position pad+1+t, strand '-' at pad+t,
+// detect.py:121-122), so the expected counts never go through LDS.
+// Returns E+ and E- of output base tid (tid < nt).
 template <int NT>
-__device__ __forceinline__ void smooth_expected_int(const double *wP, const double *wM, const double *pP,
-                                                    const double *pM, double *cP, double *cM, double *xA,
-                                                    double *xB, int nc, int ncr, int nc_max, int pad,
-                                                    int hw, int shw, bool skip_trim) {
-    constexpr int MAXI = 3;
+__device__ __forceinline__ void smooth_expected_fused(const double *wP, const double *wM, const double *pP,
+                                                      const double *pM, double *cP, double *cM, double *xA,
+                                                      double *xB, int nc, int ncr, int nc_max, int nt, int pad,
+                                                      int hw, int shw, bool skip_trim, double &e_plus,
+                                                      double &e_minus) {
+    typedef unsigned short u16;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int w = 2 * shw + 1;
     const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
-    const int ni = (ncr + NT - 1) / NT;
-    const bool le3 = shw <= 64;  // windows of at most 129 positions span at most three tiles
-    // stage 1 buffers (in cP / cM): prefix sums and change counts of both strands
     int *psP = reinterpret_cast<int *>(cP), *psM = psP + nc_max;
-    int *chB = reinterpret_cast<int *>(cM);  // change counts of both strands, 16 bits each
-    double winS[2][MAXI];
-    int winC[2][MAXI];
-    double eOut[2][MAXI];
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-        const int v = i * NT + tid;
-        if (i < ni && v < ncr) {
-            int v0 = 0, v1 = 0, c0 = 0, c1 = 0;
-            if (v < nc) {
-                const double d0 = wP[v], d1 = wM[v];
-                v0 = (int)d0;
-                v1 = (int)d1;
-                if (v + 1 < nc) {
-                    c0 = wP[v + 1] != d0;
-                    c1 = wM[v + 1] != d1;
-                }
+    int *chB = reinterpret_cast<int *>(cM);
+    u16 *mnP = reinterpret_cast<u16 *>(chB + nc_max), *mnPs = mnP + nc_max;   // prefix / suffix min '+'
+    u16 *mxP = reinterpret_cast<u16 *>(xA), *mxPs = mxP + nc_max;             // prefix / suffix max '+'
+    u16 *mnM = mxPs + nc_max, *mnMs = mnM + nc_max;
+    u16 *mxM = reinterpret_cast<u16 *>(xB), *mxMs = mxM + nc_max;
+    for (int v = tid; v < ncr; v += NT) {  // whole 64-position tiles: wave-uniform
+        const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
+        const bool okf = v < nc, okr = vr < nc;
+        int f0 = 0, f1 = 0, c0 = 0, c1 = 0;
+        if (okf) {
+            const double d0 = wP[v], d1 = wM[v];
+            f0 = (int)d0;
+            f1 = (int)d1;
+            if (v + 1 < nc) {
+                c0 = wP[v + 1] != d0;
+                c1 = wM[v + 1] != d1;
             }
-            psP[v] = scan_add(v0);
-            psM[v] = scan_add(v1);
-            chB[v] = scan_add(c0 | (c1 << 16));
         }
+        const int r0 = okr ? (int)wP[vr] : 0, r1 = okr ? (int)wM[vr] : 0;
+        psP[v] = scan_add(f0);
+        psM[v] = scan_add(f1);
+        chB[v] = scan_add(c0 | (c1 << 16));
+        mnP[v] = (u16)scan_min_nonneg(f0, okf);
+        mxP[v] = (u16)scan_max_nonneg(f0, okf);
+        mnM[v] = (u16)scan_min_nonneg(f1, okf);
+        mxM[v] = (u16)scan_max_nonneg(f1, okf);
+        // positions beyond the data scan as "no value": min = kNonnegTop there, never read back
+        mnPs[vr] = (u16)scan_min_nonneg(r0, okr);
+        mxPs[vr] = (u16)scan_max_nonneg(r0, okr);
+        mnMs[vr] = (u16)scan_min_nonneg(r1, okr);
+        mxMs[vr] = (u16)scan_max_nonneg(r1, okr);
     }
-    __syncthreads();  // (1)
+    __syncthreads();
+    e_plus = e_minus = 0.0;
+    if (tid >= nt) return;
+    const bool le3 = shw <= 64;
+    auto range_min = [&](const u16 *p, const u16 *s, int lo, int hi) {  // spans >= 2 tiles (w > 64)
+        int m = min((int)s[lo], (int)p[hi]);
+        for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = min(m, (int)p[(q << 6) + 63]);
+        return m;
+    };
+    auto range_max = [&](const u16 *p, const u16 *s, int lo, int hi) {
+        int m = max((int)s[lo], (int)p[hi]);
+        for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = max(m, (int)p[(q << 6) + 63]);
+        return m;
+    };
 #pragma unroll
     for (int strand = 0; strand < 2; ++strand) {
-        const double *ws = strand ? wM : wP;
-        // extrema buffers: strand 0 -> xA / xB, strand 1 -> cP / cM (stage 1 is consumed by then)
-        int *pmn = reinterpret_cast<int *>(strand ? cP : xA), *smn = pmn + nc_max;
-        int *pmx = reinterpret_cast<int *>(strand ? cM : xB), *smx = pmx + nc_max;
-        if (strand == 0) {
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const int v = i * NT + tid;
-                winS[0][i] = winS[1][i] = 0.0;
-                winC[0][i] = winC[1][i] = 0;
-                if (i < ni && v >= pad && v < nc - pad) {
-                    const int lo = v - shw, hi = v + shw;
-                    winS[0][i] = (double)(le3 ? tile_range_sum3(psP, lo, hi) : tile_range_sum(psP, lo, hi));
-                    winS[1][i] = (double)(le3 ? tile_range_sum3(psM, lo, hi) : tile_range_sum(psM, lo, hi));
-                    const int wc = le3 ? tile_range_sum3(chB, lo, hi - 1) : tile_range_sum(chB, lo, hi - 1);
-                    winC[0][i] = wc & 0xffff;
-                    winC[1][i] = wc >> 16;
-                }
-            }
+#pragma clang fp contract(off)
+        const int v = pad + tid + (strand ? 0 : 1);
+        const double *ws = strand ? wM : wP, *pr = strand ? pM : pP;
+        const int lo = v - shw, hi = v + shw;
+        const int S = le3 ? tile_range_sum3(strand ? psM : psP, lo, hi) : tile_range_sum(strand ? psM : psP, lo, hi);
+        const int wc = le3 ? tile_range_sum3(chB, lo, hi - 1) : tile_range_sum(chB, lo, hi - 1);
+        const int nchg = strand ? (wc >> 16) : (wc & 0xffff);
+        double t;
+        if (nchg > 4) {
+            const int mn = range_min(strand ? mnM : mnP, strand ? mnMs : mnPs, lo, hi);
+            const int mx = range_max(strand ? mxM : mxP, strand ? mxMs : mxPs, lo, hi);
+            t = ((double)S - (double)mn) - (double)mx;
+        } else if (nchg == 0) {
+            t = (double)(w - 1) * ws[lo];
         } else {
-            // combine strand 0 (its scans were published before barrier 2)
-            const int *qmn = reinterpret_cast<int *>(xA), *rmn = qmn + nc_max;
-            const int *qmx = reinterpret_cast<int *>(xB), *rmx = qmx + nc_max;
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const int v = i * NT + tid;
-                eOut[0][i] = 0.0;
-                if (i < ni && v >= pad && v < nc - pad) {
-#pragma clang fp contract(off)
-                    const int lo = v - shw, hi = v + shw;
-                    double t;
-                    const int nchg = winC[0][i];
-                    if (nchg > 4) t = (winS[0][i] - (double)(le3 ? tile_range_min3(qmn, rmn, lo, hi) : tile_range_min(qmn, rmn, lo, hi))) -
-                                      (double)(le3 ? tile_range_max3(qmx, rmx, lo, hi) : tile_range_max(qmx, rmx, lo, hi));
-                    else if (nchg == 0) t = (double)(w - 1) * wP[lo];
-                    else t = trimmed_sum_k1(wP + lo, w);
-                    const double wsm = skip_trim ? wP[v] : div_invariant(t, w_div, w_rdiv);
-                    double q = 0.0;
-                    for (int j = -hw; j < hw; ++j) q += pP[v + j];
-                    eOut[0][i] = round((pP[v] / q) * wsm);
-                }
-            }
+            t = trimmed_sum_k1(ws + lo, w);
         }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int v = i * NT + tid;
-            if (i < ni && v < ncr) {
-                const int vr = (v & ~(kWave - 1)) + (kWave - 1 - lane);
-                const bool okf = v < nc, okr = vr < nc;
-                const int xf = okf ? (int)ws[v] : 0;
-                const int xr = okr ? (int)ws[vr] : 0;
-                pmn[v] = scan_min_nonneg(xf, okf);
-                pmx[v] = scan_max_nonneg(xf, okf);
-                smn[vr] = scan_min_nonneg(xr, okr);
-                smx[vr] = scan_max_nonneg(xr, okr);
-            }
-        }
-        __syncthreads();  // (2), (3)
-    }
-    {
-        // combine strand 1 (scans in cP / cM), then publish both strands' expected counts in
-        // xA / xB, whose strand-0 scans nobody reads any more
-        const int *qmn = reinterpret_cast<int *>(cP), *rmn = qmn + nc_max;
-        const int *qmx = reinterpret_cast<int *>(cM), *rmx = qmx + nc_max;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int v = i * NT + tid;
-            if (i < ni && v >= pad && v < nc - pad) {
-#pragma clang fp contract(off)
-                const int lo = v - shw, hi = v + shw;
-                double t;
-                const int nchg = winC[1][i];
-                if (nchg > 4) t = (winS[1][i] - (double)(le3 ? tile_range_min3(qmn, rmn, lo, hi) : tile_range_min(qmn, rmn, lo, hi))) -
-                                  (double)(le3 ? tile_range_max3(qmx, rmx, lo, hi) : tile_range_max(qmx, rmx, lo, hi));
-                else if (nchg == 0) t = (double)(w - 1) * wM[lo];
-                else t = trimmed_sum_k1(wM + lo, w);
-                const double wsm = skip_trim ? wM[v] : div_invariant(t, w_div, w_rdiv);
-                double q = 0.0;
-                for (int j = -hw; j < hw; ++j) q += pM[v + j];
-                xA[v] = eOut[0][i];
-                xB[v] = round((pM[v] / q) * wsm);
-            }
-        }
+        const double wsm = skip_trim ? ws[v] : div_invariant(t, w_div, w_rdiv);
+        double q = 0.0;
+        for (int j = -hw; j < hw; ++j) q += pr[v + j];
+        const double e = round((pr[v] / q) * wsm);
+        if (strand) e_minus = e; else e_plus = e;
     }
 }
 
@@ -700,7 +662,7 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     double ob = 0.0;
     if (tid < nt) ob = cP[pad + 1 + tid] + cM[pad + tid];
     int small_int = 1;
-    const double int_lim = fmin(16777216.0, 1073741824.0 / (double)(2 * shw + 65));
+    const double int_lim = 65535.0;  // what smooth_expected_fused stores its extrema in
     // The two table gathers of every staged position of a lane are issued first and stored last,
     // so the window sums run while they are in flight (a lane owns up to kStageB positions in
     // the common geometries; more only with very wide padding).
@@ -764,11 +726,13 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
 
     // ---- C: smoothing (smoothing.h:107-133) + expected counts (predict.h:60-63);
     //         E overwrites the counts, which nobody reads any more
+    double ex_plus = 0.0, ex_minus = 0.0;  // the integer path hands E of the lane's base over in registers
     if (a.fast_trim) {
         // T = int when the whole tile's window sums are small integers (decided block-wide at the
         // barrier that ends phase B), else double
         if (all_small_int)
-            smooth_expected_int<NT>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
+            smooth_expected_fused<NT>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, nt, pad, hw, shw, ABL(1),
+                                      ex_plus, ex_minus);
         else
             smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
     } else {
@@ -793,13 +757,13 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     int *nf = reinterpret_cast<int *>(wM);
     double zv = 0.0;
     int zc = 0;
-    // expected counts: the int32 smoothing path leaves them in xA / xB, the others in cP / cM
-    const bool e_in_x = a.fast_trim && all_small_int;
-    const double *eP = e_in_x ? xA : cP, *eM = e_in_x ? xB : cM;
-    double *fA = e_in_x ? cP : xA, *fB = e_in_x ? cM : xB;  // the pair that is free now
+    // expected counts: the integer smoothing path keeps them in registers, the others in cP / cM
+    const bool e_in_reg = a.fast_trim && all_small_int;
+    const double *eP = cP, *eM = cM;
+    double *fA = xA, *fB = xB;  // scratch for the direct mode's lane regrouping
     double ex = 0.0, pv = 0.0, z = 0.0;
     bool zd = false;
-    if (tid < nt) ex = eP[pad + 1 + tid] + eM[pad + tid];
+    if (tid < nt) ex = e_in_reg ? ex_plus + ex_minus : eP[pad + 1 + tid] + eM[pad + tid];
     if (!MO && a.counts_only) {  // expected / observed tracks only (learn_dm)
         const int t = ta + tid;
         if (tid < nt && t >= t0 && t < t0 + tl) {
