@@ -946,6 +946,7 @@ struct fdr_args {
     int32_t ablate;      // timing-only diagnostics (FPT_ABLATE builds)
     int32_t n2_max;      // buffer capacity: power of two >= longest interval of the launch
     double inv_sqrt_k;
+    int32_t dbuf;            // a second pair of z buffers follows zb1: one barrier per pass instead of two
     const int32_t *iv_list;  // interval of workgroup b is iv_list[b], or iv_first + b when null
     int64_t iv_first;
     char *gws;               // GWS instances: per-workgroup buffers in global memory
@@ -1145,7 +1146,8 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
     double *zb = skey + n2;                          // n2 tile prefix sums of z, even sample
     double *zb1 = zb + n2;                           // n2 same for the odd sample of the pair
-    int *sidx = reinterpret_cast<int *>(zb1 + n2);   // n2 original positions
+    double *zalt = zb1 + n2;                         // 2 * n2 more when a.dbuf (passes alternate buffers)
+    int *sidx = reinterpret_cast<int *>(zalt + (a.dbuf ? 2 * n2 : 0));  // n2 original positions
     int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
     int *hist = nf + n2;                             // n2 + 2 histogram / prefix
     int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
@@ -1263,8 +1265,17 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         for (int t = tid; t < L; t += NT) nf[t] = table_row_of(a.exp[off + t], a.memo_exp);
         // (each lane reads back only the entries it wrote: no barrier needed)
     }
+    // With two pairs of z buffers a pass writes one pair while slower wavefronts may still be
+    // reading the other, so the barrier at the end of a pass is not needed (direct windows only).
+    const bool alternate = a.dbuf && direct;
+    double *const zb_even = zb, *const zb1_even = zb1;
     for (int s = 0; s < a.times; s += 2) {
         const bool two = s + 1 < a.times;
+        if (alternate) {
+            const bool odd_pass = (s >> 1) & 1;
+            zb = odd_pass ? zalt : zb_even;
+            zb1 = odd_pass ? zalt + n2 : zb1_even;
+        }
         for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
             double z0 = 0.0, z1 = 0.0;
             int zc = 0;
@@ -1363,8 +1374,9 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
             if (two) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
         }
-        __syncthreads();
+        if (!alternate) __syncthreads();
     }
+    __syncthreads();
 
     // ---- 3. counts: inclusive prefix of the histogram (one wavefront, carried over chunks)
     if (tid < kWave) {
@@ -1724,8 +1736,9 @@ size_t nb_guide_bytes(int n_models, int memo_exp) {
     return (size_t)n_models * memo_exp * (kGuide + 1) * sizeof(uint16_t);
 }
 
-size_t fdr_lds_bytes(int n2) {
-    return (size_t)(24 + 3 * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
+size_t fdr_lds_bytes(int n2, bool dbuf) {
+    return (size_t)(24 + (dbuf ? 5 : 3) * (size_t)n2) * sizeof(double) +
+           (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
 }
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
@@ -1752,6 +1765,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.n2_max = fl.n2_max;
     a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
     a.iv_list = fl.iv_list;
+    a.dbuf = 0;
     a.gws = (char *)fl.gws;
     a.gws_stride = fl.gws_stride;
     const int64_t n_blocks = fl.iv_list ? fl.n_list : fl.n_intervals;
@@ -1765,7 +1779,9 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         }
         return hipSuccess;
     }
-    size_t lds = fdr_lds_bytes(fl.n2_max);
+    // the second pair of z buffers only where four workgroups still fit a CU's LDS
+    a.dbuf = fdr_lds_bytes(fl.n2_max, true) <= 40 * 1024 ? 1 : 0;
+    size_t lds = fdr_lds_bytes(fl.n2_max, a.dbuf != 0);
     hipError_t e = hipFuncSetAttribute((const void *)k_fdr_null<256, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

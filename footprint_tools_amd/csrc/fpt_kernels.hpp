@@ -78,7 +78,7 @@ struct segment_launch {
     double *seg_score;
 };
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
-size_t fdr_lds_bytes(int n2);
+size_t fdr_lds_bytes(int n2, bool dbuf = false);
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide);
 size_t nb_guide_bytes(int n_models, int memo_exp);
 
