@@ -571,7 +571,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             size_t lds = fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)
                 return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
-            HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, lds));
+            HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, !memo_only && d_redo, lds));
             for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
                 int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
                 s2.tile_first = ln.first + done;

@@ -269,6 +269,7 @@ struct scan_args {
     int32_t memo_exp, memo_obs;
     int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
     int32_t counts_only;         // FPT_NB_NONE: stop after the expected counts
+    int64_t tile_end;            // second pass: one past the last tile of the launch
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
     const int32_t *dm_ids;       // per interval: dispersion-model slot relative to `model` (or nullptr)
@@ -336,13 +337,22 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
 // T = int when every window sum of the tile is an integer of magnitude <= 2^24 (cut counts
 // are): the same scans on int32 are exact and cost a third of the instructions; T = double
 // otherwise.  Each thread owns padded positions v = tid + i*NT.
+// threadIdx.x through an empty asm: inside a loop over tiles the optimiser would otherwise hoist
+// every piece of lane-index arithmetic (window bounds, LDS addresses...) out of the loop and
+// keep ~100 registers of it alive across the whole tile body.
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 template <int NT, typename T>
 __device__ __forceinline__ void smooth_expected_fast(const double *wP, const double *wM, const double *pP,
                                                      const double *pM, double *cP, double *cM, double *xA,
                                                      double *xB, int nc, int ncr, int nc_max, int pad,
-                                                     int hw, int shw, bool skip_trim) {
+                                                     int hw, int shw, bool skip_trim, int tid_in) {
     constexpr int MAXI = 3;
-    const int tid = threadIdx.x;
+    const int tid = tid_in;
     const int lane = tid & (kWave - 1);
     const int w = 2 * shw + 1;
     const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
@@ -461,9 +471,9 @@ __device__ __forceinline__ void smooth_expected_fused(const double *wP, const do
                                                       const double *pM, double *cP, double *cM, double *xA,
                                                       double *xB, int nc, int ncr, int nc_max, int nt, int pad,
                                                       int hw, int shw, bool skip_trim, double &e_plus,
-                                                      double &e_minus) {
+                                                      double &e_minus, int tid_in) {
     typedef unsigned short u16;
-    const int tid = threadIdx.x;
+    const int tid = tid_in;
     const int lane = tid & (kWave - 1);
     const int w = 2 * shw + 1;
     const double w_div = (double)(w - 2), w_rdiv = 1.0 / w_div;
@@ -549,10 +559,11 @@ __device__ __forceinline__ void smooth_expected_fused(const double *wP, const do
 // in `redo` and computed again by the full instance, launched right behind on the same stream
 // over the same tiles with an early exit for unflagged ones.
 #define FPT_SCAN_WAVES(NT, TBLG, MO) ((MO) ? 8 : (((TBLG) && (NT) < 1024) ? 6 : 4))
-template <int NT, int HWC, int SHWC, bool TBLG, bool MO>
-__global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused(const scan_args a) {
+typedef const __attribute__((address_space(4))) scan_args kernarg_scan_args;
+// LOOPED: the caller runs the body inside a loop over tiles (see opaque_tid)
+template <int NT, int HWC, int SHWC, bool TBLG, bool MO, bool LOOPED, typename Args>
+__device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     extern __shared__ double smem[];
-    if (!MO && a.redo && a.redo[a.tile_first + blockIdx.x] == 0) return;  // second pass: flagged tiles only
     const double *tbl = TBLG ? a.table : smem;  // kTable + 1 (+1 pad to keep 16-B alignment)
     double *par_lds = smem + (TBLG ? 0 : (kTable + 2));  // 24 (unused when MO)
     double *cP = par_lds + (MO ? 0 : 24);     // counts '+', scratch in C, expected '+' for D
@@ -566,12 +577,11 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     // sequence codes: nc_max + 8 bytes; with MO they share xB (first written in phase C)
     uint8_t *sq = reinterpret_cast<uint8_t *>(MO ? xB : xB + a.nc_max);
 
-    const int tid = threadIdx.x;
+    const int tid = LOOPED ? opaque_tid() : (int)threadIdx.x;
     const int lane = tid & (kWave - 1);
 
     const int hw = HWC ? HWC : a.hw, shw = SHWC ? SHWC : a.shw, pad = hw + shw;
     const int H = a.max_scale;
-    const int64_t tile = a.tile_first + blockIdx.x;
 
     int64_t iv;
     int t0, L, tl;
@@ -732,9 +742,9 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // barrier that ends phase B), else double
         if (all_small_int)
             smooth_expected_fused<NT>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, nt, pad, hw, shw, ABL(1),
-                                      ex_plus, ex_minus);
+                                      ex_plus, ex_minus, tid);
         else
-            smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1));
+            smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1), tid);
     } else {
         const int ne = nt + 1;  // padded positions [pad, nc-pad) per strand
         for (int idx = tid; idx < 2 * ne; idx += NT) {
@@ -909,11 +919,37 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
     }
 }
 
+// One tile per workgroup, except in the second pass of memo mode (REDO: the full instance over the
+// tiles the memo-only pass flagged): there a workgroup walks kRedoGroup consecutive tiles and
+// processes the flagged ones, so a pass in which nothing is flagged costs 1/kRedoGroup of the
+// workgroup launches instead of one early exit per tile.
+constexpr int kRedoGroup = 16;
+template <int NT, int HWC, int SHWC, bool TBLG, bool MO, bool REDO>
+__global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused(const scan_args a) {
+    if constexpr (!REDO) {
+        scan_tile<NT, HWC, SHWC, TBLG, MO, false>(a, a.tile_first + blockIdx.x);
+    } else {
+        // the arguments through a reference into the kernarg segment (constant address space:
+        // scalar loads) whose pointer is re-laundered every iteration, so that the argument loads
+        // are not hoisted out of the loop either
+        kernarg_scan_args *ap = (kernarg_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int i = 0; i < kRedoGroup; ++i) {
+            asm volatile("" : "+s"(ap));  // argument loads stay inside the iteration that needs them
+            const int64_t tile = ap->tile_first + (int64_t)blockIdx.x * kRedoGroup + i;
+            if (tile >= ap->tile_end) break;
+            if (ap->redo[tile] == 0) continue;
+            __syncthreads();  // a previous tile of this workgroup is done with LDS
+            scan_tile<NT, HWC, SHWC, TBLG, false, true>(*ap, tile);
+        }
+    }
+}
+
 #define FPT_SCAN_INSTANCES(X) X(256, 0, 0) X(512, 0, 0) X(1024, 0, 0) X(256, 5, 50) X(512, 5, 50) X(1024, 5, 50)
-#define FPT_INST(NT, H_, S_)                                                         \
-    template __global__ void k_scan_fused<NT, H_, S_, false, false>(const scan_args); \
-    template __global__ void k_scan_fused<NT, H_, S_, true, false>(const scan_args);  \
-    template __global__ void k_scan_fused<NT, H_, S_, true, true>(const scan_args);
+#define FPT_INST(NT, H_, S_)                                                                \
+    template __global__ void k_scan_fused<NT, H_, S_, false, false, false>(const scan_args); \
+    template __global__ void k_scan_fused<NT, H_, S_, true, false, false>(const scan_args);  \
+    template __global__ void k_scan_fused<NT, H_, S_, true, true, false>(const scan_args);   \
+    template __global__ void k_scan_fused<NT, H_, S_, true, false, true>(const scan_args);
 FPT_SCAN_INSTANCES(FPT_INST)
 #undef FPT_INST
 
@@ -1652,23 +1688,25 @@ size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only) {
 
 typedef void (*scan_kernel_t)(const scan_args);
 
-template <bool TBLG, bool MO>
+template <bool TBLG, bool MO, bool REDO>
 static scan_kernel_t scan_kernel_t_(int nt, bool dflt) {
     switch (nt) {
-    case 256: return dflt ? k_scan_fused<256, 5, 50, TBLG, MO> : k_scan_fused<256, 0, 0, TBLG, MO>;
-    case 512: return dflt ? k_scan_fused<512, 5, 50, TBLG, MO> : k_scan_fused<512, 0, 0, TBLG, MO>;
-    default: return dflt ? k_scan_fused<1024, 5, 50, TBLG, MO> : k_scan_fused<1024, 0, 0, TBLG, MO>;
+    case 256: return dflt ? k_scan_fused<256, 5, 50, TBLG, MO, REDO> : k_scan_fused<256, 0, 0, TBLG, MO, REDO>;
+    case 512: return dflt ? k_scan_fused<512, 5, 50, TBLG, MO, REDO> : k_scan_fused<512, 0, 0, TBLG, MO, REDO>;
+    default: return dflt ? k_scan_fused<1024, 5, 50, TBLG, MO, REDO> : k_scan_fused<1024, 0, 0, TBLG, MO, REDO>;
     }
 }
 
-static scan_kernel_t scan_kernel(int nt, int hw, int shw, bool tblg, bool memo_only) {
+// second_pass: the full instance over the tiles flagged by the memo-only pass (table through L2 only)
+static scan_kernel_t scan_kernel(int nt, int hw, int shw, bool tblg, bool memo_only, bool second_pass) {
     const bool dflt = (hw == 5 && shw == 50);
-    if (memo_only) return scan_kernel_t_<true, true>(nt, dflt);
-    return tblg ? scan_kernel_t_<true, false>(nt, dflt) : scan_kernel_t_<false, false>(nt, dflt);
+    if (memo_only) return scan_kernel_t_<true, true, false>(nt, dflt);
+    if (second_pass) return scan_kernel_t_<true, false, true>(nt, dflt);
+    return tblg ? scan_kernel_t_<true, false, false>(nt, dflt) : scan_kernel_t_<false, false, false>(nt, dflt);
 }
 
-hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds) {
-    return hipFuncSetAttribute((const void *)scan_kernel(nt, hw, shw, tblg, memo_only),
+hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, bool second_pass, size_t lds) {
+    return hipFuncSetAttribute((const void *)scan_kernel(nt, hw, shw, tblg, memo_only, second_pass),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -1717,7 +1755,11 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.redo = sl.redo;
     a.dm_ids = sl.dm_ids;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
-    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only), dim3(grid), dim3(nt), lds, st, a);
+    a.tile_end = sl.tile_first + (int64_t)grid;
+    const bool second_pass = sl.redo && !memo_only;
+    if (second_pass) grid = (grid + kRedoGroup - 1) / kRedoGroup;  // see k_scan_fused
+    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only, second_pass), dim3(grid),
+                       dim3(nt), lds, st, a);
 }
 
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs,

@@ -95,7 +95,7 @@ void launch_special(hipStream_t st, int fn, const double *a, const double *b, co
 void launch_window_rows(hipStream_t st, int op, const double *x, const double *w, int64_t n_rows,
                         int n, int hw, double *out);
 size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
-hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, size_t lds);
+hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, bool second_pass, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo);
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
