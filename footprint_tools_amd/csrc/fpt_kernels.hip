@@ -933,13 +933,20 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // scalar loads) whose pointer is re-laundered every iteration, so that the argument loads
         // are not hoisted out of the loop either
         kernarg_scan_args *ap = (kernarg_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
-        for (int i = 0; i < kRedoGroup; ++i) {
+        // the group's flags first (independent scalar loads, one wait), then only the flagged tiles
+        const int64_t first = ap->tile_first + (int64_t)blockIdx.x * kRedoGroup;
+        const int32_t *flags = ap->redo + first;
+        const int64_t left = ap->tile_end - first;
+        unsigned todo = 0;
+#pragma unroll
+        for (int i = 0; i < kRedoGroup; ++i)
+            if (i < left && flags[i] != 0) todo |= 1u << i;
+        while (todo) {
+            const int i = __builtin_ctz(todo);
+            todo &= todo - 1;
             asm volatile("" : "+s"(ap));  // argument loads stay inside the iteration that needs them
-            const int64_t tile = ap->tile_first + (int64_t)blockIdx.x * kRedoGroup + i;
-            if (tile >= ap->tile_end) break;
-            if (ap->redo[tile] == 0) continue;
-            __syncthreads();  // a previous tile of this workgroup is done with LDS
-            scan_tile<NT, HWC, SHWC, TBLG, false, true>(*ap, tile);
+            __syncthreads();              // a previous tile of this workgroup is done with LDS
+            scan_tile<NT, HWC, SHWC, TBLG, false, true>(*ap, first + i);
         }
     }
 }
