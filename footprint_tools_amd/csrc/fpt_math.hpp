@@ -460,11 +460,13 @@ FPT_HD double erfc_fn(double a) {
     return erfc_large(a);
 }
 
-// ndtr.c:34-59
-FPT_HD double ndtr(double a) {
+// ndtr.c:34-59, split at its branch so that a caller with several arguments per lane can run
+// the cheap central branch for all of them and the tail branch only where it is needed
+FPT_HD bool ndtr_is_central(double a) { return fabs(a * kSqrtH) < 1.0; }
+FPT_HD double ndtr_central(double a) { return 0.5 + 0.5 * erf_small(a * kSqrtH); }
+FPT_HD double ndtr_tail(double a) {
     double x = a * kSqrtH;
     double z = fabs(x);
-    if (z < 1.0) return 0.5 + 0.5 * erf_small(x);
     double y = 0.5 * erfce(z);
 #if defined(__HIP_DEVICE_COMPILE__)
     // exp(-a^2/2) for the tail.  The reference takes sqrt(expx2(a, -1)) (two exps and a square
@@ -483,6 +485,7 @@ FPT_HD double ndtr(double a) {
     if (x > 0) y = 1.0 - y;
     return y;
 }
+FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndtr_tail(a); }
 
 // ndtri.c:48-88
 FPT_HD double ndtri(double y0) {
