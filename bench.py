@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fused per-nucleotide footprint scan on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path (6-mer lookup -> expected cleavage with trimmed-mean
 smoothing -> NB p-value -> Stouffer windows) over one batch of synthetic intervals that is
-already resident in HBM.  N=1 workload = BASELINE.json configs[1] (100,000 x 500 bp, one
-scale); `--config 3` selects configs[2] (1,000,000 x 1 kb, five scales).  With N>1 every rank
+already resident in HBM.  N=1 workload = BASELINE.json configs[2], the largest single-GPU
+configuration (1,000,000 x 1 kb, five Stouffer scales); `--config 2` selects configs[1]
+(100,000 x 500 bp, one scale), `--config 4` one GPU's share of the ragged whole-genome set.  With N>1 every rank
 scans its own shard of N x batch intervals (weak scaling, no data-path collective inside the
 scan) and, after the K steps and still inside the timed region, the per-base p-value track of
 the resident batch is re-assembled on every rank with ONE RCCL all-gather (N x 400 MB for
@@ -58,31 +59,57 @@ def load_models():
     return g["table"], DM
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, table, DM, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm, results identical to the reference on
-    the golden vectors) on a bounded sample of the same workload, all host cores."""
+    the golden vectors) on a bounded sample of the same workload: all host cores, and one core.
+    k_cal (profiles/k_cal.json, measured in the build container with oracle/pyref/k_cal.py) is
+    the ratio port / genuine reference on BASELINE config 1, so value / k_cal estimates what the
+    reference itself (Python + Cython, cannot travel here) would do on these cores."""
     from oracle import oracle  # checker / baseline only
     L, scales = cfg["L"], cfg["scales"]
     l = L + 2 * (HW + SHW) + 1
-    cores = min(os.cpu_count() or 1, 64)
+    cores = os.cpu_count() or 1
 
-    def run(n):
+    def run(n, threads):
         cp = oracle.synth_counts(1, 0, n * l, 0)
         cm = oracle.synth_counts(1, 0, n * l, 1)
         sq = oracle.synth_bases(1, 0, n * (l + 6))
         t0 = time.perf_counter()
         oracle.detect_batch(cp, cm, sq, n, L, HW, SHW, CLIP, table, DM.mu_params, DM.r_params, scales,
-                            n_threads=cores)
+                            n_threads=threads)
         return time.perf_counter() - t0
 
     probe_n = 4 * cores
-    dt = run(probe_n)
+    dt = run(probe_n, cores)
     rate = probe_n * L / dt
     n = int(max(probe_n, min(rate * budget_s / L, 200000)))
-    dt = run(n)
-    return dict(value=n * L / dt, unit="bases/s", cores=cores, kind="port",
-                sample="%d intervals x %d bp of the same synthetic workload, oracle/fpt_oracle.c with "
-                       "OpenMP over intervals, %.1f s" % (n, L, dt))
+    dt = run(n, cores)
+    dt1 = run(8, 1)
+    n1 = int(max(8, min(8 * 3.0 / dt1, 20000)))  # about 3 s on one core
+    dt1 = run(n1, 1)
+    out = dict(value=n * L / dt, unit="bases/s", cores=cores, kind="port", cpu_model=cpu_model(),
+               value_1core=n1 * L / dt1,
+               sample="%d intervals x %d bp x %d scales of the same synthetic workload, oracle/fpt_oracle.c with "
+                      "OpenMP over intervals on %d threads, %.1f s; 1-core figure on %d intervals, %.1f s"
+                      % (n, L, len(scales), cores, dt, n1, dt1))
+    kc = os.path.join(ROOT, "profiles", "k_cal.json")
+    if os.path.exists(kc):
+        k = json.load(open(kc))
+        out["k_cal"] = dict(port_over_reference_1_worker=k["workers_1"]["k_cal"],
+                            port_over_reference_8_workers=k["workers_8"]["k_cal"],
+                            measured_on=k.get("cpu_model"), workload=k["workload"])
+        out["implied_reference_1core"] = out["value_1core"] / k["workers_1"]["k_cal"]
+    return out
 
 
 def main():
@@ -90,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="3", choices=sorted(CONFIGS))
     ap.add_argument("--nb-mode", default="memo", choices=["memo", "direct"],
                     help="per-base NB p-value: exact (exp,obs) memo table rebuilt inside every step, "
                          "or direct incbet per base; at N=1 the other mode is timed too and reported")
@@ -280,8 +307,12 @@ def main():
                 if rec:
                     traffic_bytes = rec["bytes_per_launch"]
                     traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
+            achieved_read = total * rd / (k_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        # north_star's wording is the HBM-READ roofline: the same launch priced on
+                        # its algorithmic read bytes only (frac above counts reads + writes)
+                        achieved_read=achieved_read, frac_read=achieved_read / HBM_PEAK_GBS,
                         kernel=("k_scan_fused<NT,HW,SHW,table=L2,memo_only> (first pass of the step)"
                                 if args.nb_mode == "memo" else "k_scan_fused<NT,HW,SHW,table=L2,full>"),
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),

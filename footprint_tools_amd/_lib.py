@@ -12,13 +12,13 @@ FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
 NB_CDF, NB_LOGPMF, NB_PMF = range(3)
 NB_AUTO, NB_DIRECT, NB_MEMO, NB_NONE = range(4)
-FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8)
+FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8, ndtr_window=9)
 MAX_SCALES = 8
 MAX_DM = 64
 
 EXPORTS = [
     "fpt_last_error", "fpt_version", "fpt_device_count", "fpt_ctx_create", "fpt_ctx_destroy",
-    "fpt_ctx_set_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
+    "fpt_ctx_set_stream", "fpt_ctx_use_own_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
@@ -112,6 +112,7 @@ def load():
         L.fpt_ctx_create.argtypes = [i32, C.POINTER(vp)]
         L.fpt_ctx_destroy.argtypes = [vp]
         L.fpt_ctx_set_stream.argtypes = [vp, vp]
+        L.fpt_ctx_use_own_stream.argtypes = [vp]
         L.fpt_ctx_synchronize.argtypes = [vp]
         L.fpt_set_bias_table.argtypes = [vp, vp, dbl]
         L.fpt_set_dispersion.argtypes = [vp, i32, vp, vp]
@@ -245,8 +246,13 @@ class Context(object):
         check(self.L.fpt_ctx_synchronize(self.h))
 
     def set_stream(self, hip_stream):
-        """Run on a caller-owned hipStream_t (integer handle); None/0 = the context's own."""
-        check(self.L.fpt_ctx_set_stream(self.h, hip_stream or None))
+        """Run on a caller-owned hipStream_t (integer handle).  0 is the device's default (null)
+        stream -- what `torch.cuda.current_stream().cuda_stream` is on the default stream -- and
+        work is then ordered with it; None goes back to the context's own non-blocking stream."""
+        if hip_stream is None:
+            check(self.L.fpt_ctx_use_own_stream(self.h))
+        else:
+            check(self.L.fpt_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
     def timing_enable(self, max_records):
         check(self.L.fpt_timing_enable(self.h, int(max_records)))

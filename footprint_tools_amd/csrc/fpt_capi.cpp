@@ -160,15 +160,25 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     fpt_ctx *c = new fpt_ctx();
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_table, (FPT_KMER_TABLE + 1) * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_models, FPT_MAX_DISPERSION_MODELS * kModelDoubles * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_flags, 16 * sizeof(int)));
-    HIP_TRY(hipMalloc(&c->d_sum, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_flags, 0, 16 * sizeof(int)));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
+    // any failure below releases what was created so far (fpt_ctx_destroy skips null members)
+    auto init = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIP_TRY(hipMalloc(&c->d_table, (FPT_KMER_TABLE + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_models, FPT_MAX_DISPERSION_MODELS * kModelDoubles * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_flags, 16 * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->d_sum, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_flags, 0, 16 * sizeof(int)));
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        return FPT_OK;
+    };
+    if (int rc = init()) {
+        const std::string keep = g_err;
+        fpt_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
     return FPT_OK;
 }
@@ -176,7 +186,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
 int fpt_ctx_destroy(fpt_ctx *c) {
     if (!c) return FPT_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < kSlots; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->d_table) (void)hipFree(c->d_table);
@@ -193,7 +203,13 @@ int fpt_ctx_destroy(fpt_ctx *c) {
 
 int fpt_ctx_set_stream(fpt_ctx *c, void *hip_stream) {
     if (int rc = check_ctx(c)) return rc;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // NULL = the device's default stream, as handed over
+    return FPT_OK;
+}
+
+int fpt_ctx_use_own_stream(fpt_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    c->stream = c->own_stream;
     return FPT_OK;
 }
 
@@ -357,7 +373,7 @@ int fpt_window(fpt_ctx *c, int op, const double *x, const double *w, int64_t n_r
 int fpt_special(fpt_ctx *c, int fn, const double *a, const double *b, const double *x, int64_t n,
                 double *out) {
     if (int rc = check_ctx(c)) return rc;
-    if (fn < 0 || fn > 8) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
+    if (fn < 0 || fn > 9) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
     if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
     if (n == 0) return FPT_OK;
     if (!a || !out) return fail(FPT_ERR_INVALID, "null buffer");

@@ -234,6 +234,23 @@ __device__ __forceinline__ int scan_min_nonneg(int x, bool present) {
     return kNonnegTop - (int)wave_scan_umax(present ? (unsigned)(kNonnegTop - x) : 0u);
 }
 
+// inclusive prefix sum within each row of 16 lanes (row_shr:1,2,4,8 with zero fill): the first
+// level of a two-level workgroup-wide prefix sum -- 12 instructions instead of the 20+ of the
+// full-wavefront scan, whose row_bcast steps need a masked move per half
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_zero(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_scan_f64(double x) {
+    x += dpp_f64_zero<0x111>(x);
+    x += dpp_f64_zero<0x112>(x);
+    x += dpp_f64_zero<0x114>(x);
+    x += dpp_f64_zero<0x118>(x);
+    return x;
+}
+
 // typed front-ends: the smoothing phase runs its scans either on doubles or, when every window
 // sum of the tile is a small integer (cut counts are), on int32, where a DPP scan step is one
 // v_add/v_min/v_max with a DPP operand instead of 5-7 instructions for a 64-bit value

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) k_special(int fn, const double *__restric
         case 5: res = fptm::erf_fn(v); break;
         case 6: res = fptm::erfc_fn(v); break;
         case 7: res = fptm::incbet(v, b[i], x[i]); break;
+        case 9: res = fptm::ndtr_window(v); break;
         default: res = fptm::chdtrc(v, x[i]); break;
         }
         out[i] = res;
@@ -764,7 +765,6 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
 
     // ---- D: expected merge (detect.py:122), p-value (dispersion.pyx:311-314), z = ndtri(1-p)
     double *zb = wP;  // window sums are dead now
-    int *nf = reinterpret_cast<int *>(wM);
     double zv = 0.0;
     int zc = 0;
     // expected counts: the integer smoothing path keeps them in registers, the others in cP / cM
@@ -872,13 +872,69 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     }
     if (a.n_scales == 0 || ABL(256)) return;
 
-    // ---- E: Stouffer windows (windowing.h:53-84).  Narrow ones (the reference's hw = 3) are
-    //         summed directly from the raw z in LDS, left to right like the reference; a
-    //         non-finite z makes the sum non-finite, which is the NaN rule.  Wider ones are
-    //         assembled from per-tile prefix sums of (z, non-finite count) like the smoothing
-    //         windows above, so their cost does not grow with the width.
+    // ---- E: Stouffer windows (windowing.h:53-84): out = ndtr(-(sum of z over 2*hs+1 bases) / sqrt(2*hs+1)),
+    //         NaN when the window holds a non-finite z, 1.0 within hs of the interval's ends.
     constexpr int kDirectWin = 8;
     double *zraw = pP;  // propensities are dead after C
+    if (a.n_scales == 1 && a.max_scale <= kDirectWin) {
+        // One narrow scale (the reference's only one is hw = 3): summed directly from the raw z in
+        // LDS, left to right like the reference; a non-finite z makes the sum non-finite.
+        if (tid < nt) zraw[tid] = z;
+        __syncthreads();
+        const int hs = a.scales[0];
+        const double rk = a.scale_sqrt[0];
+        double *dst = a.winp_out + out_off;
+        for (int v = tid; v < tl; v += NT) {
+            const int t = t0 + v;
+            double res = 1.0;  // edges are 1.0 (windowing.pyx:51)
+            if (t >= hs && t < L - hs) {
+                double sv = 0.0;
+                for (int j = t - ta - hs; j <= t - ta + hs; ++j) sv += zraw[j];
+                res = !isfinite(sv) ? NAN : (ABL(4) ? sv : fptm::ndtr_window(-(sv * rk)));
+            }
+            dst[t] = res;
+        }
+        return;
+    }
+    // Several scales (or a wide one): every window sum is a difference of two entries of ONE
+    // workgroup-wide prefix sum of z, built in two levels -- rows of 16 lanes on the DPP path, the
+    // NT/16 row totals scanned by the first wavefront -- so a scale costs two LDS reads and a
+    // subtraction whatever its width.  Tiles holding a non-finite z (p = 0, p >= 1, p below 2^-53:
+    // the NaN rule) are rare and take the tile-prefix path below, which counts them per window.
+    constexpr int NROW = NT / 16;
+    double *rowtot = pM, *rowcar = pM + NROW;  // propensities are dead after C
+    {
+        const double zr = row_scan_f64(zv);  // lanes beyond nt hold 0
+        zb[tid] = zr;
+        if ((lane & 15) == 15) rowtot[tid >> 4] = zr;
+    }
+    const bool any_nonfinite = __syncthreads_or(zc) != 0;
+    if (!any_nonfinite) {
+        if (tid < kWave) {
+            const double tv = tid < NROW ? rowtot[tid] : 0.0;
+            const double inc = wave_scan_f64(tv, 0.0, op_add());
+            if (tid < NROW) rowcar[tid] = inc - tv;
+        }
+        __syncthreads();
+        const int t = t0 + tid, idx = t - ta;  // tl <= nt <= NT: one output base per lane
+        for (int s = 0; s < a.n_scales; ++s) {
+            const int hs = a.scales[s];
+            const double rk = a.scale_sqrt[s];
+            double *dst = a.winp_out + (int64_t)s * a.total_bases + out_off;
+            const bool inside = tid < tl && t >= hs && t < L - hs;
+            const int hi = inside ? idx + hs : 0, lo = inside ? idx - hs - 1 : -1;
+            const int lo_c = lo < 0 ? 0 : lo;
+            const double p_hi = zb[hi] + rowcar[hi >> 4];
+            const double p_lo = zb[lo_c] + rowcar[lo_c >> 4];
+            const double sv = p_hi - (lo < 0 ? 0.0 : p_lo);
+            const double pw = ABL(4) ? sv : fptm::ndtr_window(-(sv * rk));
+            if (tid < tl) dst[t] = inside ? pw : 1.0;  // edges are 1.0 (windowing.pyx:51)
+        }
+        return;
+    }
+    // tile-prefix path: per-wavefront prefix sums of (z with non-finite values as 0, count of
+    // non-finite values) published per 64-base tile; narrow windows directly from the raw z
+    int *nf = reinterpret_cast<int *>(wM);
     if (a.min_scale <= kDirectWin && tid < nt) zraw[tid] = z;
     if (a.max_scale > kDirectWin) {
         wave_scan(zv, zc, lane);
@@ -899,7 +955,7 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
                 if (t >= hs && t < L - hs) {
                     double sv = 0.0;
                     for (int j = t - ta - hs; j <= t - ta + hs; ++j) sv += zraw[j];
-                    res = !isfinite(sv) ? NAN : (ABL(4) ? sv : fptm::ndtr(-(sv * rk)));
+                    res = !isfinite(sv) ? NAN : (ABL(4) ? sv : fptm::ndtr_window(-(sv * rk)));
                 }
                 dst[t] = res;
             }
@@ -912,7 +968,7 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
                 const int lo = t - ta - hs, hi = t - ta + hs;
                 const double sv = hs <= 64 ? tile_range_sum3(zb, lo, hi) : tile_range_sum(zb, lo, hi);
                 const int sc = hs <= 64 ? tile_range_sum3(nf, lo, hi) : tile_range_sum(nf, lo, hi);
-                res = (sc > 0) ? NAN : (ABL(4) ? sv : fptm::ndtr(-(sv * rk)));
+                res = (sc > 0) ? NAN : (ABL(4) ? sv : fptm::ndtr_window(-(sv * rk)));
             }
             dst[t] = res;
         }

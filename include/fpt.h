@@ -62,7 +62,8 @@ enum fpt_nb_what {
 enum fpt_special_fn {
     FPT_FN_GAMMA = 0, FPT_FN_LGAM = 1, FPT_FN_NDTR = 2, FPT_FN_NDTRI = 3, FPT_FN_LOG1P = 4,
     FPT_FN_ERF = 5, FPT_FN_ERFC = 6, FPT_FN_INCBET = 7, /* (a,b,x) */
-    FPT_FN_CHDTRC = 8 /* (df = a, x) */
+    FPT_FN_CHDTRC = 8, /* (df = a, x) */
+    FPT_FN_NDTR_WINDOW = 9 /* the normal cdf as the fused scan's Stouffer windows evaluate it */
 };
 
 #define FPT_MAX_DISPERSION_MODELS 64
@@ -77,8 +78,12 @@ int fpt_device_count(int *n_out);
  * dispersion-model table and a grow-only device workspace. */
 int fpt_ctx_create(int device_id, fpt_ctx **out);
 int fpt_ctx_destroy(fpt_ctx *ctx);
-/* run on a caller-provided hipStream_t (e.g. the framework's current stream); NULL = own stream */
+/* run on a caller-provided hipStream_t (e.g. the framework's current stream).  The handle is
+ * taken as it is: NULL is the device's default (null) stream, which is what a framework running
+ * on its default stream hands over, and work is then ordered with that stream.  To go back to
+ * the context's own non-blocking stream call fpt_ctx_use_own_stream. */
 int fpt_ctx_set_stream(fpt_ctx *ctx, void *hip_stream);
+int fpt_ctx_use_own_stream(fpt_ctx *ctx);
 int fpt_ctx_synchronize(fpt_ctx *ctx);
 
 /* bias_model.__getitem__ / kmer_model.read_model (modeling/bias.py:16-17, 63-86):

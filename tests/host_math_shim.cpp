@@ -13,7 +13,8 @@ void hm_map1(int op, const double *x, long n, double *out) {
                  : op == 3 ? fptm::ndtri(v)
                  : op == 4 ? fptm::log1p_fn(v)
                  : op == 5 ? fptm::erf_fn(v)
-                           : fptm::erfc_fn(v);
+                 : op == 6 ? fptm::erfc_fn(v)
+                           : fptm::ndtr_window(v);
     }
 }
 void hm_incbet(const double *a, const double *b, const double *x, long n, double *out) {

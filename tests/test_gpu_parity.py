@@ -55,6 +55,21 @@ def test_special_functions(fpt, ctx):
         assert v < P_TOL, (k, v)
 
 
+def test_ndtr_window_device(fpt, ctx, orc):
+    """The normal cdf as phase E of the fused scan evaluates it (one formula for |a| < 26, the
+    restated ndtr.c beyond) against the reference's ndtr on its golden grid and, densely, against
+    the oracle's ndtr: contract 1e-6, expected <= 1e-12."""
+    w = golden("window.npz")
+    assert rel_err(special(fpt, ctx, "ndtr_window", w["ndtr_a"]), w["ndtr_val"]) < 1e-12
+    rs = np.random.RandomState(11)
+    a = np.concatenate([rs.uniform(-26, 26, 300000), rs.normal(0, 1.5, 300000), rs.uniform(-40, 40, 20000),
+                        np.linspace(-26.5, 26.5, 40001), [0.0, -0.0, 26.0, -26.0, 75.0, -75.0, np.inf, -np.inf, np.nan]])
+    got, want = special(fpt, ctx, "ndtr_window", a), orc.map1("ndtr", a)
+    err = rel_err(got, want)
+    print("ndtr_window max rel err %.2e" % err)
+    assert err < 1e-12
+
+
 # ---------------------------------------------------------------- A1: 6-mer lookup, bit-exact
 def test_kmer_probs(fpt, ctx):
     g = golden("kmer_probs.npz")
@@ -487,6 +502,60 @@ def test_full_size_properties(fpt, orc):
     # winp of a half batch lands at winp_out + s*total_half: with one scale that is the same slot
     assert [sc.checksum_dev(d_o2.ptr + k * t8, total) for k in range(4)] == sums
     for d in (d_cp, d_cm, d_sq, d_out, d_o2):
+        d.free()
+
+
+def test_full_size_config3_properties(fpt, orc):
+    """BASELINE config 3 at full size (1,000,000 x 1 kb, five Stouffer scales, what bench.py times):
+    sampled intervals equal the oracle, the launch is idempotent, and two half batches (what two
+    ranks would run) checksum to the whole -- per track, the checksum being additive."""
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = fpt.get_ctx()
+    n_iv, L, hw, shw, clip, scales = 1000000, 1000, 5, 50, 0.01, (3, 5, 10, 20, 40)
+    S = len(scales)
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales)
+    l = sc.padded_len(L)
+    total = n_iv * L
+    t8 = total * 8
+    d_cp, d_cm = DeviceArray(ctx, n_iv * l * 8), DeviceArray(ctx, n_iv * l * 8)
+    d_sq = DeviceArray(ctx, n_iv * (l + 6))
+    d_out = DeviceArray(ctx, (3 + S) * t8)
+    sc.synth_dev(1, n_iv, L, d_cp.ptr, d_cm.ptr, d_sq.ptr)
+
+    def run(n, first, base, tot8):
+        sc.scan_dev(n, d_cp.ptr + first * l * 8, d_cm.ptr + first * l * 8, d_sq.ptr + first * (l + 6),
+                    base, base + tot8, base + 2 * tot8, base + 3 * tot8, interval_len=L)
+
+    run(n_iv, 0, d_out.ptr, t8)
+    ctx.synchronize()
+    sums = [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(3 + S)]
+    for iv in (0, 1, 500000, 999999):
+        cp = orc.synth_counts(1, iv * l, l, 0)
+        cm = orc.synth_counts(1, iv * l, l, 1)
+        sq = orc.synth_bases(1, iv * (l + 6), l + 6)
+        e, o, p, wp = orc.detect_batch(cp, cm, sq, 1, L, hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                       np.array(scales, np.int32))
+        assert np.array_equal(d_out.download(np.float64, L, iv * L * 8), e)
+        assert np.array_equal(d_out.download(np.float64, L, t8 + iv * L * 8), o)
+        assert rel_err(d_out.download(np.float64, L, 2 * t8 + iv * L * 8), p) < P_TOL
+        for s in range(S):
+            assert rel_err(d_out.download(np.float64, L, (3 + s) * t8 + iv * L * 8), wp[s]) < P_TOL
+    run(n_iv, 0, d_out.ptr, t8)  # idempotence
+    ctx.synchronize()
+    assert [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(3 + S)] == sums
+    half = n_iv // 2
+    h8 = half * L * 8
+    d_h = DeviceArray(ctx, (3 + S) * h8)
+    part = [0] * (3 + S)
+    for first in (0, half):
+        run(half, first, d_h.ptr, h8)
+        ctx.synchronize()
+        for k in range(3 + S):
+            part[k] = (part[k] + sc.checksum_dev(d_h.ptr + k * h8, half * L)) % (1 << 64)
+    assert part == sums
+    for d in (d_cp, d_cm, d_sq, d_out, d_h):
         d.free()
 
 
