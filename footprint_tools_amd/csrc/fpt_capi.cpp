@@ -46,6 +46,7 @@ struct fpt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     double *d_table = nullptr;   // 4097 doubles (slot 4096 = default)
+    double *d_table2 = nullptr;  // 2 x 4096 doubles: the same table in the lean scan kernel's order
     double *d_models = nullptr;  // FPT_MAX_DISPERSION_MODELS * 24
     int *d_flags = nullptr;      // error flags
     unsigned long long *d_sum = nullptr;
@@ -59,6 +60,7 @@ struct fpt_ctx {
     int tev_used = 0;
     int n_cu = 0;
     int memo_exp = 256, memo_obs = 256;
+    bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
     // the 1e-4 tail of the widest rows is hit in every batch.
@@ -158,6 +160,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
         return fail(FPT_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
     fpt_ctx *c = new fpt_ctx();
+    if (const char *e = getenv("FPT_SCAN_LEAN")) c->use_lean = atoi(e) != 0;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     // any failure below releases what was created so far (fpt_ctx_destroy skips null members)
@@ -165,6 +168,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIP_TRY(hipMalloc(&c->d_table, (FPT_KMER_TABLE + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_table2, 2 * FPT_KMER_TABLE * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_models, FPT_MAX_DISPERSION_MODELS * kModelDoubles * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_flags, 16 * sizeof(int)));
         HIP_TRY(hipMalloc(&c->d_sum, 16 * sizeof(unsigned long long)));
@@ -190,6 +194,7 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     for (int i = 0; i < kSlots; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_table2) (void)hipFree(c->d_table2);
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_sum) (void)hipFree(c->d_sum);
@@ -227,6 +232,9 @@ int fpt_set_bias_table(fpt_ctx *c, const double *table4096, double dflt) {
     t[FPT_KMER_TABLE] = dflt;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_table, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> t2(2 * FPT_KMER_TABLE);
+    fptk::build_lean_table(table4096, t2.data());
+    HIP_TRY(hipMemcpy(c->d_table2, t2.data(), t2.size() * sizeof(double), hipMemcpyHostToDevice));
     c->have_table = true;
     return FPT_OK;
 }
@@ -439,6 +447,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     sl.counts_minus = d->counts_minus;
     sl.seq = d->seq;
     sl.table = c->d_table;
+    sl.table2 = c->d_table2;
+    sl.n_cu = c->n_cu;
     sl.model = c->d_models + (size_t)d->dm_id * kModelDoubles;
     sl.exp_out = d->exp_out;
     sl.obs_out = d->obs_out;
@@ -584,14 +594,19 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             s2.tile_len = ln.tile_len;
             s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
             s2.redo = (int32_t *)d_redo;
-            size_t lds = fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
+            // first pass of memo mode: the lean kernel where it applies (the `detect` window widths)
+            const bool lean = memo_only && c->use_lean && fptk::scan_lean_applies(s2);
+            size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt)
+                              : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)
                 return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
-            HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, !memo_only && d_redo, lds));
+            if (lean) HIP_TRY(fptk::scan_lean_set_lds(ln.nt));
+            else HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, !memo_only && d_redo, lds));
             for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
                 int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
                 s2.tile_first = ln.first + done;
-                fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
+                if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
+                else fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
                 if (int rc = launch_ok("k_scan_fused")) return rc;
             }
         }

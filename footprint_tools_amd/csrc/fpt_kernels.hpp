@@ -36,7 +36,16 @@ struct scan_launch {
     int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
     const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
+    const void *table2;    // bias table in the lean kernel's order (build_lean_table), or nullptr
+    int32_t n_cu;          // compute units of the device (sizes the persistent grid of the lean kernel)
 };
+
+// fpt_scan_lean.hip: the first pass of memo mode for the `detect` defaults (hw 5, shw 50, clip 0.01)
+bool scan_lean_applies(const scan_launch &sl);
+size_t scan_lean_lds_bytes(int nt);
+hipError_t scan_lean_set_lds(int nt);
+void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl);
+void build_lean_table(const double *table4096, double *out8192);
 
 struct fdr_launch {
     int64_t n_intervals;

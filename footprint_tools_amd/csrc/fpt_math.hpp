@@ -493,7 +493,7 @@ FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndt
 // instructions).  Here, for t = |a| < 26,
 //     Phi(-t) = exp(-t^2/2) * g(t),   g(t) = Phi(-t) exp(t^2/2)   (half the scaled complementary
 //                                                                   error function, smooth, ~1/t)
-// with g a degree-17 polynomial in u = alpha/(t+5) + beta (u in [-1, 1] for t in [0, 26]) and exp
+// with g a degree-17 polynomial in 1/(t+5) (shifted to the centre of its range) and exp
 // by the usual reduction to |r| <= ln2/2 and a degree-10 polynomial: ~47 instructions, no
 // division, no branch.  Coefficients: tools/fit_ndtr_fast.py (Chebyshev series of the functions in
 // 60-digit arithmetic, truncated); measured against 60-digit values: relative error <= 2.5e-13
@@ -501,17 +501,24 @@ FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndt
 // reference's exp(-a^2) leaves the normal range and its value degrades, ndtr.c:49 / expx2.c),
 // infinities and NaN take ndtr() above, unchanged.
 constexpr double kNdtrFastLimit = 26.0;
+// g as a polynomial in v = 1/(t+5) - kNdtrR0 (highest power first) and exp(r) on |r| <= ln2/2
+#define FPT_NDTR_G_LIST                                                                                    \
+    -3.26604337552876651e+08, 8.15002226258950830e+08, 3.97188768134408370e+07, -8.87980925451137275e+07,  \
+        -6.83395857208489906e+06, 7.32657135714256205e+06, 1.32626037720134528e+06,                        \
+        -4.97107352772716549e+05, -2.26533562941670069e+05, -4.44113235120385980e+03,                      \
+        2.50634717617242968e+04, 1.17812358042428295e+04, 3.34532871217322145e+03,                         \
+        7.06038092613871299e+02, 1.18661330139268586e+02, 1.63755034045534558e+01,                         \
+        1.88100183563785173e+00, 1.03451588220061952e-01
+#define FPT_NDTR_E_LIST                                                                                    \
+    2.76326406754302347e-07, 2.76401822473621876e-06, 2.48014854792164305e-05, 1.98411702665183209e-04,   \
+        1.38888889523180450e-03, 8.33333338567131612e-03, 4.16666666664880780e-02,                         \
+        1.66666666665543917e-01, 5.00000000000001887e-01, 1.00000000000000666e+00, 1.00000000000000000e+00
+constexpr double kNdtrR0 = 0.11612903225806452;          // centre of 1/(t+5) over t in [0, 26]
+constexpr double kNdtrNegHalfLog2e = -0.7213475204444817;  // -0.5 * log2(e)
+constexpr double kNdtrLn2Hi = 0.6931471803691238, kNdtrLn2Lo = 1.9082149292705877e-10;
 FPT_HD double ndtr_fast(double a) {
-    const double kG[18] = {-1.64217739069545413e-10, 4.88590773166831551e-09,  2.83904169591598088e-09,
-                           -7.56775031444752151e-08, -6.94422598402443559e-08, 8.87647702683859263e-07,
-                           1.91583009230280140e-06,  -8.56183252012462410e-06, -4.65197575793240478e-05,
-                           -1.08739404165630874e-05, 7.31682735524650618e-04,  4.10072620386873338e-03,
-                           1.38834393911736395e-02,  3.49361263480003625e-02,  7.00074364246847936e-02,
-                           1.15190846009137746e-01,  1.57761444279303692e-01,  1.03451588220061952e-01};
-    const double kE[11] = {2.76326406754302347e-07, 2.76401822473621876e-06, 2.48014854792164305e-05,
-                           1.98411702665183209e-04, 1.38888889523180450e-03, 8.33333338567131612e-03,
-                           4.16666666664880780e-02, 1.66666666665543917e-01, 5.00000000000001887e-01,
-                           1.00000000000000666e+00, 1.00000000000000000e+00};
+    const double kG[18] = {FPT_NDTR_G_LIST};
+    const double kE[11] = {FPT_NDTR_E_LIST};
     const double t = fabs(a);
     const double d = t + 5.0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -521,12 +528,11 @@ FPT_HD double ndtr_fast(double a) {
 #else
     const double r = 1.0 / d;
 #endif
-    const double u = fma(1.19230769230769234e+01, r, -1.38461538461538458e+00);
-    const double g = horner<17>(u, kG);
-    const double s = -0.5 * (t * t);
-    const double n = rint(s * 1.4426950408889634);
-    double rr = fma(n, -0.6931471803691238, s);   // ln2 in two parts: the first has 32 significant bits
-    rr = fma(n, -1.9082149292705877e-10, rr);
+    const double g = horner<17>(r - kNdtrR0, kG);
+    const double t2 = t * t;
+    const double n = rint(t2 * kNdtrNegHalfLog2e);
+    double rr = fma(n, -kNdtrLn2Hi, -0.5 * t2);  // ln2 in two parts: the first has 32 significant bits
+    rr = fma(n, -kNdtrLn2Lo, rr);
     const double e = horner<10>(rr, kE);
     const double y = ldexp(e * g, (int)n);
     return a > 0.0 ? 1.0 - y : y;

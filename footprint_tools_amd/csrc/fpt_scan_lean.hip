@@ -1,0 +1,635 @@
+// fpt_scan_lean.hip -- the first pass of the fused scan in memo mode (gfx950 / CDNA4, wave64).
+//
+// Same path as k_scan_fused (cli/detect.py:120-130 for one tile of one interval per workgroup,
+// one output base per lane), written for the case every real batch is made of -- cut counts that
+// are small non-negative integers, A/C/G/T bases, (exp, obs) pairs inside the memo table, the
+// `detect` window widths hw = 5 / shw = 50 / clip 0.01 -- and for nothing else.  A tile that steps
+// outside that case is marked in `redo` and computed again by the general kernel
+// (k_scan_fused<..., REDO>), launched right behind on the same stream; whatever this kernel wrote
+// for such a tile is overwritten there.  No early exit is needed: every out-of-case input still
+// indexes inside its arrays.
+//
+// What keeps the instruction count down (the general kernel is bound by vector-instruction issue:
+// ~1,400 per base on five scales; measured, profiles/):
+//   * counts live in LDS as one 32-bit word per position (strand '+' | strand '-' << 16), so a
+//     2*hw window sum of both strands is nine packed integer adds (exact: window sums of integers
+//     do not depend on the order), and every scan below runs on 32-bit integers on the DPP path;
+//   * the sequence lives in LDS as two bit planes (bits 1 and 2 of the ASCII code: A=00 C=01 T=10
+//     G=11, case-insensitive) written straight from two wavefront ballots; the 6-mer of a position
+//     is six bits of each plane, and the bias table is re-indexed by that 12-bit number with the
+//     forward and the reverse-complement propensity side by side, so one 16-byte gather per
+//     position replaces seven byte loads, two index computations and two gathers;
+//   * the trimmed sum of a smoothing window is S - min - max from per-64-position-tile prefix sums
+//     and prefix / suffix extrema; the one case where smoothing.h:61-69 gives something else
+//     (2nd smallest == 2nd largest: at least 99 of 101 values equal and non-zero) needs a run of
+//     33 equal values, hence 16 equal non-zero values in an aligned row of 16 lanes -- two ballots
+//     and a few scalar instructions per tile, and such a tile goes to the general kernel;
+//   * expected = round(P/Q * t/99): Q is summed in the reference's order, the two divisions are
+//     replaced by one reciprocal with two Newton steps, and a base whose product lies within
+//     1e-13 (relative) of a half-integer -- where the rounding of the exact operations could
+//     decide -- sends its tile to the general kernel;
+//   * Stouffer windows from one workgroup-wide prefix sum of z; the normal cdf by the one-formula
+//     evaluation of fpt_math.hpp (ndtr_fast) with every polynomial coefficient held in scalar
+//     registers: the compiler's own choice for `acc * x + c` with a 64-bit constant is two
+//     v_mov_b32 and a v_fmac_f64, three vector instructions per Horner step instead of one.
+#include "fpt_kernels.hpp"
+
+#include <cstddef>
+
+#include "fpt_device.hpp"
+
+using namespace fptd;
+
+namespace {
+
+typedef unsigned int u32;
+
+constexpr int kHW = 5, kSHW = 50, kPad = kHW + kSHW, kW = 2 * kSHW + 1;
+constexpr u32 kCountMax = 6553;  // 10 of them fit 16 bits
+
+// fp64 constants that the kernel wants in scalar registers: they travel in the kernel-argument
+// segment, which the compiler cannot fold back into literals
+struct lean_coef {
+    double g[18];  // FPT_NDTR_G_LIST
+    double e[11];  // FPT_NDTR_E_LIST
+    double neg_r0, neg_half_log2e, neg_ln2_hi, neg_ln2_lo;
+    double c99, band, limit;
+};
+
+struct lean_args {
+    int32_t interval_len;        // uniform mode when interval_off == nullptr
+    const int64_t *interval_off; // ragged: output offsets
+    const int32_t *tile_iv;      // ragged: tile table
+    const int32_t *tile_t0;
+    const int32_t *tile_tl;
+    int64_t tile_first, tile_end;  // tiles of this launch: workgroup b takes b, b + gridDim.x, ...
+    int32_t tiles_per_interval, tile_len;
+    int32_t n_scales;
+    int32_t scales[FPT_MAX_SCALES];
+    double scale_rsqrt[FPT_MAX_SCALES];
+    int32_t max_scale;
+    int64_t total_bases;
+    const double *counts_plus, *counts_minus;
+    const uint8_t *seq;
+    const double2 *table2;  // 4096 x (forward, reverse-complement) propensity, bit-plane index
+    double *exp_out, *obs_out, *pval_out, *winp_out;
+    const double2 *memo;
+    int32_t memo_exp, memo_obs;
+    int32_t *redo;
+    const int32_t *dm_ids;
+    int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
+    lean_coef c;
+};
+#ifdef FPT_ABLATE
+#define LEAN_STOP(n) (a.stop == (n))
+#else
+#define LEAN_STOP(n) false
+#endif
+
+// ---- fp64 arithmetic with one operand in scalar registers (VOP3, one instruction each)
+__device__ __forceinline__ double mul_vs(double a, double s) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+    return r;
+}
+__device__ __forceinline__ double add_vs(double a, double s) {
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+    return r;
+}
+__device__ __forceinline__ double fma_svv(double s, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(b), "v"(c));
+    return r;
+}
+
+typedef const __attribute__((address_space(4))) lean_coef kcoef;        // in the kernel-argument segment
+typedef const __attribute__((address_space(4))) double kdouble;
+
+#define FPT_HSTEP(n) "v_fma_f64 %0, %0, %1, %" #n "\n\t"
+// degree-17 and degree-10 Horner chains, coefficients highest power first in scalar registers
+__device__ __forceinline__ double horner17_s(double x, kdouble *c) {
+    double acc;
+    asm("v_mov_b64 %0, %2\n\t" FPT_HSTEP(3) FPT_HSTEP(4) FPT_HSTEP(5) FPT_HSTEP(6) FPT_HSTEP(7) FPT_HSTEP(8)
+            FPT_HSTEP(9) FPT_HSTEP(10) FPT_HSTEP(11) FPT_HSTEP(12) FPT_HSTEP(13) FPT_HSTEP(14) FPT_HSTEP(15)
+                FPT_HSTEP(16) FPT_HSTEP(17) FPT_HSTEP(18) FPT_HSTEP(19)
+        : "=&v"(acc)
+        : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]),
+          "s"(c[9]), "s"(c[10]), "s"(c[11]), "s"(c[12]), "s"(c[13]), "s"(c[14]), "s"(c[15]), "s"(c[16]), "s"(c[17]));
+    return acc;
+}
+__device__ __forceinline__ double horner10_s(double x, kdouble *c) {
+    double acc;
+    asm("v_mov_b64 %0, %2\n\t" FPT_HSTEP(3) FPT_HSTEP(4) FPT_HSTEP(5) FPT_HSTEP(6) FPT_HSTEP(7) FPT_HSTEP(8)
+            FPT_HSTEP(9) FPT_HSTEP(10) FPT_HSTEP(11) FPT_HSTEP(12)
+        : "=&v"(acc)
+        : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]),
+          "s"(c[9]), "s"(c[10]));
+    return acc;
+}
+#undef FPT_HSTEP
+
+// fptm::ndtr_fast with the constants in scalar registers (same operations, same coefficients).
+// The 18 + 11 coefficient pairs do not fit the scalar register file next to the kernel's own
+// state, and left alone the compiler loads them all before the loop over the scales and spills
+// them through v_writelane / v_readlane (32 vector instructions per evaluation).  Passing the
+// pointer through an empty asm that depends on the argument, and again on the first chain's
+// result, keeps each set's loads (four s_load_dwordx16) next to its use.
+__device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
+    asm volatile("" : "+s"(c) : "v"(a));
+    const double t = fabs(a);
+    const double d = t + 5.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double g = horner17_s(add_vs(r, c->neg_r0), c->g);
+    asm volatile("" : "+s"(c) : "v"(g));
+    const double t2 = t * t;
+    const double n = rint(mul_vs(t2, c->neg_half_log2e));
+    double rr = fma_svv(c->neg_ln2_hi, n, -0.5 * t2);
+    rr = fma_svv(c->neg_ln2_lo, n, rr);
+    const double e = horner10_s(rr, c->e);
+    const double y = ldexp(e * g, (int)n);
+    return a > 0.0 ? 1.0 - y : y;
+}
+
+// LDS carve-up for a workgroup of NT lanes: positions are padded up to NCR = NT + 128
+// (NT output bases + 2*pad + 1 padded positions + 6 sequence bases, in whole 64-position tiles)
+template <int NT>
+struct lean_lds {
+    static constexpr int NCR = NT + 128;
+    // doubles
+    static constexpr int oPP = 0;                  // P+[v]
+    static constexpr int oPM = oPP + NCR;          // P-[v-1] (slot 0 is a dummy)
+    static constexpr int oZB = oPM + NCR + 2;      // row prefix sums of z (see Z / C in the kernel)
+    static constexpr int oRT = oZB + NT + 48;      // row totals (64), then row carries (64 + 4)
+    static constexpr int nDoubles = oRT + 64 + 68;
+    // 32-bit words, after the doubles
+    static constexpr int oB0 = 0;                  // sequence bit planes
+    static constexpr int oB1 = oB0 + NCR / 32 + 4;
+    static constexpr int oPK = oB1 + NCR / 32 + 4; // packed counts with 8 zero words either side
+    static constexpr int oWP = oPK + NCR + 16;     // packed 2*hw window sums
+    static constexpr int oSP = oWP + NCR;          // tile prefix sums of W+, W-
+    static constexpr int oSM = oSP + NCR;
+    static constexpr int oXP = oSM + NCR;          // W+: (0xffff - prefix min) | prefix max << 16
+    static constexpr int oXPs = oXP + NCR;         //     same for the suffixes
+    static constexpr int oXM = oXPs + NCR;
+    static constexpr int oXMs = oXM + NCR;
+    static constexpr int nWords = oXMs + NCR;
+    static constexpr size_t bytes = (size_t)nDoubles * 8 + (size_t)nWords * 4;
+};
+
+// sum / extrema of the 101 positions [lo, hi] (hi = lo + 100) from the per-tile scans: the window
+// starts in tile q0 = lo >> 6 and ends one or two tiles later
+__device__ __forceinline__ u32 window_sum(const u32 *ps, int lo, int hi) {
+    const int below = lo - 1, q = below >> 6;  // lo >= 5: below >= 0
+    const int e1 = (q << 6) + 63, e2 = e1 + 64;
+    const u32 s2 = ps[(hi >> 6) == q + 2 ? e2 : below];  // a middle tile, or a term that cancels
+    return (ps[hi] - ps[below]) + ps[e1] + ((hi >> 6) == q + 2 ? s2 : 0u);
+}
+
+// threadIdx.x through an empty asm (see the tile loop of k_scan_lean)
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// geometry of one tile: output bases [t0, t0+tl) of interval iv, widened by the largest Stouffer
+// half-width H on both sides for the p-values its windows need
+struct lean_tile {
+    int64_t out_off;  // offset of the interval in the output tracks
+    int t0, tl, L, ta, nt, nc, ncs;
+    const double *gcp, *gcm;
+    const uint8_t *gsq;
+    int dm;
+};
+
+// A uniform read of launch-constant data (tile table, interval offsets, model ids) as a SCALAR
+// load: through a generic pointer the compiler issues a vector load plus v_readfirstlane, and the
+// in-order memory counter then makes the wavefront wait for every store still in flight (the
+// tracks of the previous phase) before the next tile's geometry is known.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p, int64_t i) {
+    return ((const __attribute__((address_space(4))) T *)p)[i];
+}
+
+template <typename Args>
+__device__ __forceinline__ lean_tile lean_geometry(const Args &a, int64_t tile) {
+    lean_tile g;
+    int64_t iv;
+    if (a.interval_off) {
+        iv = uniform_load(a.tile_iv, tile);
+        g.t0 = uniform_load(a.tile_t0, tile);
+        g.tl = uniform_load(a.tile_tl, tile);
+        g.out_off = uniform_load(a.interval_off, iv);
+        g.L = (int)(uniform_load(a.interval_off, iv + 1) - g.out_off);
+    } else {
+        if (a.tiles_per_interval == 1) {  // a 64-bit scalar division costs ~150 instructions
+            iv = tile;
+            g.t0 = 0;
+        } else if ((tile >> 32) == 0) {
+            const uint32_t q = (uint32_t)tile / (uint32_t)a.tiles_per_interval;
+            iv = q;
+            g.t0 = (int)((uint32_t)tile - q * (uint32_t)a.tiles_per_interval) * a.tile_len;
+        } else {
+            iv = tile / a.tiles_per_interval;
+            g.t0 = (int)(tile % a.tiles_per_interval) * a.tile_len;
+        }
+        g.L = a.interval_len;
+        g.out_off = iv * (int64_t)g.L;
+        g.tl = min(a.tile_len, g.L - g.t0);
+    }
+    const int H = a.max_scale;
+    g.ta = max(0, g.t0 - H);
+    g.nt = min(g.L, g.t0 + g.tl + H) - g.ta;  // bases needing p / z (<= NT)
+    g.nc = g.nt + 2 * kPad + 1;                // padded positions
+    g.ncs = (g.nc + 6 + 63) & ~63;             // positions staged, in whole tiles (<= NT + 128)
+    g.gcp = a.counts_plus + (g.out_off + iv * (int64_t)(2 * kPad + 1) + g.ta);
+    g.gcm = a.counts_minus + (g.out_off + iv * (int64_t)(2 * kPad + 1) + g.ta);
+    g.gsq = a.seq + (g.out_off + iv * (int64_t)(2 * kPad + 7) + g.ta);
+    g.dm = a.dm_ids ? uniform_load(a.dm_ids, iv) : 0;
+    return g;
+}
+
+// the inputs of one tile as they sit in a lane's registers between the load and phase A
+struct lean_inputs {
+    double cp[2], cm[2];
+    u32 ch[2];
+};
+
+template <int NT>
+__device__ __forceinline__ void lean_load(const lean_tile &g, int tid, lean_inputs &in, bool fake = false) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // every load of a lane in flight before the first is used
+        const int v = i * NT + tid;
+        in.cp[i] = in.cm[i] = 0.0;
+        in.ch[i] = 'A';
+        if (fake) {  // ablation builds: what the kernel costs without its HBM reads
+            in.cp[i] = (double)((v * 7 + g.t0) % 20);
+            in.cm[i] = (double)((v * 13 + g.t0) % 20);
+            in.ch[i] = "ACGT"[(v * 5 + (v >> 3)) & 3];
+            continue;
+        }
+        if (v < g.nc) {
+            in.cp[i] = g.gcp[v];
+            in.cm[i] = g.gcm[v];
+        }
+        if (v < g.nc + 6) in.ch[i] = g.gsq[v];
+    }
+}
+
+// phase A of one tile: counts -> packed 16-bit integers, sequence -> two bit planes (LDS).
+// Returns true if this lane saw an input outside the case the kernel handles.
+template <int NT>
+__device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int tid, u32 *pk, u32 *bits0, u32 *bits1) {
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    bool bad = false;
+    if (tid < 8) {
+        pk[tid] = 0;
+        pk[8 + ncs + tid] = 0;
+    }
+    if (tid < 4) {
+        bits0[(ncs >> 5) + tid] = 0;
+        bits1[(ncs >> 5) + tid] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i * NT + wave * kWave >= ncs) break;  // whole tiles: wavefront-uniform
+        const int v = i * NT + tid;
+        const int ip = (int)in.cp[i], im = (int)in.cm[i];
+        bad |= !((double)ip == in.cp[i]) | !((double)im == in.cm[i]) | ((u32)ip > kCountMax) | ((u32)im > kCountMax);
+        pk[8 + v] = (u32)ip | ((u32)im << 16);
+        const u32 ch = in.ch[i], up = ch & 0xDFu;
+        bad |= !((up == 'A') | (up == 'C') | (up == 'G') | (up == 'T'));
+        const unsigned long long m0 = __ballot((ch & 2u) != 0), m1 = __ballot((ch & 4u) != 0);
+        if (lane == 0) {
+            *reinterpret_cast<unsigned long long *>(bits0 + ((i * NT + wave * kWave) >> 5)) = m0;
+            *reinterpret_cast<unsigned long long *>(bits1 + ((i * NT + wave * kWave) >> 5)) = m1;
+        }
+    }
+    return bad;
+}
+
+// Persistent, software-pipelined workgroups: workgroup b walks tiles b, b + gridDim.x, ... of the
+// launch.  The inputs of its next tile are requested before phase E of the current one and moved
+// waited for after phase E's arithmetic, BEFORE any of the tile's stores is issued: a wavefront's
+// memory counter retires in order, so a wait for loads also waits for every store issued before
+// it -- with all stores of a tile (exp, obs, p and the window p-values of up to kHeld scales, held
+// in registers meanwhile) behind that wait, it covers loads only, and they have had the whole of
+// phase E to arrive.  Phase A of the next tile (registers -> LDS) follows the stores.
+constexpr int kHeld = 5;
+template <int NT>
+__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
+    typedef lean_lds<NT> LY;
+    extern __shared__ double smem[];
+    double *PP = smem + LY::oPP, *PM = smem + LY::oPM, *Z = smem + LY::oZB, *rowtot = smem + LY::oRT;
+    double *C = rowtot + 64;
+    u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
+    u32 *bits0 = words + LY::oB0, *bits1 = words + LY::oB1, *pk = words + LY::oPK, *Wp = words + LY::oWP;
+    u32 *psP = words + LY::oSP, *psM = words + LY::oSM;
+    u32 *xP = words + LY::oXP, *xPs = words + LY::oXPs, *xM = words + LY::oXM, *xMs = words + LY::oXMs;
+    constexpr int NROW = NT / 16;
+    // Z[16 + i] = prefix sum of z up to base i within its row of 16, C[1 + row] = sum of the rows
+    // before; Z[15] = C[0] = 0 stand for "before the first base", and the slot kEdge holds a
+    // prefix of -1e4, which makes the window p-value of a base near the interval's edge come out
+    // as exactly 1.0 (windowing.pyx:51) without a select: ndtr(+1e4 / sqrt(K)) = 1.
+    constexpr int kEdge = NT + 32 + 15;  // row NROW + 2: C[NROW + 2] = 0
+
+    typedef const __attribute__((address_space(4))) lean_args kargs;
+    kargs *ka = (kargs *)__builtin_amdgcn_kernarg_segment_ptr();
+
+    int64_t tile = a_.tile_first + blockIdx.x;
+    if (tile >= a_.tile_end) return;
+    lean_tile g = lean_geometry(a_, tile);
+    lean_inputs in;
+    lean_load<NT>(g, threadIdx.x, in, a_.stop == 5 || a_.stop == 6);
+    bool bad = lean_stage<NT>(in, g.ncs, threadIdx.x, pk, bits0, bits1);
+    if (threadIdx.x == 0) {
+        Z[15] = 0.0;
+        Z[kEdge] = -1e4;
+        C[0] = 0.0;
+        C[NROW + 2] = 0.0;
+    }
+
+    for (;;) {
+    // The arguments through a reference into the kernel-argument segment whose pointer passes an
+    // empty asm every iteration, and the lane index likewise: otherwise the optimiser hoists every
+    // argument load and every piece of lane-index arithmetic out of the tile loop and keeps them
+    // alive across the whole body (40 more vector registers, scalar registers spilled).
+    asm volatile("" : "+s"(ka));
+    kargs &a = *ka;
+    kcoef *kc = &ka->c;
+    const int tid = opaque_tid(), lane = tid & (kWave - 1), wave = tid >> 6;
+    const int t0 = g.t0, tl = g.tl, L = g.L, ta = g.ta, nt = g.nt, ncs = g.ncs;
+    const int64_t out_off = g.out_off;
+    const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
+    __syncthreads();  // phase A of this tile (done behind phase E of the previous one) is visible
+    if (LEAN_STOP(1)) return;
+
+    // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i * NT + wave * kWave >= ncs) break;
+        const int v = i * NT + tid;
+        const int w32 = v >> 5, sh = v & 31;
+        const u32 f0 = __builtin_amdgcn_alignbit(bits0[w32 + 1], bits0[w32], sh) & 63u;
+        const u32 f1 = __builtin_amdgcn_alignbit(bits1[w32 + 1], bits1[w32], sh) & 63u;
+        const double2 tt = a.table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+        const u32 *pw = pk + 8 + v - kHW;
+        u32 W = pw[0];
+#pragma unroll
+        for (int j = 1; j < 2 * kHW; ++j) W += pw[j];
+        Wp[v] = W;
+        const int vr = v + (kWave - 1) - 2 * lane;  // the tile mirrored: suffix scans are prefix scans of it
+        const u32 Wr = Wp[vr];
+        const u32 wp = W & 0xffffu, wm = W >> 16, rp = Wr & 0xffffu, rm = Wr >> 16;
+        psP[v] = (u32)wave_scan_i32((int)wp);
+        psM[v] = (u32)wave_scan_i32((int)wm);
+        xP[v] = wave_scan_umax(0xffffu - wp) | (wave_scan_umax(wp) << 16);
+        xM[v] = wave_scan_umax(0xffffu - wm) | (wave_scan_umax(wm) << 16);
+        xPs[vr] = wave_scan_umax(0xffffu - rp) | (wave_scan_umax(rp) << 16);
+        xMs[vr] = wave_scan_umax(0xffffu - rm) | (wave_scan_umax(rm) << 16);
+        // a row of 16 equal non-zero window sums (lanes 0..14 equal their right neighbour)?
+        const u32 d = W ^ (u32)__builtin_amdgcn_update_dpp(0, (int)W, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+        constexpr unsigned long long kLast = 0x8000800080008000ull, kFirst = 0x0001000100010001ull;
+        unsigned long long rP = (__ballot((d & 0xffffu) == 0) & __ballot(wp != 0)) | kLast;
+        unsigned long long rM = (__ballot((d >> 16) == 0) & __ballot(wm != 0)) | kLast;
+        rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8;
+        rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8;
+        bad |= ((rP | rM) & kFirst) != 0;
+        PP[v] = tt.x;
+        PM[v] = tt.y;
+    }
+    __syncthreads();
+    if (LEAN_STOP(2)) return;
+
+    // ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands
+    //         ('+' at padded position pad+1+t, '-' at pad+t; detect.py:121-122)
+    double z = 0.0, ex = 0.0, pv = 0.0;
+    u32 k = 0;
+    const int t = ta + tid;
+    const bool mine = tid < nt && t >= t0 && t < t0 + tl && !LEAN_STOP(6);
+    if (tid < nt) {
+        double e2[2];
+#pragma unroll
+        for (int strand = 0; strand < 2; ++strand) {
+            const int v = kPad + tid + (strand ? 0 : 1);
+            const int lo = v - kSHW, hi = v + kSHW;
+            const u32 S = window_sum(strand ? psM : psP, lo, hi);
+            const u32 *xp = strand ? xM : xP, *xs = strand ? xMs : xPs;
+            const int mid = (lo | 63) + 64;  // last position of the tile after lo's
+            const u32 x1 = xs[lo], x2 = xp[hi], x3 = xp[(hi >> 6) == (lo >> 6) + 2 ? mid : hi];
+            const u32 cmin = max(max(x1 & 0xffffu, x2 & 0xffffu), x3 & 0xffffu);  // 0xffff - min
+            const u32 mx = max(max(x1 >> 16, x2 >> 16), x3 >> 16);
+            const double tsum = (double)((S + cmin) - mx - 0xffffu);  // S - min - max
+            const double *P = (strand ? PM : PP) + (kPad + tid + 1 - kHW);  // P[v-hw .. v+hw-1]
+            double q = P[0];
+#pragma unroll
+            for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
+            const double q99 = mul_vs(q, kc->c99);
+            double r = __builtin_amdgcn_rcp(q99);
+            r = fma(fma(-q99, r, 1.0), r, r);
+            r = fma(fma(-q99, r, 1.0), r, r);
+            const double x = (P[kHW] * tsum) * r;  // ~ P/Q * t/99
+            const double fr = x - floor(x);
+            bad |= !(fabs(fr - 0.5) > mul_vs(x, kc->band));  // too close to a tie (or not a number)
+            e2[strand] = floor(x + 0.5);
+        }
+        ex = e2[0] + e2[1];
+        // ---- D: observed count, p-value and z from the (exp, obs) table
+        k = (pk[8 + kPad + 1 + tid] & 0xffffu) + (pk[8 + kPad + tid] >> 16);
+        const u32 ei = (u32)(int)ex;
+        const bool hit = ei < (u32)a.memo_exp && k < (u32)a.memo_obs;
+        const double2 pz = memo[hit ? ei * (u32)a.memo_obs + k : 0u];
+        pv = pz.x;
+        z = pz.y;
+        bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
+    }
+
+    // The next tile's inputs start their way from HBM now, behind the last load this tile waits
+    // for (the table gathers of phases B and D).
+    const int64_t tile_next = tile + gridDim.x;
+    const bool more = tile_next < a.tile_end;
+    if (more) {
+        g = lean_geometry(a, tile_next);
+        lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    }
+
+    // ---- E: Stouffer windows (windowing.h:53-84), arithmetic only: the results of the first
+    //         kHeld scales are stored after the next tile's phase A
+    double held[kHeld];
+    const bool direct = a.n_scales == 1 && a.max_scale <= 8;
+    if (a.n_scales == 0 || LEAN_STOP(3)) {
+        __syncthreads();  // phase D of every wavefront is done with the packed counts
+    } else if (direct) {
+        // one narrow scale (the reference's only one is 3): summed directly, left to right
+        Z[16 + tid] = z;
+        __syncthreads();
+        const int hs = a.scales[0];
+        const bool inside = mine && t >= hs && t < L - hs;
+        double sv = 0.0;
+        if (inside)
+            for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
+        const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
+        bad |= inside && !(fabs(arg) < kc->limit);
+        held[0] = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+    } else {
+        // one workgroup-wide prefix sum of z in two levels: rows of 16 lanes on the DPP path, the
+        // NT/16 row totals scanned by the first wavefront
+        {
+            const double zr = row_scan_f64(z);  // lanes beyond nt hold 0
+            Z[16 + tid] = zr;
+            if ((lane & 15) == 15) rowtot[tid >> 4] = zr;
+        }
+        __syncthreads();
+        if (tid < kWave) {
+            const double tv = tid < NROW ? rowtot[tid] : 0.0;
+            const double inc = wave_scan_f64(tv, 0.0, op_add());
+            if (tid < NROW) C[1 + tid] = inc - tv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < FPT_MAX_SCALES; ++s) {
+            if (s >= a.n_scales) break;
+            const int hs = a.scales[s];
+            const bool inside = mine && t >= hs && t < L - hs;
+            const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
+            const double sv = (Z[hi] + C[hi >> 4]) - (Z[lo] + C[lo >> 4]);
+            const double arg = -(sv * a.scale_rsqrt[s]);
+            bad |= inside && !(fabs(arg) < kc->limit);
+            const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+            if (s < kHeld) held[s] = pw;
+            else if (mine) a.winp_out[(int64_t)s * a.total_bases + out_off + t] = pw;
+        }
+    }
+    if (bad) a.redo[tile] = 1;
+
+    // ---- the prefetched inputs have had phase E to arrive: wait for them here (the empty asm
+    //      "uses" their registers), and only then issue this tile's stores, so that the wait is
+    //      not also a wait for those stores; then phase A of the next tile
+    if (more)
+        asm volatile("" : "+v"(in.cp[0]), "+v"(in.cm[0]), "+v"(in.ch[0]), "+v"(in.cp[1]), "+v"(in.cm[1]), "+v"(in.ch[1]));
+    if (mine) {
+        const int64_t gi = out_off + t;
+        if (a.exp_out) a.exp_out[gi] = ex;
+        if (a.obs_out) a.obs_out[gi] = (double)k;
+        if (a.pval_out) a.pval_out[gi] = pv;
+        if (a.n_scales > 0 && !LEAN_STOP(3)) {
+            double *dst = a.winp_out + gi;
+#pragma unroll
+            for (int s = 0; s < kHeld; ++s)
+                if (s < a.n_scales) dst[(int64_t)s * a.total_bases] = held[s];
+        }
+    }
+    bad = false;
+    if (more) bad = lean_stage<NT>(in, g.ncs, tid, pk, bits0, bits1);
+    if (!more) break;
+    tile = tile_next;
+    }
+}
+
+template __global__ void k_scan_lean<256>(const lean_args);
+template __global__ void k_scan_lean<512>(const lean_args);
+template __global__ void k_scan_lean<1024>(const lean_args);
+
+typedef void (*lean_kernel_t)(const lean_args);
+lean_kernel_t lean_kernel(int nt) {
+    return nt == 256 ? k_scan_lean<256> : (nt == 512 ? k_scan_lean<512> : k_scan_lean<1024>);
+}
+
+}  // namespace
+
+namespace fptk {
+
+size_t scan_lean_lds_bytes(int nt) {
+    return nt == 256 ? lean_lds<256>::bytes : (nt == 512 ? lean_lds<512>::bytes : lean_lds<1024>::bytes);
+}
+
+hipError_t scan_lean_set_lds(int nt) {
+    return hipFuncSetAttribute((const void *)lean_kernel(nt), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)scan_lean_lds_bytes(nt));
+}
+
+bool scan_lean_applies(const scan_launch &sl) {
+    if (sl.hw != kHW || sl.shw != kSHW || sl.k_trim != 1 || !sl.memo || !sl.redo || sl.counts_only || !sl.table2)
+        return false;
+    if (sl.memo_exp < 1 || sl.memo_obs < 1 || (int64_t)sl.memo_exp * sl.memo_obs > 0x7fffffff) return false;
+    for (int i = 0; i < sl.n_scales; ++i)
+        if (sl.scales[i] > 200) return false;
+    return true;
+}
+
+void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
+    lean_args a;
+    a.interval_len = sl.interval_len;
+    a.interval_off = sl.interval_off;
+    a.tile_iv = sl.tile_iv;
+    a.tile_t0 = sl.tile_t0;
+    a.tile_tl = sl.tile_tl;
+    a.tile_first = sl.tile_first;
+    a.tile_end = sl.tile_first + grid;
+    a.tiles_per_interval = sl.tiles_per_interval;
+    a.tile_len = sl.tile_len;
+    a.n_scales = sl.n_scales;
+    a.max_scale = 0;
+    for (int i = 0; i < FPT_MAX_SCALES; ++i) {
+        a.scales[i] = i < sl.n_scales ? sl.scales[i] : 0;
+        // 1/sqrt(K): the reference divides by sqrt(K) (windowing.h:64); multiplying by the
+        // reciprocal moves z by an ulp, far inside the 1e-6 contract on the window p-value
+        a.scale_rsqrt[i] = i < sl.n_scales ? 1.0 / sqrt((double)(2 * sl.scales[i] + 1)) : 1.0;
+        if (i < sl.n_scales && sl.scales[i] > a.max_scale) a.max_scale = sl.scales[i];
+    }
+    a.total_bases = sl.total_bases;
+    a.counts_plus = sl.counts_plus;
+    a.counts_minus = sl.counts_minus;
+    a.seq = sl.seq;
+    a.table2 = (const double2 *)sl.table2;
+    a.exp_out = sl.exp_out;
+    a.obs_out = sl.obs_out;
+    a.pval_out = sl.pval_out;
+    a.winp_out = sl.winp_out;
+    a.memo = (const double2 *)sl.memo;
+    a.memo_exp = sl.memo_exp;
+    a.memo_obs = sl.memo_obs;
+    a.redo = sl.redo;
+    a.dm_ids = sl.dm_ids;
+    a.stop = sl.ablate;
+    const double g[18] = {FPT_NDTR_G_LIST}, e[11] = {FPT_NDTR_E_LIST};
+    for (int i = 0; i < 18; ++i) a.c.g[i] = g[i];
+    for (int i = 0; i < 11; ++i) a.c.e[i] = e[i];
+    a.c.neg_r0 = -fptm::kNdtrR0;
+    a.c.neg_half_log2e = fptm::kNdtrNegHalfLog2e;
+    a.c.neg_ln2_hi = -fptm::kNdtrLn2Hi;
+    a.c.neg_ln2_lo = -fptm::kNdtrLn2Lo;
+    a.c.c99 = (double)(kW - 2);
+    a.c.band = 1e-13;
+    a.c.limit = fptm::kNdtrFastLimit;
+    // persistent workgroups: as many as the device holds at once (by LDS: 160 KB per CU, and 32
+    // wavefronts per CU), each walking the tiles of the launch with stride gridDim.x
+    const size_t lds = scan_lean_lds_bytes(nt);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2048 / nt) per_cu = 2048 / nt;
+    const int cap = (sl.n_cu > 0 ? sl.n_cu : 256) * (per_cu > 0 ? per_cu : 1);
+    hipLaunchKernelGGL(lean_kernel(nt), dim3(grid < cap ? grid : cap), dim3(nt), lds, st, a);
+}
+
+// The bias table in the order the lean kernel indexes it: entry F = plane0 | plane1 << 6, where bit
+// m of plane0 / plane1 is bit 1 / bit 2 of the ASCII code of base m of the 6-mer (A=00 C=01 T=10
+// G=11).  .x = table[6-mer] (bias.py:101-111), .y = table[reverse complement of the 6-mer]
+// (predict.pyx:47-61,150-153), both in the reference's A<C<G<T base-4 order.
+void build_lean_table(const double *table4096, double *out8192) {
+    static const int kStd[4] = {0, 1, 3, 2};  // plane code -> A0 C1 G2 T3
+    for (int F = 0; F < 4096; ++F) {
+        int fwd = 0, rev = 0;
+        for (int m = 0; m < 6; ++m) {
+            const int b = kStd[((F >> m) & 1) | (((F >> (6 + m)) & 1) << 1)];
+            fwd = fwd * 4 + b;              // base m is digit 5-m
+            rev += (3 - b) << (2 * m);      // complement of base m is digit m of the reverse complement
+        }
+        out8192[2 * F] = table4096[fwd];
+        out8192[2 * F + 1] = table4096[rev];
+    }
+}
+
+}  // namespace fptk

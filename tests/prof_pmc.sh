@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         kn = row["Kernel_Name"]
-        if "scan_fused" in kn or "fdr_null" in kn:
+        if "scan_fused" in kn or "scan_lean" in kn or "fdr_null" in kn:
             m = re.search(r"<(.*?)>", kn)
             agg[kn.split("<")[0].split("(")[0] + "<" + (m.group(1) if m else "") + ">"][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kn in sorted(agg):

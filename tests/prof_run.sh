@@ -37,7 +37,7 @@ print("== rocprofv3 --pmc passes, per dispatch (mean over dispatches), by kernel
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "scan_fused" in row["Kernel_Name"]:
+        if "scan_fused" in row["Kernel_Name"] or "scan_lean" in row["Kernel_Name"]:
             per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 agg = collections.defaultdict(float)
 for name in sorted(per):

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Developer aid: compile fpt_kernels.hip to gfx950 assembly and print, per kernel, registers,
 scratch, LDS and static instruction counts (VALU / SALU / LDS / VMEM).  Usage:
-    python tools/kernel_stats.py [substring-of-kernel-name]"""
+    python tools/kernel_stats.py [substring-of-kernel-name [source-file]]"""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/fpt_kernels.s"
+SRC = sys.argv[2] if len(sys.argv) > 2 else "fpt_kernels.hip"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
                        "-disable-machine-licm", "-S", "--cuda-device-only", "-x", "hip",
-                       os.path.join(ROOT, "footprint_tools_amd", "csrc", "fpt_kernels.hip"), "-o", out],
+                       os.path.join(ROOT, "footprint_tools_amd", "csrc", SRC), "-o", out],
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
