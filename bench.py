@@ -313,7 +313,8 @@ def main():
                         # north_star's wording is the HBM-READ roofline: the same launch priced on
                         # its algorithmic read bytes only (frac above counts reads + writes)
                         achieved_read=achieved_read, frac_read=achieved_read / HBM_PEAK_GBS,
-                        kernel=("k_scan_fused<NT,HW,SHW,table=L2,memo_only> (first pass of the step)"
+                        kernel=("k_scan_lean<NT> (first pass of the step; tiles outside its case are redone by "
+                                "k_scan_fused<NT,5,50,table=L2,full>)"
                                 if args.nb_mode == "memo" else "k_scan_fused<NT,HW,SHW,table=L2,full>"),
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),

@@ -522,9 +522,8 @@ FPT_HD double ndtr_fast(double a) {
     const double t = fabs(a);
     const double d = t + 5.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(d);  // v_rcp_f64 seed, two Newton steps to full precision
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
+    double r = __builtin_amdgcn_rcp(d);  // v_rcp_f64 is good to 2^-24 (measured 4.6e-8): one
+    r = fma(fma(-d, r, 1.0), r, r);      // Newton step leaves 2.2e-15, which g passes on damped
 #else
     const double r = 1.0 / d;
 #endif

@@ -35,6 +35,7 @@
 #include "fpt_kernels.hpp"
 
 #include <cstddef>
+#include <cstdlib>
 
 #include "fpt_device.hpp"
 
@@ -62,7 +63,7 @@ struct lean_args {
     const int32_t *tile_iv;      // ragged: tile table
     const int32_t *tile_t0;
     const int32_t *tile_tl;
-    int64_t tile_first, tile_end;  // tiles of this launch: workgroup b takes b, b + gridDim.x, ...
+    int64_t tile_first;
     int32_t tiles_per_interval, tile_len;
     int32_t n_scales;
     int32_t scales[FPT_MAX_SCALES];
@@ -139,8 +140,7 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     asm volatile("" : "+s"(c) : "v"(a));
     const double t = fabs(a);
     const double d = t + 5.0;
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
+    double r = __builtin_amdgcn_rcp(d);  // 2^-24 (measured 4.6e-8); one Newton step: 2.2e-15
     r = fma(fma(-d, r, 1.0), r, r);
     const double g = horner17_s(add_vs(r, c->neg_r0), c->g);
     asm volatile("" : "+s"(c) : "v"(g));
@@ -186,13 +186,6 @@ __device__ __forceinline__ u32 window_sum(const u32 *ps, int lo, int hi) {
     const int e1 = (q << 6) + 63, e2 = e1 + 64;
     const u32 s2 = ps[(hi >> 6) == q + 2 ? e2 : below];  // a middle tile, or a term that cancels
     return (ps[hi] - ps[below]) + ps[e1] + ((hi >> 6) == q + 2 ? s2 : 0u);
-}
-
-// threadIdx.x through an empty asm (see the tile loop of k_scan_lean)
-__device__ __forceinline__ int opaque_tid() {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
 }
 
 // geometry of one tile: output bases [t0, t0+tl) of interval iv, widened by the largest Stouffer
@@ -311,16 +304,15 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
     return bad;
 }
 
-// Persistent, software-pipelined workgroups: workgroup b walks tiles b, b + gridDim.x, ... of the
-// launch.  The inputs of its next tile are requested before phase E of the current one and moved
-// waited for after phase E's arithmetic, BEFORE any of the tile's stores is issued: a wavefront's
-// memory counter retires in order, so a wait for loads also waits for every store issued before
-// it -- with all stores of a tile (exp, obs, p and the window p-values of up to kHeld scales, held
-// in registers meanwhile) behind that wait, it covers loads only, and they have had the whole of
-// phase E to arrive.  Phase A of the next tile (registers -> LDS) follows the stores.
-constexpr int kHeld = 5;
+// One tile per workgroup; the hardware dispatcher overlaps the load phase of one workgroup with the
+// arithmetic of the other one resident on the compute unit.  Persistent workgroups walking the
+// tiles with the next tile's inputs prefetched into registers (before phase E, with and without
+// all of a tile's stores held back behind the wait for them) were measured on config 3 at
+// 29.4-30.0 ms against 27.3 ms for this form, and 22.9 against 19.8 ms with loads and stores
+// ablated: workgroups that start together stay in step, so both residents of a compute unit
+// reach their barriers and their memory phases at the same time.
 template <int NT>
-__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
+__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     typedef lean_lds<NT> LY;
     extern __shared__ double smem[];
     double *PP = smem + LY::oPP, *PM = smem + LY::oPM, *Z = smem + LY::oZB, *rowtot = smem + LY::oRT;
@@ -337,34 +329,25 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
     constexpr int kEdge = NT + 32 + 15;  // row NROW + 2: C[NROW + 2] = 0
 
     typedef const __attribute__((address_space(4))) lean_args kargs;
-    kargs *ka = (kargs *)__builtin_amdgcn_kernarg_segment_ptr();
+    kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int64_t tile = a.tile_first + blockIdx.x;
+    const lean_tile g = lean_geometry(a, tile);
+    const int t0 = g.t0, tl = g.tl, L = g.L, ta = g.ta, nt = g.nt, ncs = g.ncs;
+    const int64_t out_off = g.out_off;
+    const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
 
-    int64_t tile = a_.tile_first + blockIdx.x;
-    if (tile >= a_.tile_end) return;
-    lean_tile g = lean_geometry(a_, tile);
+    // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
     lean_inputs in;
-    lean_load<NT>(g, threadIdx.x, in, a_.stop == 5 || a_.stop == 6);
-    bool bad = lean_stage<NT>(in, g.ncs, threadIdx.x, pk, bits0, bits1);
-    if (threadIdx.x == 0) {
+    lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    bool bad = lean_stage<NT>(in, ncs, tid, pk, bits0, bits1);  // outside the case this kernel handles?
+    if (tid == 0) {
         Z[15] = 0.0;
         Z[kEdge] = -1e4;
         C[0] = 0.0;
         C[NROW + 2] = 0.0;
     }
-
-    for (;;) {
-    // The arguments through a reference into the kernel-argument segment whose pointer passes an
-    // empty asm every iteration, and the lane index likewise: otherwise the optimiser hoists every
-    // argument load and every piece of lane-index arithmetic out of the tile loop and keeps them
-    // alive across the whole body (40 more vector registers, scalar registers spilled).
-    asm volatile("" : "+s"(ka));
-    kargs &a = *ka;
-    kcoef *kc = &ka->c;
-    const int tid = opaque_tid(), lane = tid & (kWave - 1), wave = tid >> 6;
-    const int t0 = g.t0, tl = g.tl, L = g.L, ta = g.ta, nt = g.nt, ncs = g.ncs;
-    const int64_t out_off = g.out_off;
-    const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
-    __syncthreads();  // phase A of this tile (done behind phase E of the previous one) is visible
+    __syncthreads();
     if (LEAN_STOP(1)) return;
 
     // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums
@@ -406,8 +389,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
 
     // ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands
     //         ('+' at padded position pad+1+t, '-' at pad+t; detect.py:121-122)
-    double z = 0.0, ex = 0.0, pv = 0.0;
-    u32 k = 0;
+    double z = 0.0;
     const int t = ta + tid;
     const bool mine = tid < nt && t >= t0 && t < t0 + tl && !LEAN_STOP(6);
     if (tid < nt) {
@@ -428,41 +410,32 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
 #pragma unroll
             for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
             const double q99 = mul_vs(q, kc->c99);
-            double r = __builtin_amdgcn_rcp(q99);
-            r = fma(fma(-q99, r, 1.0), r, r);
+            double r = __builtin_amdgcn_rcp(q99);  // 2^-24; one Newton step: 2e-15, far inside the band
             r = fma(fma(-q99, r, 1.0), r, r);
             const double x = (P[kHW] * tsum) * r;  // ~ P/Q * t/99
             const double fr = x - floor(x);
             bad |= !(fabs(fr - 0.5) > mul_vs(x, kc->band));  // too close to a tie (or not a number)
             e2[strand] = floor(x + 0.5);
         }
-        ex = e2[0] + e2[1];
+        const double ex = e2[0] + e2[1];
         // ---- D: observed count, p-value and z from the (exp, obs) table
-        k = (pk[8 + kPad + 1 + tid] & 0xffffu) + (pk[8 + kPad + tid] >> 16);
+        const u32 k = (pk[8 + kPad + 1 + tid] & 0xffffu) + (pk[8 + kPad + tid] >> 16);
         const u32 ei = (u32)(int)ex;
         const bool hit = ei < (u32)a.memo_exp && k < (u32)a.memo_obs;
         const double2 pz = memo[hit ? ei * (u32)a.memo_obs + k : 0u];
-        pv = pz.x;
         z = pz.y;
         bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
+        if (mine) {
+            const int64_t gi = out_off + t;
+            if (a.exp_out) a.exp_out[gi] = ex;
+            if (a.obs_out) a.obs_out[gi] = (double)k;
+            if (a.pval_out) a.pval_out[gi] = pz.x;
+        }
     }
 
-    // The next tile's inputs start their way from HBM now, behind the last load this tile waits
-    // for (the table gathers of phases B and D).
-    const int64_t tile_next = tile + gridDim.x;
-    const bool more = tile_next < a.tile_end;
-    if (more) {
-        g = lean_geometry(a, tile_next);
-        lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
-    }
-
-    // ---- E: Stouffer windows (windowing.h:53-84), arithmetic only: the results of the first
-    //         kHeld scales are stored after the next tile's phase A
-    double held[kHeld];
-    const bool direct = a.n_scales == 1 && a.max_scale <= 8;
+    // ---- E: Stouffer windows (windowing.h:53-84)
     if (a.n_scales == 0 || LEAN_STOP(3)) {
-        __syncthreads();  // phase D of every wavefront is done with the packed counts
-    } else if (direct) {
+    } else if (a.n_scales == 1 && a.max_scale <= 8) {
         // one narrow scale (the reference's only one is 3): summed directly, left to right
         Z[16 + tid] = z;
         __syncthreads();
@@ -473,7 +446,8 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
             for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
         const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
         bad |= inside && !(fabs(arg) < kc->limit);
-        held[0] = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+        const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+        if (mine) a.winp_out[out_off + t] = pw;
     } else {
         // one workgroup-wide prefix sum of z in two levels: rows of 16 lanes on the DPP path, the
         // NT/16 row totals scanned by the first wavefront
@@ -489,9 +463,8 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
             if (tid < NROW) C[1 + tid] = inc - tv;
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < FPT_MAX_SCALES; ++s) {
-            if (s >= a.n_scales) break;
+        double *dst = a.winp_out + out_off + t;
+        for (int s = 0; s < a.n_scales; ++s) {
             const int hs = a.scales[s];
             const bool inside = mine && t >= hs && t < L - hs;
             const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
@@ -499,39 +472,11 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a_) {
             const double arg = -(sv * a.scale_rsqrt[s]);
             bad |= inside && !(fabs(arg) < kc->limit);
             const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
-            if (s < kHeld) held[s] = pw;
-            else if (mine) a.winp_out[(int64_t)s * a.total_bases + out_off + t] = pw;
+            if (mine) dst[(int64_t)s * a.total_bases] = pw;
         }
     }
     if (bad) a.redo[tile] = 1;
-
-    // ---- the prefetched inputs have had phase E to arrive: wait for them here (the empty asm
-    //      "uses" their registers), and only then issue this tile's stores, so that the wait is
-    //      not also a wait for those stores; then phase A of the next tile
-    if (more)
-        asm volatile("" : "+v"(in.cp[0]), "+v"(in.cm[0]), "+v"(in.ch[0]), "+v"(in.cp[1]), "+v"(in.cm[1]), "+v"(in.ch[1]));
-    if (mine) {
-        const int64_t gi = out_off + t;
-        if (a.exp_out) a.exp_out[gi] = ex;
-        if (a.obs_out) a.obs_out[gi] = (double)k;
-        if (a.pval_out) a.pval_out[gi] = pv;
-        if (a.n_scales > 0 && !LEAN_STOP(3)) {
-            double *dst = a.winp_out + gi;
-#pragma unroll
-            for (int s = 0; s < kHeld; ++s)
-                if (s < a.n_scales) dst[(int64_t)s * a.total_bases] = held[s];
-        }
-    }
-    bad = false;
-    if (more) bad = lean_stage<NT>(in, g.ncs, tid, pk, bits0, bits1);
-    if (!more) break;
-    tile = tile_next;
-    }
 }
-
-template __global__ void k_scan_lean<256>(const lean_args);
-template __global__ void k_scan_lean<512>(const lean_args);
-template __global__ void k_scan_lean<1024>(const lean_args);
 
 typedef void (*lean_kernel_t)(const lean_args);
 lean_kernel_t lean_kernel(int nt) {
@@ -568,7 +513,6 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.tile_t0 = sl.tile_t0;
     a.tile_tl = sl.tile_tl;
     a.tile_first = sl.tile_first;
-    a.tile_end = sl.tile_first + grid;
     a.tiles_per_interval = sl.tiles_per_interval;
     a.tile_len = sl.tile_len;
     a.n_scales = sl.n_scales;
@@ -605,13 +549,7 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.c.c99 = (double)(kW - 2);
     a.c.band = 1e-13;
     a.c.limit = fptm::kNdtrFastLimit;
-    // persistent workgroups: as many as the device holds at once (by LDS: 160 KB per CU, and 32
-    // wavefronts per CU), each walking the tiles of the launch with stride gridDim.x
-    const size_t lds = scan_lean_lds_bytes(nt);
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2048 / nt) per_cu = 2048 / nt;
-    const int cap = (sl.n_cu > 0 ? sl.n_cu : 256) * (per_cu > 0 ? per_cu : 1);
-    hipLaunchKernelGGL(lean_kernel(nt), dim3(grid < cap ? grid : cap), dim3(nt), lds, st, a);
+    hipLaunchKernelGGL(lean_kernel(nt), dim3(grid), dim3(nt), scan_lean_lds_bytes(nt), st, a);
 }
 
 // The bias table in the order the lean kernel indexes it: entry F = plane0 | plane1 << 6, where bit
