@@ -20,7 +20,7 @@ EXPORTS = [
     "fpt_last_error", "fpt_version", "fpt_device_count", "fpt_ctx_create", "fpt_ctx_destroy",
     "fpt_ctx_set_stream", "fpt_ctx_use_own_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
-    "fpt_scan_dev", "fpt_synth_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
+    "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
     "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
@@ -128,6 +128,8 @@ def load():
         L.fpt_segment_count_dev.argtypes = [vp, C.POINTER(SegmentDesc), C.POINTER(C.c_int64)]
         L.fpt_segment_fill_dev.argtypes = [vp, C.POINTER(SegmentDesc), i64, vp, vp, vp, vp]
         L.fpt_synth_dev.argtypes = [vp, C.c_uint64, i64, i64, vp, vp, i64, i64, vp]
+        L.fpt_scan_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32 * 2)]
+        L.fpt_synth_hotspots_dev.argtypes = [vp, C.c_uint64, i64, i64, i32, i32, vp, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
         L.fpt_dev_alloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.fpt_dev_free.argtypes = [vp, vp]
@@ -253,6 +255,13 @@ class Context(object):
             check(self.L.fpt_ctx_use_own_stream(self.h))
         else:
             check(self.L.fpt_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
+    def scan_stats(self):
+        """(tiles, tiles redone by the general kernel, (max exp, max obs) that missed the first-level
+        table) of the most recent memo-mode scan; synchronises."""
+        t, r, m = C.c_int64(0), C.c_int64(0), (C.c_int32 * 2)(-1, -1)
+        check(self.L.fpt_scan_stats(self.h, C.byref(t), C.byref(r), C.byref(m)))
+        return t.value, r.value, (m[0], m[1])
 
     def timing_enable(self, max_records):
         check(self.L.fpt_timing_enable(self.h, int(max_records)))

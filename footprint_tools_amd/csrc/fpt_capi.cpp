@@ -60,6 +60,9 @@ struct fpt_ctx {
     int tev_used = 0;
     int n_cu = 0;
     int memo_exp = 256, memo_obs = 256;
+    // second-level table of the redo pass: capacity (entries beyond what a batch needs are never
+    // computed), 16 bytes per entry and model; batches with more models than memo2_models skip it
+    int memo2_rows = 1024, memo2_stride = 4096, memo2_models = 4;
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
@@ -73,6 +76,8 @@ struct fpt_ctx {
     int plan_H = -1;
     int64_t plan_tiles = 0;
     int64_t plan_cls_count[3] = {0, 0, 0};
+    int64_t last_tiles = 0;      // tiles of the most recent memo-mode scan (fpt_scan_stats)
+    bool last_has_redo = false;
 };
 
 namespace {
@@ -569,7 +574,19 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     sl.memo_exp = c->memo_exp;
     sl.memo_obs = c->memo_obs;
 
+    // second-level table (built between the two passes, sized on the device by what the first
+    // pass missed): only with the lean first pass, which records those maxima
+    void *d_memo2 = nullptr;
+    int32_t *d_miss = c->d_flags + 8;
+    if (use_memo && sl.table_global && c->use_lean && n_dm <= c->memo2_models && fptk::scan_lean_applies_hw(hw, shw, k)) {
+        if (int rc = ws_get(c, 10, (size_t)c->memo2_rows * c->memo2_stride * 16 * n_dm, &d_memo2)) return rc;
+        sl.memo2 = d_memo2;
+        sl.memo2_max = d_miss;
+        sl.memo2_rows = c->memo2_rows;
+        sl.memo2_stride = c->memo2_stride;
+    }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used] : c->ev0, c->stream));
+    if (d_memo2) HIP_TRY(hipMemsetAsync(d_miss, 0xff, 2 * sizeof(int32_t), c->stream));  // -1, -1
     if (use_memo) {  // rebuilt on every call: part of the timed work, never reused across calls
         fptk::launch_nb_memo(c->stream, sl.model, n_dm, c->memo_exp, c->memo_obs, d_memo);
         if (int rc = launch_ok("k_nb_memo")) return rc;
@@ -611,10 +628,32 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             }
         }
         if (rec && main_pass) HIP_TRY(hipEventRecord(c->tev[c->tev_used + 2], c->stream));
+        if (memo_only && d_memo2) {  // between the passes: the table for what the first pass missed
+            fptk::launch_nb_memo2(c->stream, sl.model, n_dm, d_miss, c->memo_exp, c->memo_obs, c->memo2_rows,
+                                  c->memo2_stride, d_memo2);
+            if (int rc = launch_ok("k_nb_memo2")) return rc;
+        }
     }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 3] : c->ev1, c->stream));
+    c->last_tiles = tiles_total;
+    c->last_has_redo = d_redo != nullptr;
     if (rec) c->tev_used += 4;
     else c->timed = true;
+    return FPT_OK;
+}
+
+int fpt_scan_stats(fpt_ctx *c, int64_t *tiles_out, int64_t *redone_out, int32_t *miss_max_out) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int64_t redone = 0;
+    if (c->last_has_redo && c->last_tiles > 0 && c->ws[7]) {
+        std::vector<int32_t> flags((size_t)c->last_tiles);
+        HIP_TRY(hipMemcpy(flags.data(), c->ws[7], flags.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int32_t f : flags) redone += f != 0;
+    }
+    if (tiles_out) *tiles_out = c->last_tiles;
+    if (redone_out) *redone_out = redone;
+    if (miss_max_out) HIP_TRY(hipMemcpy(miss_max_out, c->d_flags + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return FPT_OK;
 }
 
@@ -862,6 +901,15 @@ int fpt_synth_dev(fpt_ctx *c, uint64_t seed, int64_t pos0_counts, int64_t n_coun
     if (n_counts < 0 || n_seq < 0) return fail(FPT_ERR_INVALID, "negative length");
     fptk::launch_synth(c->stream, seed, pos0_counts, n_counts, cp, cm, pos0_seq, n_seq, seq);
     return launch_ok("k_synth");
+}
+
+int fpt_synth_hotspots_dev(fpt_ctx *c, uint64_t seed, int64_t pos0_counts, int64_t n_counts, int32_t padded_len,
+                           int32_t per_mille, double *cp, double *cm) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_counts < 0 || padded_len < 1 || per_mille < 0 || per_mille > 1000)
+        return fail(FPT_ERR_INVALID, "bad hotspot parameters");
+    fptk::launch_synth_hotspots(c->stream, seed, pos0_counts, n_counts, padded_len, per_mille, cp, cm);
+    return launch_ok("k_synth_hotspots");
 }
 
 int fpt_checksum_dev(fpt_ctx *c, const double *dev, int64_t n, uint64_t *host_out) {

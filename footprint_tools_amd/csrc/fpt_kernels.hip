@@ -274,6 +274,12 @@ struct scan_args {
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
     const int32_t *dm_ids;       // per interval: dispersion-model slot relative to `model` (or nullptr)
+    // second-level (exp, obs) table of the redo pass: rows of memo2_stride entries, valid for
+    // exp <= memo2_max[0] and obs <= memo2_max[1] (device values: the largest pair the first pass
+    // missed, found without a host round trip), or nullptr
+    const double2 *memo2;
+    const int32_t *memo2_max;
+    int32_t memo2_rows, memo2_stride;
 };
 #ifdef FPT_ABLATE
 #define ABL(bit) (a.ablate & (bit))
@@ -317,6 +323,36 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
         double z = fptm::ndtri(1.0 - pv);
         if (zd) z = __longlong_as_double(kZeroDivZBits);
         memo[idx] = make_double2(pv, z);
+    }
+}
+
+// Second-level table for the redo pass of memo mode: the (exp, obs) pairs up to the largest pair
+// the first pass missed (maxima left on the device by that pass: no host round trip), except the
+// corner the first-level table already holds.  Heavy-tailed data (hotspots with counts in the
+// hundreds) would otherwise send every base of a flagged tile through the direct incbet.
+__global__ void __launch_bounds__(256, 4) k_nb_memo2(const double *__restrict__ models, const int32_t *__restrict__ mx,
+                                                     int memo_exp, int memo_obs, int rows, int stride,
+                                                     double2 *__restrict__ memos) {
+    __shared__ double par[24];
+    const double *model = models + (size_t)blockIdx.y * 24;
+    double2 *memo = memos + (size_t)blockIdx.y * rows * stride;
+    if (threadIdx.x < 24) par[threadIdx.x] = model[threadIdx.x];
+    __syncthreads();
+    const int ne = min(mx[0] + 1, rows), nk = min(mx[1] + 1, stride);
+    if (ne <= 0 || nk <= 0) return;
+    // one entry per thread, then the next block row: no loop around the incbet body (see k_nb_values)
+    const long long n = (long long)ne * nk;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int ei = (int)(idx / nk), k = (int)(idx % nk);
+        if (ei < memo_exp && k < memo_obs) continue;  // first-level table
+        bool zd = false;
+        const double ex = (double)ei;
+        double r = fptm::fit_r(par + 9, ex, &zd);
+        double mu = fptm::fit_mu(par, ex);
+        double pv = fptm::nb_cdf(k, r / (r + mu), r);
+        double z = fptm::ndtri(1.0 - pv);
+        if (zd) z = __longlong_as_double(kZeroDivZBits);
+        memo[(size_t)ei * stride + k] = make_double2(pv, z);
     }
 }
 
@@ -848,6 +884,13 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
         } else if (MO) {
             pv = z = NAN;
             a.redo[tile] = 1;  // the full instance recomputes this tile
+        } else if (a.memo2 && ex >= 0.0 && ex < (double)a.memo2_rows && (double)ei == ex && k >= 0 &&
+                   k < a.memo2_stride && ei <= a.memo2_max[0] && k <= a.memo2_max[1]) {
+            // second-level table, built between the passes for the pairs the first pass missed
+            const double2 pz = a.memo2[((size_t)dm * a.memo2_rows + ei) * a.memo2_stride + k];
+            pv = pz.x;
+            z = pz.y;
+            zd = __double_as_longlong(z) == kZeroDivZBits;
         } else {
             const double r = fptm::fit_r(par + 9, ex, &zd);
             const double mu = fptm::fit_mu(par, ex);
@@ -1656,6 +1699,32 @@ __global__ void __launch_bounds__(256) k_synth_counts(uint64_t key, int64_t pos0
     }
 }
 
+// Hotspot bursts on top of the uniform counts (heavy-tailed workload: real DNase data has
+// hotspots with counts in the hundreds): interval iv = position / padded_len carries one with
+// probability per_mille / 1000 -- a triangular bump of 80..199 positions and peak 100..499 per
+// strand, plus 0..15 of noise -- decided by a hash of (seed, iv), so every strand, rank and the
+// oracle see the same hotspots.
+__global__ void __launch_bounds__(256) k_synth_hotspots(uint64_t key_iv, uint64_t key_noise, int64_t pos0, int64_t n,
+                                                        int32_t padded_len, int32_t per_mille,
+                                                        double *__restrict__ counts) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = pos0 + i;
+        const int64_t iv = p / padded_len;
+        const int u = (int)(p - iv * padded_len);
+        const uint64_t hv = splitmix64(key_iv + (uint64_t)iv);
+        if ((int)(hv % 1000u) >= per_mille) continue;
+        const int width = 80 + (int)((hv >> 40) % 120u), half = width / 2;
+        const int span = padded_len - 2 * half > 1 ? padded_len - 2 * half : 1;
+        const int centre = half + (int)((hv >> 20) % (uint64_t)span);
+        const int dist = u > centre ? u - centre : centre - u;
+        if (dist >= half) continue;
+        const int peak = 100 + (int)((hv >> 10) % 400u);
+        const uint64_t hn = splitmix64(key_noise + (uint64_t)p);
+        counts[i] += (double)((peak * (half - dist)) / half + (int)((hn >> 7) & 15u));
+    }
+}
+
 __global__ void __launch_bounds__(256) k_synth_bases(uint64_t key, int64_t pos0, int64_t n,
                                                      uint8_t *__restrict__ out) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1817,6 +1886,10 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.counts_only = sl.counts_only;
     a.redo = sl.redo;
     a.dm_ids = sl.dm_ids;
+    a.memo2 = (const double2 *)sl.memo2;
+    a.memo2_max = sl.memo2_max;
+    a.memo2_rows = sl.memo2_rows;
+    a.memo2_stride = sl.memo2_stride;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
     a.tile_end = sl.tile_first + (int64_t)grid;
     const bool second_pass = sl.redo && !memo_only;
@@ -1830,6 +1903,12 @@ void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo
     int n = memo_exp * memo_obs;
     hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256, n_models), dim3(256), 0, st, models, memo_exp,
                        memo_obs, (double2 *)memo);
+}
+
+void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
+                     int memo_obs, int rows, int stride, void *memo2) {
+    hipLaunchKernelGGL(k_nb_memo2, dim3(1024, n_models), dim3(256), 0, st, models, miss_max, memo_exp, memo_obs, rows,
+                       stride, (double2 *)memo2);
 }
 
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {
@@ -1945,6 +2024,24 @@ void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_
     if (seq && n_seq > 0)
         hipLaunchKernelGGL(k_synth_bases, dim3(grid_for(n_seq, 256, 4096)), dim3(256), 0, st,
                            mix(seed + 2), pos0_seq, n_seq, seq);
+}
+
+void launch_synth_hotspots(hipStream_t st, uint64_t seed, int64_t pos0, int64_t n, int padded_len, int per_mille,
+                           double *counts_plus, double *counts_minus) {
+    auto mix = [](uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    if (n <= 0) return;
+    if (counts_plus)
+        hipLaunchKernelGGL(k_synth_hotspots, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, mix(seed + 7),
+                           mix(seed + 8), pos0, n, padded_len, per_mille, counts_plus);
+    if (counts_minus)
+        hipLaunchKernelGGL(k_synth_hotspots, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, mix(seed + 7),
+                           mix(seed + 9), pos0, n, padded_len, per_mille, counts_minus);
 }
 
 void launch_checksum(hipStream_t st, const double *x, int64_t n, unsigned long long *out) {

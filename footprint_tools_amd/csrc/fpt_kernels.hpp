@@ -37,11 +37,16 @@ struct scan_launch {
     const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
     const void *table2;    // bias table in the lean kernel's order (build_lean_table), or nullptr
-    int32_t n_cu;          // compute units of the device (sizes the persistent grid of the lean kernel)
+    int32_t n_cu;          // compute units of the device
+    // second-level (exp, obs) table of the redo pass (launch_nb_memo2), or nullptr
+    const void *memo2;
+    int32_t *memo2_max;    // device: [0] largest exp, [1] largest obs the first pass missed (-1: none)
+    int32_t memo2_rows, memo2_stride;
 };
 
 // fpt_scan_lean.hip: the first pass of memo mode for the `detect` defaults (hw 5, shw 50, clip 0.01)
 bool scan_lean_applies(const scan_launch &sl);
+bool scan_lean_applies_hw(int hw, int shw, int k_trim);
 size_t scan_lean_lds_bytes(int nt);
 hipError_t scan_lean_set_lds(int nt);
 void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl);
@@ -107,11 +112,15 @@ size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
 hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, bool second_pass, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo);
+void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
+                     int memo_obs, int rows, int stride, void *memo2);
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
                    unsigned long long *hist);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);
+void launch_synth_hotspots(hipStream_t st, uint64_t seed, int64_t pos0, int64_t n, int padded_len, int per_mille,
+                           double *counts_plus, double *counts_minus);
 void launch_checksum(hipStream_t st, const double *x, int64_t n, unsigned long long *out);
 
 }  // namespace fptk

@@ -77,6 +77,8 @@ struct lean_args {
     const double2 *memo;
     int32_t memo_exp, memo_obs;
     int32_t *redo;
+    int32_t *miss_max;  // [0] largest exp, [1] largest obs among the pairs that missed the table
+    int32_t miss_rows, miss_stride;  // ... as far as the second-level table could hold them
     const int32_t *dm_ids;
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
     lean_coef c;
@@ -425,6 +427,10 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         const double2 pz = memo[hit ? ei * (u32)a.memo_obs + k : 0u];
         z = pz.y;
         bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
+        if (!hit && a.miss_max && ei < (u32)a.miss_rows && k < (u32)a.miss_stride) {
+            atomicMax(&a.miss_max[0], (int)ei);  // sizes the second-level table of the redo pass
+            atomicMax(&a.miss_max[1], (int)k);
+        }
         if (mine) {
             const int64_t gi = out_off + t;
             if (a.exp_out) a.exp_out[gi] = ex;
@@ -496,6 +502,8 @@ hipError_t scan_lean_set_lds(int nt) {
                                (int)scan_lean_lds_bytes(nt));
 }
 
+bool scan_lean_applies_hw(int hw, int shw, int k_trim) { return hw == kHW && shw == kSHW && k_trim == 1; }
+
 bool scan_lean_applies(const scan_launch &sl) {
     if (sl.hw != kHW || sl.shw != kSHW || sl.k_trim != 1 || !sl.memo || !sl.redo || sl.counts_only || !sl.table2)
         return false;
@@ -537,6 +545,9 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.memo_exp = sl.memo_exp;
     a.memo_obs = sl.memo_obs;
     a.redo = sl.redo;
+    a.miss_max = sl.memo2 ? sl.memo2_max : nullptr;
+    a.miss_rows = sl.memo2_rows;
+    a.miss_stride = sl.memo2_stride;
     a.dm_ids = sl.dm_ids;
     a.stop = sl.ablate;
     const double g[18] = {FPT_NDTR_G_LIST}, e[11] = {FPT_NDTR_E_LIST};

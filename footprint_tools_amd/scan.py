@@ -351,6 +351,14 @@ class FootprintScanner(object):
                                             counts_plus, counts_minus, first_interval * (lp + 6),
                                             n_intervals * (lp + 6), seq))
 
+    def synth_hotspots_dev(self, seed, n_intervals, interval_len, counts_plus, counts_minus, per_mille,
+                           first_interval=0):
+        """Heavy-tailed variant of the synthetic workload: add hotspot bursts (peaks of 100..499
+        cuts per strand in `per_mille`/1000 of the intervals) to counts made by synth_dev."""
+        lp = self.padded_len(interval_len)
+        _lib.check(self.ctx.L.fpt_synth_hotspots_dev(self.ctx.h, int(seed), first_interval * lp, n_intervals * lp,
+                                                     lp, int(per_mille), counts_plus, counts_minus))
+
     def checksum_dev(self, ptr, n):
         out = C.c_uint64()
         _lib.check(self.ctx.L.fpt_checksum_dev(self.ctx.h, ptr, int(n), C.byref(out)))

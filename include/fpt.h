@@ -274,6 +274,20 @@ int fpt_synth_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int64_t n_co
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);
 
+/* Diagnostics of the most recent fpt_scan_dev in memo mode (synchronises): tiles launched, tiles
+ * the first pass handed to the general kernel, and the largest (exp, obs) pair that missed the
+ * first-level table (-1, -1: none; what sized the second-level table). */
+int fpt_scan_stats(fpt_ctx *ctx, int64_t *tiles_out, int64_t *redone_out, int32_t miss_max_out[2]);
+
+/* Heavy-tailed variant of the synthetic workload: adds hotspot bursts to counts made by
+ * fpt_synth_dev (in place).  Interval iv = position / padded_len carries a hotspot with probability
+ * per_mille / 1000: a triangular bump 80..199 positions wide with a peak of 100..499 cuts per
+ * strand (observed counts up to ~1000, far outside the first-level (exp, obs) table), decided by
+ * a hash of (seed, iv) so that both strands, every rank and the CPU oracle agree. */
+int fpt_synth_hotspots_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int64_t n_counts,
+                           int32_t padded_len, int32_t per_mille, double *counts_plus,
+                           double *counts_minus);
+
 /* 64-bit order-independent checksum (sum of value bit patterns mod 2^64) of a device track,
  * written to *host_out after synchronising; for size-independent parity checks. */
 int fpt_checksum_dev(fpt_ctx *ctx, const double *dev, int64_t n, uint64_t *host_out);

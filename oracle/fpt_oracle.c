@@ -1060,6 +1060,27 @@ void orc_synth_fill(uint64_t seed, int64_t pos0, int64_t n, int stream, double *
     }
 }
 
+/* Hotspot bursts of the heavy-tailed workload (include/fpt.h: fpt_synth_hotspots_dev), added in
+ * place to counts of stream 0 ('+') or 1 ('-'). */
+void orc_synth_hotspots(uint64_t seed, int64_t pos0, int64_t n, int stream, int padded_len, int per_mille,
+                        double *counts) {
+    const uint64_t key_iv = orc_splitmix64(seed + 7), key_noise = orc_splitmix64(seed + 8 + (uint64_t)stream);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t p = pos0 + i, iv = p / padded_len;
+        const int u = (int)(p - iv * padded_len);
+        const uint64_t hv = orc_splitmix64(key_iv + (uint64_t)iv);
+        if ((int)(hv % 1000u) >= per_mille) continue;
+        const int width = 80 + (int)((hv >> 40) % 120u), half = width / 2;
+        const int span = padded_len - 2 * half > 1 ? padded_len - 2 * half : 1;
+        const int centre = half + (int)((hv >> 20) % (uint64_t)span);
+        const int dist = u > centre ? u - centre : centre - u;
+        if (dist >= half) continue;
+        const int peak = 100 + (int)((hv >> 10) % 400u);
+        const uint64_t hn = orc_splitmix64(key_noise + (uint64_t)p);
+        counts[i] += (double)((peak * (half - dist)) / half + (int)((hn >> 7) & 15u));
+    }
+}
+
 /* ------------------------------------------------------------------ empirical FDR with the
  * library's reproducible null sampler (cli/detect.py:132-135 with the NB draws taken by
  * inverse-CDF from Philox uniforms instead of numpy's MT19937; see include/fpt.h fpt_fdr_dev) */

@@ -114,6 +114,8 @@ void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *ex
 
 /* ---- synthetic inputs (bench-defined): splitmix64 counter hash */
 uint64_t orc_splitmix64(uint64_t x);
+void orc_synth_hotspots(uint64_t seed, int64_t pos0, int64_t n, int stream, int padded_len, int per_mille,
+                        double *counts);
 void orc_synth_fill(uint64_t seed, int64_t pos0, int64_t n, int stream, double *counts,
                     uint8_t *bases);
 

@@ -247,6 +247,14 @@ def synth_counts(seed, pos0, n, stream):
     return out
 
 
+def synth_hotspots(counts, seed, pos0, stream, padded_len, per_mille):
+    """Add the hotspot bursts of the heavy-tailed workload to `counts` (in place; stream 0 / 1)."""
+    L = lib()
+    L.orc_synth_hotspots.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_synth_hotspots(seed, pos0, counts.size, stream, padded_len, per_mille, counts.ctypes.data)
+    return counts
+
+
 def synth_bases(seed, pos0, n):
     out = np.empty(n, np.uint8)
     lib().orc_synth_fill(seed, pos0, n, 2, None, out.ctypes.data)

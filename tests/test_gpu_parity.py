@@ -559,6 +559,60 @@ def test_full_size_config3_properties(fpt, orc):
         d.free()
 
 
+def test_heavy_tailed_workload(fpt, orc):
+    """Hotspot bursts (observed counts up to ~1000, expected counts in the hundreds: far outside the
+    256 x 256 first-level table): the first pass hands those tiles to the general kernel, which reads
+    a second-level table sized on the device by the largest pair that missed.  Everything equals the
+    oracle, and identical bits come out with the second-level table switched off (direct incbet)."""
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = fpt.get_ctx()
+    n_iv, L, hw, shw, clip, scales, per_mille = 3000, 500, 5, 50, 0.01, (3, 10, 40), 100
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales, nb_mode="memo")
+    l = sc.padded_len(L)
+    total = n_iv * L
+    t8 = total * 8
+    S = len(scales)
+    d_cp, d_cm = DeviceArray(ctx, n_iv * l * 8), DeviceArray(ctx, n_iv * l * 8)
+    d_sq = DeviceArray(ctx, n_iv * (l + 6))
+    d_out = DeviceArray(ctx, (3 + S) * t8)
+    sc.synth_dev(5, n_iv, L, d_cp.ptr, d_cm.ptr, d_sq.ptr)
+    sc.synth_hotspots_dev(5, n_iv, L, d_cp.ptr, d_cm.ptr, per_mille)
+    sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr, d_out.ptr + t8, d_out.ptr + 2 * t8,
+                d_out.ptr + 3 * t8, interval_len=L)
+    tiles, redone, miss = ctx.scan_stats()
+    assert tiles == n_iv and 0.05 * n_iv < redone < 0.2 * n_iv, (tiles, redone)
+    assert miss[0] >= 256 or miss[1] >= 256, miss
+    cp = orc.synth_hotspots(orc.synth_counts(5, 0, n_iv * l, 0), 5, 0, 0, l, per_mille)
+    cm = orc.synth_hotspots(orc.synth_counts(5, 0, n_iv * l, 1), 5, 0, 1, l, per_mille)
+    sq = orc.synth_bases(5, 0, n_iv * (l + 6))
+    assert np.array_equal(d_cp.download(np.float64, n_iv * l), cp)
+    assert np.array_equal(d_cm.download(np.float64, n_iv * l), cm)
+    assert cp.max() > 300
+    e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, clip, table, lat["mu_A"], lat["r_A"],
+                                   np.array(scales, np.int32), n_threads=8)
+    got = d_out.download(np.float64, (3 + S) * total).reshape(3 + S, total)
+    assert np.array_equal(got[0], e) and np.array_equal(got[1], o)
+    assert o.max() > 600 and e.max() > 256
+    assert rel_err(got[2], p) < P_TOL
+    for s in range(S):
+        assert rel_err(got[3 + s], wp[s]) < P_TOL
+    # the same batch through the direct evaluation: identical bits
+    sc2 = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales, nb_mode="direct")
+    d_o2 = DeviceArray(ctx, (3 + S) * t8)
+    sc2.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_o2.ptr, d_o2.ptr + t8, d_o2.ptr + 2 * t8,
+                 d_o2.ptr + 3 * t8, interval_len=L)
+    ctx.synchronize()
+    got2 = d_o2.download(np.float64, (3 + S) * total).reshape(3 + S, total)
+    for k in range(3):
+        assert np.array_equal(got[k], got2[k], equal_nan=True), k
+    for s in range(S):  # window p-values: the lean pass and the general kernel sum z in different orders
+        assert rel_err(got[3 + s], got2[3 + s]) < 1e-9
+    for d in (d_cp, d_cm, d_sq, d_out, d_o2):
+        d.free()
+
+
 # ---------------------------------------------------------------- reference API flow (notebook cell 4)
 def test_reference_api_flow(fpt, orc, tmp_path):
     from footprint_tools_amd.modeling import bias, dispersion, predict
