@@ -4,12 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    (the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT: bench.py imports no
+    torch; the collective is RCCL bound by the library itself, footprint_tools_amd/distributed.py)
 
 One step = one pass of the hot path (6-mer lookup -> expected cleavage with trimmed-mean
 smoothing -> NB p-value -> Stouffer windows) over one batch of synthetic intervals that is
 already resident in HBM.  N=1 workload = BASELINE.json configs[2], the largest single-GPU
 configuration (1,000,000 x 1 kb, five Stouffer scales); `--config 2` selects configs[1]
-(100,000 x 500 bp, one scale), `--config 4` one GPU's share of the ragged whole-genome set.  With N>1 every rank
+(100,000 x 500 bp, one scale), `--config 4` the ragged whole-genome set (437,500 intervals per
+GPU, ONE global list cut by scan.shard_intervals, ragged all-gather).  With N>1 every rank
 scans its own shard of N x batch intervals (weak scaling, no data-path collective inside the
 scan) and, after the K steps and still inside the timed region, the per-base p-value track of
 the resident batch is re-assembled on every rank with ONE RCCL all-gather (N x 400 MB for
@@ -129,16 +132,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="N>1 collective backend; gloo is a smoke-test mode for boxes with fewer GPUs "
-                         "than ranks (all ranks share GPU 0, the track is gathered through host memory)")
+    ap.add_argument("--allgather", action="store_true",
+                    help="N=1: run the track all-gather anyway, on a one-rank RCCL communicator")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="smoke-test mode for boxes with fewer GPUs than ranks: every rank uses GPU 0 "
+                         "(RCCL refuses two ranks on one device, so the all-gather is skipped)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d must be launched with one process per GPU, e.g. python -m "
+                 "torch.distributed.run --nproc-per-node %d ... (only RANK / LOCAL_RANK / WORLD_SIZE / "
+                 "MASTER_PORT are read; no torch is imported)" % (args.gpus, args.gpus))
     cfg = CONFIGS[args.config]
     n_iv, L, scales = cfg["n_iv"], cfg["L"], cfg["scales"]
     S = len(scales)
@@ -150,59 +157,58 @@ def main():
         base = cpu_baseline(cfg, table, DM)
 
     from footprint_tools_amd import _lib
-    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
 
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "gloo":
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(0 if args.share_gpu else local_rank)
     sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
+    comm = None
+    do_gather = (world > 1 and not args.no_allgather and not args.share_gpu) or (world == 1 and args.allgather)
+    if (world > 1 and not args.share_gpu) or do_gather:
+        from footprint_tools_amd.distributed import TrackComm
+        comm = TrackComm(ctx, rank, world)  # RCCL, bound by the library; no torch
     ragged = L == 0
+    pad2 = 2 * (HW + SHW)
     if ragged:
-        rs = np.random.RandomState(4 + rank)
-        lens = np.clip(rs.lognormal(4.9, 0.62, n_iv), 50, 2000).astype(np.int64)
+        # ONE global interval list (BASELINE.json configs[3]: the whole-genome DHS set is ~3.5M
+        # intervals / ~600 Mb on 8 GPUs; here n_iv intervals per GPU), cut into contiguous ranges
+        # balanced by padded bases; the synthetic data is a function of the global position, so
+        # the job does not depend on the number of ranks
+        rs = np.random.RandomState(4)
+        lens_all = np.clip(rs.lognormal(4.9, 0.62, n_iv * world), 50, 2000).astype(np.int64)
+        bounds = shard_intervals(lens_all, world, HW + SHW)
+        a_iv, b_iv = bounds[rank]
+        lens = lens_all[a_iv:b_iv]
+        n_iv = int(lens.size)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         total = int(off[-1])
+        counts = [int(lens_all[a:b].sum()) for a, b in bounds]  # bases per rank
+        pos0_counts = int((lens_all[:a_iv] + pad2 + 1).sum())
+        pos0_seq = int((lens_all[:a_iv] + pad2 + 7).sum())
         n_counts, n_seq = sc.input_sizes(n_iv, total)
     else:
         l = sc.padded_len(L)
         total = n_iv * L  # bases per rank per step
+        counts = [total] * world
         n_counts, n_seq = n_iv * l, n_iv * (l + 6)
+    total_all = int(sum(counts))
 
     # ---- resident buffers: inputs generated on the device, outputs written in place
-    if world > 1:
-        dev = torch.device("cuda", local_rank)
-        t_cp = torch.empty(n_counts, dtype=torch.float64, device=dev)
-        t_cm = torch.empty(n_counts, dtype=torch.float64, device=dev)
-        t_sq = torch.empty(n_seq, dtype=torch.uint8, device=dev)
-        t_out = torch.empty((2 + S) * total, dtype=torch.float64, device=dev)   # exp, obs, winp[S]
-        t_p = [torch.empty(total, dtype=torch.float64, device=dev)]  # p-value track of the resident batch
-        t_gather = None if args.no_allgather else torch.empty(
-            world * total, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        p_cp, p_cm, p_sq, p_out = t_cp.data_ptr(), t_cm.data_ptr(), t_sq.data_ptr(), t_out.data_ptr()
-        p_p = [t.data_ptr() for t in t_p]
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    else:
-        d_cp, d_cm = DeviceArray(ctx, n_counts * 8), DeviceArray(ctx, n_counts * 8)
-        d_sq = DeviceArray(ctx, n_seq)
-        d_out = DeviceArray(ctx, (2 + S) * total * 8)
-        d_p = [DeviceArray(ctx, total * 8)]
-        p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
-        p_p = [d_p[0].ptr]
-    # rank r owns intervals [r*n_iv, (r+1)*n_iv) of the global synthetic job
+    d_cp, d_cm = DeviceArray(ctx, n_counts * 8), DeviceArray(ctx, n_counts * 8)
+    d_sq = DeviceArray(ctx, n_seq)
+    d_out = DeviceArray(ctx, (2 + S) * total * 8)   # exp, obs, winp[S]
+    d_gather = DeviceArray(ctx, total_all * 8) if do_gather else None
+    # the p-value track of the resident batch: with a gather it is written straight into its
+    # slice of the gathered track (the collective runs in place)
+    my_off = int(sum(counts[:rank])) * 8
+    d_p = None if do_gather else DeviceArray(ctx, total * 8)
+    p_p = d_gather.ptr + my_off if do_gather else d_p.ptr
+    p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
     d_off = None
     if ragged:
-        _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1 + rank, 0, n_counts, p_cp, p_cm, 0, n_seq, p_sq))
+        _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1, pos0_counts, n_counts, p_cp, p_cm, pos0_seq, n_seq, p_sq))
         d_off = DeviceArray(ctx, off.nbytes).upload(off)
     else:
+        # rank r owns intervals [r*n_iv, (r+1)*n_iv) of the global synthetic job
         sc.synth_dev(1, n_iv, L, p_cp, p_cm, p_sq, first_interval=rank * n_iv)
         if args.hotspots:
             sc.synth_hotspots_dev(1, n_iv, L, p_cp, p_cm, args.hotspots, first_interval=rank * n_iv)
@@ -210,63 +216,57 @@ def main():
 
     t8 = total * 8
 
-    def step(i):
+    def step():
         sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_out, obs_out=p_out + t8,
-                    pval_out=p_p[i % len(p_p)], winp_out=p_out + 2 * t8 if S else None,
+                    pval_out=p_p, winp_out=p_out + 2 * t8 if S else None,
                     interval_len=None if ragged else L, interval_off_dev=d_off.ptr if ragged else None,
                     interval_off_host=off if ragged else None)
 
     def sync():
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        else:
-            ctx.synchronize()
-
-    def run_steps(k):
-        for i in range(k):
-            step(i)
+        ctx.synchronize()
+        if comm is not None:
+            comm.barrier()
 
     def gather_track():
         """The one collective of the job: every rank ends up with the whole p-value track."""
-        if world > 1 and not args.no_allgather:
-            last = t_p[(args.steps - 1) % len(t_p)]
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(t_gather, last)
-            else:
-                dist.all_gather_into_tensor(t_gather, last.cpu())
+        if do_gather:
+            comm.allgather_dev(p_p, counts, d_gather.ptr)
 
     def measure(steps, warmup):
-        run_steps(warmup)
-        gather_track()  # also brings the communicator up before the timed region
+        for _ in range(warmup):
+            step()
+        gather_track()  # also brings the communicator's channels up before the timed region
         sync()
         ctx.timing_enable(steps)
         t0 = time.perf_counter()
-        run_steps(steps)
+        for _ in range(steps):
+            step()
+        ctx.synchronize()
+        t1 = time.perf_counter()  # scans done on this rank; the collective follows
         gather_track()
         sync()
+        t2 = time.perf_counter()
         seq_ms, main_ms = ctx.timing_read()
-        return time.perf_counter() - t0, main_ms, seq_ms
+        return t2 - t0, main_ms, seq_ms, t1 - t0, t2 - t1
 
-    dt, kernel_ms, seq_ms = measure(args.steps, args.warmup)
+    dt, kernel_ms, seq_ms, dt_scan, dt_gather = measure(args.steps, args.warmup)
     other = None
     if world == 1 and not args.no_other_mode:  # the other evaluation mode, reported beside the headline
         main_mode = sc.nb_mode
         sc.nb_mode = _lib.NB_DIRECT if args.nb_mode == "memo" else _lib.NB_MEMO
         k2 = max(3, args.steps // 4)
-        dt2, kms2, _ = measure(k2, 1)
+        dt2, kms2 = measure(k2, 1)[:2]
         other = dict(nb_pvalue="direct incbet per base" if args.nb_mode == "memo" else "memo table",
                      value=total * k2 / dt2, unit="bases/s", ms_per_step=dt2 / k2 * 1e3,
                      kernel_ms=float(np.mean(kms2)), steps=k2)
         sc.nb_mode = main_mode
-        step(args.steps - 1)  # leave the headline mode's outputs in the buffers for the parity check
+        step()  # leave the headline mode's outputs in the buffers for the parity check
         sync()
 
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if comm is not None:  # the contract: the slowest rank's time
+        dt = comm.max_over_ranks(dt)
+        dt_scan = comm.max_over_ranks(dt_scan)
+        dt_gather = comm.max_over_ranks(dt_gather)
 
     # ---- parity spot check outside the timed region (oracle = checker only)
     parity = None
@@ -274,11 +274,11 @@ def main():
         from oracle import oracle
         iv = n_iv - 1
         if ragged:
-            Li, pad2 = int(lens[iv]), 2 * (HW + SHW)
+            Li = int(lens[iv])
             li = Li + pad2 + 1
-            c0, s0 = int(off[iv]) + iv * (pad2 + 1), int(off[iv]) + iv * (pad2 + 7)
-            cp, cm = oracle.synth_counts(1 + rank, c0, li, 0), oracle.synth_counts(1 + rank, c0, li, 1)
-            sq = oracle.synth_bases(1 + rank, s0, li + 6)
+            c0, s0 = pos0_counts + int(off[iv]) + iv * (pad2 + 1), pos0_seq + int(off[iv]) + iv * (pad2 + 7)
+            cp, cm = oracle.synth_counts(1, c0, li, 0), oracle.synth_counts(1, c0, li, 1)
+            sq = oracle.synth_bases(1, s0, li + 6)
             o0 = int(off[iv])
         else:
             Li, g0 = L, rank * n_iv + iv
@@ -291,16 +291,29 @@ def main():
             o0 = iv * L
         e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, Li, HW, SHW, CLIP, table, DM.mu_params,
                                           DM.r_params, scales)
-        last = (args.steps - 1) % len(p_p)
-        if world > 1:
-            torch.cuda.synchronize()
-            ge = t_out[o0:o0 + Li].cpu().numpy()
-            gp = t_p[last][o0:o0 + Li].cpu().numpy()
-        else:
-            ge = d_out.download(np.float64, Li, o0 * 8)
-            gp = d_p[0].download(np.float64, Li, o0 * 8)
+        ge = d_out.download(np.float64, Li, o0 * 8)
+        src = d_gather if do_gather else d_p
+        gp = src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
         rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
         parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
+        if do_gather and world > 1:  # the gathered track holds the other ranks' slices too
+            r2 = world - 1
+            if ragged:
+                a2, b2 = bounds[r2]
+                iv2 = b2 - 1
+                L2 = int(lens_all[iv2])
+                c2 = int((lens_all[:iv2] + pad2 + 1).sum())
+                s2 = int((lens_all[:iv2] + pad2 + 7).sum())
+                o2 = int(lens_all[:iv2].sum())
+            else:
+                L2, g2 = L, r2 * n_iv + n_iv - 1
+                c2, s2, o2 = g2 * l, g2 * (l + 6), g2 * L
+            cp, cm = oracle.synth_counts(1, c2, L2 + pad2 + 1, 0), oracle.synth_counts(1, c2, L2 + pad2 + 1, 1)
+            sq = oracle.synth_bases(1, s2, L2 + pad2 + 7)
+            p2 = oracle.detect_batch(cp, cm, sq, 1, L2, HW, SHW, CLIP, table, DM.mu_params, DM.r_params, scales)[2]
+            g2p = d_gather.download(np.float64, L2, o2 * 8)
+            parity["gathered_last_rank_p_max_rel_err"] = float(
+                np.nanmax(np.abs(g2p - p2) / np.maximum(np.abs(p2), 1e-300)))
 
     # ---- robustness of memo mode: tiles the first pass handed on, and (N=1) the same job with
     #      hotspot bursts in 2 % of the intervals, timed beside the headline
@@ -314,12 +327,12 @@ def main():
         pm = 20
         sc.synth_hotspots_dev(1, n_iv, L, p_cp, p_cm, pm)
         kh = max(3, args.steps // 4)
-        dth, kmsh, seqh = measure(kh, 1)
+        dth = measure(kh, 1)[0]
         tiles, redone, miss = ctx.scan_stats()
         heavy = dict(workload=cfg["name"] + "+hotspots_%dpermille" % pm, value=total * kh / dth, unit="bases/s",
                      ms_per_step=dth / kh * 1e3, steps=kh, tiles=tiles, tiles_redone=redone,
                      redone_fraction=redone / max(tiles, 1), largest_pair_outside_first_table=list(miss),
-                     ratio_to_headline=(total * kh / dth) / (world * total * args.steps / dt),
+                     ratio_to_headline=(total * kh / dth) / (total_all * args.steps / dt),
                      note="observed counts up to ~1000 in the hotspots; the redo pass reads a second-level "
                           "(exp, obs) table sized on the device by the largest pair the first pass missed")
 
@@ -353,7 +366,7 @@ def main():
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))
         out = {
             "metric": "bases/sec per-nucleotide footprint stats",
-            "value": world * total * args.steps / dt,
+            "value": total_all * args.steps / dt,
             "unit": "bases/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -364,16 +377,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": cfg["name"] + ("+hotspots_%dpermille" % args.hotspots if args.hotspots else ""), "intervals_per_gpu": n_iv, "interval_bp": L if not ragged else "lognormal, mean %.0f, [50,2000]" % (total / n_iv),
+            "config": {"workload": cfg["name"] + ("+hotspots_%dpermille" % args.hotspots if args.hotspots else ""),
+                       "intervals_per_gpu": n_iv if not ragged else cfg["n_iv"],
+                       "interval_bp": L if not ragged else "lognormal, mean %.0f, [50,2000]" % (total_all / lens_all.size),
                        "half_win_width": HW, "smoothing_half_win_width": SHW, "smoothing_clip": CLIP,
                        "stouffer_half_widths": list(scales), "bias_model": "vierstra_et_al.6mer",
                        "dispersion_model": "DM-SYNTH-A",
                        "nb_pvalue": ("exact (exp,obs)->(p,z) memo table, 256x256, rebuilt by the device "
-                                     "incbet inside every step; direct incbet fallback outside it"
+                                     "incbet inside every step; second-level table / direct incbet outside it"
                                      if args.nb_mode == "memo" else "direct incbet per base"),
-                       "allgather_p_track": bool(world > 1 and not args.no_allgather),
-                       "allgather_backend": (args.backend if world > 1 else None)},
+                       "sharding": ("one global interval list cut into contiguous ranges balanced by padded bases"
+                                    if ragged else "rank r owns intervals [r*n, (r+1)*n) of the global job"),
+                       "allgather_p_track": bool(do_gather),
+                       "allgather": ("RCCL (librccl.so bound by libfpt_hip, no torch), %s, once after the %d steps, "
+                                     "inside the timed region" % ("ragged shards: grouped ncclBroadcast" if ragged
+                                                                  else "ncclAllGather", args.steps))
+                       if do_gather else None},
             "roofline": roof,
+            "multi_gpu": (dict(scan_s=dt_scan, allgather_s=dt_gather, allgather_bytes_per_rank=total_all * 8,
+                               allgather_GBps_per_rank=(total_all * 8 / dt_gather / 1e9 if dt_gather > 0 else None),
+                               bases_per_rank=counts)
+                          if (world > 1 or do_gather) else None),
             "cpu_baseline": base,
             "other_nb_mode": other,
             "memo_robustness": robust,
@@ -381,9 +405,9 @@ def main():
             "parity": parity,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

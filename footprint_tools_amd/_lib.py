@@ -22,6 +22,7 @@ EXPORTS = [
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
+    "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
     "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
@@ -128,6 +129,10 @@ def load():
         L.fpt_segment_count_dev.argtypes = [vp, C.POINTER(SegmentDesc), C.POINTER(C.c_int64)]
         L.fpt_segment_fill_dev.argtypes = [vp, C.POINTER(SegmentDesc), i64, vp, vp, vp, vp]
         L.fpt_synth_dev.argtypes = [vp, C.c_uint64, i64, i64, vp, vp, i64, i64, vp]
+        L.fpt_comm_unique_id.argtypes = [vp]
+        L.fpt_comm_init.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.fpt_comm_destroy.argtypes = [vp]
+        L.fpt_allgather_track.argtypes = [vp, vp, vp, vp, vp]
         L.fpt_scan_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32 * 2)]
         L.fpt_synth_hotspots_dev.argtypes = [vp, C.c_uint64, i64, i64, i32, i32, vp, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]

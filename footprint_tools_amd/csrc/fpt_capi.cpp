@@ -128,6 +128,19 @@ int trim_k(int shw, double clip) {
 
 }  // namespace
 
+// shared with fpt_comm.cpp (hidden visibility: not part of the C ABI)
+int fpt_internal_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+hipStream_t fpt_internal_stream(fpt_ctx *c) { return c->stream; }
+int fpt_internal_check_ctx(fpt_ctx *c) { return check_ctx(c); }
+
 extern "C" {
 #pragma GCC visibility push(default)
 

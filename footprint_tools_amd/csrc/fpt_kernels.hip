@@ -1702,8 +1702,8 @@ __global__ void __launch_bounds__(256) k_synth_counts(uint64_t key, int64_t pos0
 // Hotspot bursts on top of the uniform counts (heavy-tailed workload: real DNase data has
 // hotspots with counts in the hundreds): interval iv = position / padded_len carries one with
 // probability per_mille / 1000 -- a triangular bump of 80..199 positions and peak 100..499 per
-// strand, plus 0..15 of noise -- decided by a hash of (seed, iv), so every strand, rank and the
-// oracle see the same hotspots.
+// strand, plus 0..15 of noise -- decided by a hash of (seed, iv), so every strand, every rank and
+// the CPU checker see the same hotspots.
 __global__ void __launch_bounds__(256) k_synth_hotspots(uint64_t key_iv, uint64_t key_noise, int64_t pos0, int64_t n,
                                                         int32_t padded_len, int32_t per_mille,
                                                         double *__restrict__ counts) {

@@ -1,13 +1,30 @@
-"""Interval-sharded scans across the GPUs of one node (one process per GPU).
+"""Interval-sharded scans across the GPUs of one node: one process and one context per GPU.
 
-Intervals are independent (every window is confined to its own padded interval), so a batch is
+Intervals are independent (every window is confined to its own padded interval), so a job is
 split into contiguous interval ranges balanced by padded bases (`scan.shard_intervals`), every
 rank scans its own range with no communication, and the per-base statistics track is
-re-assembled on every rank with ONE collective at the end: an all-gather over RCCL/xGMI
-(`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" works for CPU tensors in tests).
-PyTorch is only plumbing here (process group, device tensors); the scan itself is libfpt_hip.
+re-assembled on every rank with ONE collective at the end: an all-gather over RCCL / xGMI.
+
+RCCL is bound directly by the library (`fpt_comm_*`, `fpt_allgather_track` in include/fpt.h;
+librccl.so through dlopen) -- no PyTorch, no MPI.  The only thing the host program has to carry
+between the processes is the 128-byte communicator id that rank 0 makes; `TrackComm` does that
+through a file (the ranks of one node share /tmp), keyed by the launcher's MASTER_PORT and the
+parent process id, or by FPT_COMM_FILE.  Barriers and the max-over-ranks of a timing are tiny
+all-gathers on the same communicator.
+
+Reference counterpart: cli/detect.py:380-411 -- worker processes (`batch_iter(num_workers=...)`)
+compute per-interval statistics and one writer thread formats them.  `sharded_deviation_stats`
+is that shape with GPUs for workers: every rank computes its shard, the statistics are gathered,
+rank 0 writes.
 """
+import ctypes as C
+import os
+import time
+
 import numpy as np
+
+from . import _lib
+from .scan import DeviceArray, shard_intervals
 
 
 def shard_track_sizes(lengths, bounds):
@@ -16,14 +33,176 @@ def shard_track_sizes(lengths, bounds):
     return [int(lengths[a:b].sum()) for a, b in bounds]
 
 
-def allgather_track(local, sizes, group=None):
-    """All-gather the ranks' track slices into the whole track (returned on every rank).
+def rank_info():
+    """(rank, world_size, local_rank) from the launcher's environment (torch.distributed.run,
+    mpirun or the caller's own): RANK / WORLD_SIZE / LOCAL_RANK, defaults 0 / 1 / rank."""
+    rank = int(os.environ.get("RANK", os.environ.get("OMPI_COMM_WORLD_RANK", "0")))
+    world = int(os.environ.get("WORLD_SIZE", os.environ.get("OMPI_COMM_WORLD_SIZE", "1")))
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("OMPI_COMM_WORLD_LOCAL_RANK", str(rank))))
+    return rank, world, local
 
-    local : 1-D torch tensor holding this rank's slice (sizes[rank] elements), on the device
-            the process group communicates from (CUDA for nccl/RCCL, CPU for gloo).
-    sizes : per-rank slice lengths in rank order.
-    Equal slices use all_gather_into_tensor directly; ragged slices are padded to the longest
-    one (the equal-count form of the collective) and trimmed afterwards."""
+
+def _id_path():
+    p = os.environ.get("FPT_COMM_FILE")
+    if p:
+        return p
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                        "fpt_comm_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+
+
+class TrackComm(object):
+    """RCCL communicator of the job's ranks, for the track all-gather (and barriers / timing).
+
+    ctx   : this rank's _lib.Context (its GPU)
+    rank, world : default from the environment (rank_info)
+    path  : file through which rank 0 hands the communicator id to the others
+    """
+
+    def __init__(self, ctx, rank=None, world=None, path=None, timeout_s=300.0):
+        r, w, _ = rank_info()
+        self.ctx, self.L = ctx, ctx.L
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        path = path or _id_path()
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _lib.check(self.L.fpt_comm_unique_id(ident))
+            if self.world > 1:
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "wb") as f:
+                    f.write(bytes(ident))
+                os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError("no communicator id at %s after %.0f s" % (path, timeout_s))
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                raw = f.read()
+            if len(raw) != 128:
+                raise IOError("communicator id file %s is damaged" % path)
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        # RCCL prints a version banner on stdout while rank 0 initialises; programs that print
+        # a result on stdout (bench.py: ONE JSON line) get it on stderr instead
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = self.L.fpt_comm_init(ctx.h, ident, self.world, self.rank, C.byref(h))
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        _lib.check(rc)
+        self.h = h
+        self._scratch = DeviceArray(ctx, 8 * (self.world + 1))
+        self._path = path
+        self.barrier()
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.synchronize()
+            self.L.fpt_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the collective
+    def allgather_dev(self, send_ptr, counts, recv_ptr):
+        """Enqueue the all-gather of a per-base track on the context's stream: rank r contributes
+        counts[r] doubles at device pointer send_ptr, every rank receives sum(counts) doubles at
+        recv_ptr in rank order.  Does not synchronise."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if counts.size != self.world:
+            raise ValueError("need one count per rank")
+        _lib.check(self.L.fpt_allgather_track(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr))
+
+    def allgather_host(self, value):
+        """one double per rank -> list of all ranks' values (a tiny all-gather; synchronises)"""
+        mine = np.array([float(value)])
+        _lib.check(self.L.fpt_memcpy_h2d(self.ctx.h, self._scratch.ptr + 8 * self.world, mine.ctypes.data, 8))
+        self.allgather_dev(self._scratch.ptr + 8 * self.world, np.ones(self.world, np.int64), self._scratch.ptr)
+        self.ctx.synchronize()
+        return self._scratch.download(np.float64, self.world).tolist()
+
+    def barrier(self):
+        self.allgather_host(0.0)
+
+    def max_over_ranks(self, value):
+        return max(self.allgather_host(value))
+
+    def allgather_rows(self, local, counts):
+        """Host convenience: `local` is this rank's (counts[rank], k) float64 matrix; returns the
+        (sum(counts), k) matrix of all ranks in rank order (through device memory and RCCL)."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        k = local.shape[1] if local.ndim == 2 else 1
+        counts = np.asarray(counts, dtype=np.int64)
+        if local.size != counts[self.rank] * k:
+            raise ValueError("local block has %d values, expected %d" % (local.size, counts[self.rank] * k))
+        total = int(counts.sum())
+        recv = DeviceArray(self.ctx, max(total * k, 1) * 8)
+        off = int(counts[:self.rank].sum()) * k * 8
+        if local.size:
+            _lib.check(self.L.fpt_memcpy_h2d(self.ctx.h, recv.ptr + off, local.ctypes.data, local.size * 8))
+        self.allgather_dev(recv.ptr + off, counts * k, recv.ptr)  # in place: the slice sits where it belongs
+        self.ctx.synchronize()
+        out = recv.download(np.float64, total * k).reshape(total, k)
+        recv.free()
+        return out
+
+
+def sharded_deviation_stats(intervals, read_func, fasta_func, bm, dm, gather=None, rank=None, world=None,
+                            batch_size=4096, stats_cls=None, **kw):
+    """`detect.deviation_stats` over the ranks of a job (the shape of cli/detect.py:380-411 with
+    GPUs for workers): the interval list is cut into contiguous ranges balanced by padded bases,
+    this rank computes the records of its range, the per-base statistics are gathered, and every
+    rank returns the records of ALL intervals in list order (rank 0 writes them).
+
+    gather(local_matrix, counts) -> full matrix; default: TrackComm(ctx).allgather_rows.
+    stats_cls: the per-rank driver (default detect.deviation_stats; tests pass a CPU stand-in).  The
+    null draws of the FDR pass are keyed by global base index, so the records do not depend on
+    the number of ranks."""
+    if stats_cls is None:
+        from .detect import deviation_stats as stats_cls
+
+    r, w, _ = rank_info()
+    rank = r if rank is None else int(rank)
+    world = w if world is None else int(world)
+    ds = stats_cls(intervals, read_func, fasta_func, bm, dm, batch_size=batch_size, **kw)
+    lens = np.array([iv.end - iv.start for iv in ds.intervals], dtype=np.int64)
+    bounds = shard_intervals(lens, world, ds.padding)
+    a, b = bounds[rank]
+    blocks = []
+    for s in range(a, b, int(batch_size)):
+        blocks += [rec["stats"] for rec in ds.compute(range(s, min(s + int(batch_size), b)))]
+    ncol = 5 if dm else 2
+    local = np.concatenate(blocks) if blocks else np.zeros((0, ncol))
+    counts = shard_track_sizes(lens, bounds)
+    if gather is None:
+        comm = TrackComm(ds._scanner().ctx, rank, world)
+        full = comm.allgather_rows(local, counts)
+        comm.close()
+    else:
+        full = gather(local, counts)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    return [{"interval": iv, "stats": full[off[i]:off[i + 1]]} for i, iv in enumerate(ds.intervals)]
+
+
+def allgather_track(local, sizes, group=None):
+    """torch.distributed form of the same collective, for hosts that already run a process group
+    (and for the CPU test of the host logic with the gloo backend): all-gather the ranks' track
+    slices into the whole track.  Ragged slices are padded to the longest one."""
     import torch
     import torch.distributed as dist
 

@@ -274,6 +274,26 @@ int fpt_synth_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int64_t n_co
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);
 
+/* ---- the one collective of the sharded job (BASELINE.json north_star: "a
+ * single RCCL all-gather over xGMI at the end to reassemble the per-base statistics track").
+ * Intervals shard across GPUs with no communication during the scan (one process and one
+ * context per GPU); afterwards every rank contributes its slice of a per-base track and receives
+ * all slices in rank order.  RCCL is bound directly (librccl.so through dlopen at the first
+ * call): rank 0 makes an id with fpt_comm_unique_id, the host program carries the 128 bytes to
+ * the other ranks (file, socket, environment), every rank calls fpt_comm_init.
+ * Reference counterpart: the worker processes of cli/detect.py:380-411 hand their per-interval
+ * statistics to one writer; nothing in the reference exchanges arrays between devices. */
+#define FPT_COMM_ID_BYTES 128
+typedef struct fpt_comm fpt_comm;
+int fpt_comm_unique_id(uint8_t id_out[FPT_COMM_ID_BYTES]);
+int fpt_comm_init(fpt_ctx *ctx, const uint8_t id[FPT_COMM_ID_BYTES], int world_size, int rank, fpt_comm **out);
+int fpt_comm_destroy(fpt_comm *comm);
+/* counts[r] = doubles contributed by rank r (world_size entries, the same on every rank); send =
+ * this rank's counts[rank] doubles, recv = sum(counts) doubles (device pointers; send may lie
+ * inside recv at its own offset).  Equal counts: one ncclAllGather; ragged: one ncclBroadcast per
+ * shard inside a group.  Enqueued on the context's stream; does not synchronise. */
+int fpt_allgather_track(fpt_ctx *ctx, fpt_comm *comm, const double *send, const int64_t *counts, double *recv);
+
 /* Diagnostics of the most recent fpt_scan_dev in memo mode (synchronises): tiles launched, tiles
  * the first pass handed to the general kernel, and the largest (exp, obs) pair that missed the
  * first-level table (-1, -1: none; what sized the second-level table). */

@@ -54,6 +54,39 @@ full = allgather_track(local, sizes).numpy()
 if rank == 0:
     want = run(0, len(lens))
     assert full.shape == want.shape and np.array_equal(full, want, equal_nan=True), "gathered track differs"
+
+# the sharded detect driver's host logic (range per rank, row gather, records of ALL intervals in
+# list order on every rank) with a CPU stand-in for the per-rank GPU driver
+from footprint_tools_amd.distributed import sharded_deviation_stats
+
+class Iv(object):
+    def __init__(self, i, L):
+        self.chrom, self.start, self.end, self.i = "c", 0, int(L), i
+
+class StubStats(object):
+    def __init__(self, intervals, read_func, fasta_func, bm, dm, batch_size=4096, **kw):
+        self.intervals, self.padding = list(intervals), pad
+    def compute(self, indices):
+        out = []
+        for i in indices:
+            p = run(i, i + 1)
+            out.append({"interval": self.intervals[i], "stats": np.column_stack([p, p * 2, p + 1, p, p])})
+        return out
+
+def gather_rows(local, counts):
+    k = local.shape[1]
+    flat = allgather_track(torch.from_numpy(np.ascontiguousarray(local).ravel()), [c * k for c in counts])
+    return flat.numpy().reshape(-1, k)
+
+ivs = [Iv(i, L) for i, L in enumerate(lens)]
+recs = sharded_deviation_stats(ivs, None, None, None, True, gather=gather_rows, rank=rank, world=world,
+                               batch_size=7, stats_cls=StubStats)
+assert len(recs) == len(ivs)
+for i, rec in enumerate(recs):
+    p = run(i, i + 1)
+    assert rec["interval"] is ivs[i] and rec["stats"].shape == (int(lens[i]), 5)
+    assert np.array_equal(rec["stats"][:, 0], p, equal_nan=True) and np.array_equal(rec["stats"][:, 2], p + 1, equal_nan=True)
+if rank == 0:
     print("OK", mode, bounds, sizes)
 dist.barrier()
 dist.destroy_process_group()

@@ -3,6 +3,8 @@ API) against the golden vectors of the genuine reference and against the CPU ora
 
 Bars (BASELINE.json north_star): 6-mer indices, window extents, obs and the integer-valued
 expected counts bit-exact; p-values / window p-values within 1e-6 relative, NaN masks identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -906,6 +908,69 @@ def test_deviation_stats_driver(fpt, orc, tmp_path):
     rec = detect.deviation_stats(ivs[:1], Reads2(), Fasta(), bm, dm2, hw, shw, 0.01, fdr_shuffle_n=5)[0]
     assert (rec["stats"][:, 0] == 2.0).any()
     assert np.all(rec["stats"][:, 2:4] == 0.0) and np.all(rec["stats"][:, 4] == 1.0)
+
+
+def test_rccl_track_allgather_one_rank(fpt, orc, tmp_path):
+    """The directly bound RCCL collective (fpt_comm_*, fpt_allgather_track) on a one-rank
+    communicator -- all a one-GPU box can run: equal and in-place forms, the host conveniences
+    (barrier, max over ranks, row gather) and the sharded detect driver on top of it."""
+    import itertools
+    from footprint_tools_amd import detect
+    from footprint_tools_amd.distributed import TrackComm, sharded_deviation_stats
+    from footprint_tools_amd.modeling import bias, dispersion
+    from footprint_tools_amd.scan import DeviceArray
+    ctx = fpt.get_ctx()
+    comm = TrackComm(ctx, rank=0, world=1, path=str(tmp_path / "id"))
+    assert comm.allgather_host(3.5) == [3.5] and comm.max_over_ranks(-2.0) == -2.0
+    x = np.random.RandomState(3).rand(100000)
+    d_s, d_r = DeviceArray(ctx, x.nbytes).upload(x), DeviceArray(ctx, x.nbytes)
+    comm.allgather_dev(d_s.ptr, [x.size], d_r.ptr)
+    ctx.synchronize()
+    assert np.array_equal(d_r.download(np.float64, x.size), x)
+    comm.allgather_dev(d_s.ptr, [x.size], d_s.ptr)  # in place
+    ctx.synchronize()
+    assert np.array_equal(d_s.download(np.float64, x.size), x)
+    m = x[:99999].reshape(33333, 3)
+    assert np.array_equal(comm.allgather_rows(m, [33333]), m)
+    with pytest.raises(ValueError):
+        comm.allgather_dev(d_s.ptr, [1, 2], d_r.ptr)
+    comm.close()
+    # the sharded detect driver (one rank = the whole list) equals the plain one
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    bm = bias.bias_model()
+    for j, kk in enumerate(itertools.product("ACGT", repeat=6)):
+        bm["".join(kk)] = float(table[j])
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+    gp, gm = orc.synth_counts(31, 0, 6000, 0), orc.synth_counts(31, 0, 6000, 1)
+    gseq = orc.synth_bases(31, 0, 6000).tobytes().decode()
+
+    class Interval(object):
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end = c, s, e
+
+        def widen(self, w):
+            return Interval(self.chrom, self.start - w, self.end + w)
+
+    class Reads(object):
+        def __getitem__(self, iv):
+            return {"+": gp[iv.start:iv.end], "-": gm[iv.start:iv.end]}
+
+    class Fasta(object):
+        def fetch(self, chrom, s, e):
+            return gseq[s:e]
+
+    ivs = [Interval("chr1", 200, 700), Interval("chr1", 900, 1037), Interval("chr1", 1500, 2750)]
+    kw = dict(half_win_width=5, smoothing_half_win_width=50, smoothing_clip=0.01, fdr_shuffle_n=20, seed=5)
+    want = detect.deviation_stats(ivs, Reads(), Fasta(), bm, dm, **kw).compute(range(3))
+    os.environ["FPT_COMM_FILE"] = str(tmp_path / "id2")
+    try:
+        got = sharded_deviation_stats(ivs, Reads(), Fasta(), bm, dm, rank=0, world=1, **kw)
+    finally:
+        del os.environ["FPT_COMM_FILE"]
+    for a, b in zip(got, want):
+        assert a["interval"] is b["interval"] and np.array_equal(a["stats"], b["stats"], equal_nan=True)
 
 
 def test_exp_obs_histogram(fpt, orc):
