@@ -1,0 +1,205 @@
+"""Cut-count ingestion: alignments -> per-base 5' cleavage counts (footprint_tools/cutcounts.py).
+
+`bamfile` mirrors the reference class of the same name for the part the hot path needs:
+
+    reads = bamfile(path, min_qual=1, remove_dups=False, remove_qcfail=True, offset=(0, -1))
+    reads[interval]  ->  {'+': float64[len], '-': float64[len], 'fragments': []}     (lookup, :274-313)
+
+and adds the batched form the scan consumes: `cut_counts_dev(intervals, pad)` fills the padded CSR
+count arrays of a whole interval list on the device in one kernel launch per batch of reads.
+
+The rule (cutcounts.py:119-145, 196-205, 231-248), applied on the device by k_cut_counts:
+a read counts if it is not QC-fail (remove_qcfail) / duplicate (remove_dups), has MAPQ >= min_qual
+and -- when paired -- is a proper pair and neither secondary nor supplementary; forward reads cut
+at reference_start + offset[0] on '+', reverse reads at reference_end + offset[1] on '-'.
+
+Differences, on purpose: the file is read sequentially by the library's own BGZF/BAM reader
+(htslib / pysam are not available here; no index, no CRAM), all alignments are kept on the device
+after the first pass, and 'fragments' (the fragment intervals the reference also returns; unused
+on this path) is always empty.  Unmapped reads carrying a position are skipped.  Parity of the
+reader is unpinned (no pysam to compare with); the rule itself is pinned by hand-derived vectors
+in tests/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .scan import DeviceArray
+
+
+class ReadError(Exception):
+    ERROR_ALIGNMENT = (0, "Read alignment problematic (QC fail, duplicate, or MAPQ < 1)")
+    ERROR_5PROXIMITY = (1, "Variant too close to 5' end of tag")
+    ERROR_BASEQ = (2, "Base quality < 20")
+    ERROR_GENOTYPE = (3, "Base does not match reference or expected alternate allele")
+    ERROR_MISMATCH = (4, "Read contains too many mismatches")
+
+    def __init__(self, e):
+        self.value = e[0]
+        self.message = e[1]
+
+
+class CutCountDesc(C.Structure):
+    """struct fpt_cutcount_desc of include/fpt.h"""
+    _fields_ = [
+        ("n_reads", C.c_int64), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p), ("ref_end", C.c_void_p),
+        ("flag", C.c_void_p), ("mapq", C.c_void_p),
+        ("offset_plus", C.c_int32), ("offset_minus", C.c_int32),
+        ("min_qual", C.c_int32), ("remove_dups", C.c_int32), ("remove_qcfail", C.c_int32),
+        ("n_intervals", C.c_int64), ("start_key", C.c_void_p), ("maxend_key", C.c_void_p),
+        ("padded_len", C.c_void_p), ("counts_off", C.c_void_p),
+        ("counts_plus", C.c_void_p), ("counts_minus", C.c_void_p),
+    ]
+
+
+def _bind(L):
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.fpt_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fpt_bam_close.argtypes = [vp]
+    L.fpt_bam_n_refs.argtypes = [vp, C.POINTER(i32)]
+    L.fpt_bam_ref.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64)]
+    L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.fpt_cut_counts_dev.argtypes = [vp, C.POINTER(CutCountDesc)]
+    return L
+
+
+def read_alignments(filepath, batch=1 << 20):
+    """One sequential pass over a BAM file: (references, ref_id, start, end, flag, mapq) with
+    references = [(name, length), ...] and the rest numpy arrays over all alignments.  Needs no GPU."""
+    L = _bind(_lib.load())
+    h = C.c_void_p()
+    try:
+        _lib.check(L.fpt_bam_open(str(filepath).encode(), C.byref(h)))
+    except ValueError as e:  # the reference raises IOError("Cannot open BAM file: ...") (cutcounts.py:103)
+        raise IOError(str(e))
+    try:
+        n = C.c_int32()
+        _lib.check(L.fpt_bam_n_refs(h, C.byref(n)))
+        refs = []
+        buf = C.create_string_buffer(1024)
+        for i in range(n.value):
+            ln = C.c_int64()
+            _lib.check(L.fpt_bam_ref(h, i, buf, 1024, C.byref(ln)))
+            refs.append((buf.value.decode(), ln.value))
+        parts = []
+        while True:
+            rid, st, en = (np.empty(batch, np.int32) for _ in range(3))
+            fl, mq = np.empty(batch, np.uint16), np.empty(batch, np.uint8)
+            got = C.c_int64()
+            _lib.check(L.fpt_bam_read(h, batch, rid.ctypes.data, st.ctypes.data, en.ctypes.data, fl.ctypes.data,
+                                      mq.ctypes.data, C.byref(got)))
+            if got.value == 0:
+                break
+            parts.append([a[:got.value] for a in (rid, st, en, fl, mq)])
+        cols = [np.concatenate([p[k] for p in parts]) if parts else np.empty(0, dt)
+                for k, dt in enumerate((np.int32, np.int32, np.int32, np.uint16, np.uint8))]
+        return (refs,) + tuple(cols)
+    finally:
+        L.fpt_bam_close(h)
+
+
+class bamfile(object):
+    """Class to access a BAM file (and convert tags to cleavage counts); cutcounts.py:40-109."""
+
+    def __init__(self, filepath, min_qual=1, remove_dups=False, remove_qcfail=True, offset=(0, -1),
+                 is_cram=False, fasta_reference_filepath=None, ctx=None):
+        if is_cram:
+            raise IOError("Cannot open BAM file: %s (CRAM needs htslib, which this build does not have)" % filepath)
+        self.filepath = filepath
+        self.offset = offset
+        self.min_qual = min_qual
+        self.remove_dups = remove_dups
+        self.remove_qcfail = remove_qcfail
+        self._ctx = ctx
+        self.references, rid, st, en, fl, mq = read_alignments(filepath)
+        self._ref_index = {name: i for i, (name, _) in enumerate(self.references)}
+        self._host = (rid, st, en, fl, mq)
+        self._dev = None
+
+    def close(self):
+        """Closes BAM file"""
+        if self._dev:
+            for d in self._dev:
+                d.free()
+            self._dev = None
+        return True
+
+    @property
+    def n_reads(self):
+        return int(self._host[0].size)
+
+    def _reads_dev(self):
+        if self._dev is None:
+            ctx = self._ctx or _lib.get_ctx()
+            self._ctx = ctx
+            self._dev = [DeviceArray(ctx, max(a.nbytes, 16)).upload(a) if a.size else DeviceArray(ctx, 16)
+                         for a in self._host]
+        return self._dev
+
+    def cut_counts_ranges_dev(self, chroms, starts, lengths, counts_plus=None, counts_minus=None):
+        """Counts of the ranges [starts[i], starts[i] + lengths[i]) on chroms[i], written back to
+        back (CSR) into two device arrays of sum(lengths) doubles: returns (plus, minus, offsets).
+        Existing arrays are accumulated into (several files of one dataset)."""
+        ctx = self._ctx or _lib.get_ctx()
+        self._ctx = ctx
+        L = _bind(ctx.L)
+        starts = np.asarray(starts, dtype=np.int64)
+        lengths = np.asarray(lengths, dtype=np.int64)
+        n = starts.size
+        off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        total = int(off[-1])
+        if counts_plus is None:
+            counts_plus, counts_minus = DeviceArray(ctx, max(total, 1) * 8), DeviceArray(ctx, max(total, 1) * 8)
+            zeros = np.zeros(max(total, 1))
+            counts_plus.upload(zeros)
+            counts_minus.upload(zeros)
+        rid = np.array([self._ref_index.get(c, -1) for c in chroms], dtype=np.int64)
+        known = rid >= 0  # a chromosome the file does not have: all zeros, like an empty fetch
+        key = (rid << 32) | np.clip(starts, 0, None)
+        # ranges starting before 0 keep their true length: shift by the clipped part
+        clip = np.clip(-starts, 0, None)
+        order = np.argsort(key[known], kind="stable")
+        idx = np.nonzero(known)[0][order]
+        if idx.size and self.n_reads:
+            skey = key[idx]
+            plen = (lengths[idx] - clip[idx]).astype(np.int32)
+            ekey = np.maximum.accumulate(skey + plen)
+            coff = (off[:-1][idx] + clip[idx]).astype(np.int64)
+            dev = self._reads_dev()
+            tmp = [DeviceArray(ctx, a.nbytes).upload(a) for a in (skey, ekey, plen, coff)]
+            d = CutCountDesc()
+            d.n_reads = self.n_reads
+            d.ref_id, d.ref_start, d.ref_end, d.flag, d.mapq = (x.ptr for x in dev)
+            d.offset_plus, d.offset_minus = int(self.offset[0]), int(self.offset[1])
+            d.min_qual, d.remove_dups, d.remove_qcfail = int(self.min_qual), int(bool(self.remove_dups)), int(bool(self.remove_qcfail))
+            d.n_intervals = idx.size
+            d.start_key, d.maxend_key, d.padded_len, d.counts_off = (x.ptr for x in tmp)
+            d.counts_plus, d.counts_minus = counts_plus.ptr, counts_minus.ptr
+            _lib.check(L.fpt_cut_counts_dev(ctx.h, C.byref(d)))
+            ctx.synchronize()
+            for x in tmp:
+                x.free()
+        return counts_plus, counts_minus, off
+
+    def cut_counts_dev(self, intervals, pad):
+        """The padded count arrays of an interval list exactly as the fused scan reads them
+        (`prediction.compute` fetches [start - pad - 1, end + pad), modeling/predict.pyx:132-134):
+        (counts_plus, counts_minus) DeviceArrays in FootprintScanner.scan_dev's CSR layout."""
+        ivs = list(intervals)
+        cp, cm, _ = self.cut_counts_ranges_dev([iv.chrom for iv in ivs], [iv.start - pad - 1 for iv in ivs],
+                                               [iv.end - iv.start + 2 * pad + 1 for iv in ivs])
+        return cp, cm
+
+    def lookup(self, interval):
+        """Lookup reads in a defined genomic region (cutcounts.py:274-313)."""
+        n = interval.end - interval.start
+        cp, cm, _ = self.cut_counts_ranges_dev([interval.chrom], [interval.start], [n])
+        fw, rev = cp.download(np.float64, n), cm.download(np.float64, n)
+        cp.free()
+        cm.free()
+        flip = getattr(interval, "strand", None) == "-"
+        return {"+": rev[::-1] if flip else fw, "-": fw[::-1] if flip else rev, "fragments": []}
+
+    def __getitem__(self, x):
+        return self.lookup(x)

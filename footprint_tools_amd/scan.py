@@ -36,8 +36,10 @@ class DeviceArray(object):
         return self
 
     def download(self, dtype, count, offset_bytes=0):
-        out = np.empty(count, dtype=dtype)
-        _lib.check(self.ctx.L.fpt_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset_bytes,
+        out = np.empty(int(count), dtype=dtype)
+        if int(offset_bytes) < 0 or int(offset_bytes) + out.nbytes > self.nbytes:
+            raise ValueError("download outside the allocation")
+        _lib.check(self.ctx.L.fpt_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + int(offset_bytes),
                                              out.nbytes))
         return out
 

@@ -274,6 +274,46 @@ int fpt_synth_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int64_t n_co
                   double *counts_plus, double *counts_minus, int64_t pos0_seq, int64_t n_seq,
                   uint8_t *seq);
 
+/* ---- cut-count ingestion: the step right before the path.
+ * Reference: cutcounts.bamfile (footprint_tools/cutcounts.py): `validate_read` :119-145, the
+ * pairing rules of `read_pair_generator` :196-205, `_add_read` :231-248 (forward reads cut at
+ * reference_start + offset[0] on '+', reverse reads at reference_end + offset[1] on '-'; default
+ * offset (0, -1)) and `lookup` :274-313.  A read is counted once whether or not its mate is in the
+ * fetched window, so counts[x] = number of valid reads whose cut position is x, for any interval.
+ *
+ * fpt_bam_*: a sequential BAM reader (BGZF through zlib; htslib is not in this image -- parity of
+ * the reader is UNPINNED, it is tested on files the tests write).  fpt_bam_read hands out up to
+ * max_reads alignments per call (reference id, 0-based start, end = start + reference-consuming
+ * CIGAR operations as pysam's reference_end, SAM flag, MAPQ); *n_out = 0 at the end of the file. */
+typedef struct fpt_bam fpt_bam;
+int fpt_bam_open(const char *path, fpt_bam **out);
+int fpt_bam_close(fpt_bam *bam);
+int fpt_bam_n_refs(fpt_bam *bam, int32_t *n_out);
+int fpt_bam_ref(fpt_bam *bam, int32_t i, char *name_out, int32_t cap, int64_t *len_out);
+int fpt_bam_read(fpt_bam *bam, int64_t max_reads, int32_t *ref_id, int32_t *ref_start, int32_t *ref_end,
+                 uint16_t *flag, uint8_t *mapq, int64_t *n_out);
+
+/* Alignments -> cut counts of a batch of intervals, added into the padded CSR count arrays the
+ * fused scan reads (zero them first; several calls accumulate, e.g. one per fpt_bam_read batch).
+ * All pointers are device pointers.  Intervals are given by ascending start_key =
+ * (reference id << 32 | padded start), padded start = start - pad - 1 (modeling/predict.pyx:
+ * 132-134), with maxend_key[i] = max over j <= i of (reference id << 32 | padded start + padded
+ * len); an alignment lands in every interval whose padded range holds its cut position. */
+typedef struct fpt_cutcount_desc {
+    int64_t n_reads;
+    const int32_t *ref_id, *ref_start, *ref_end;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    int32_t offset_plus, offset_minus;               /* bamfile(offset=(0, -1)) */
+    int32_t min_qual, remove_dups, remove_qcfail;    /* bamfile(min_qual=1, remove_dups=False, remove_qcfail=True) */
+    int64_t n_intervals;
+    const int64_t *start_key, *maxend_key;
+    const int32_t *padded_len;
+    const int64_t *counts_off;                       /* element offset of each interval in the count arrays */
+    double *counts_plus, *counts_minus;
+} fpt_cutcount_desc;
+int fpt_cut_counts_dev(fpt_ctx *ctx, const fpt_cutcount_desc *d);
+
 /* ---- the one collective of the sharded job (BASELINE.json north_star: "a
  * single RCCL all-gather over xGMI at the end to reassemble the per-base statistics track").
  * Intervals shard across GPUs with no communication during the scan (one process and one

@@ -973,6 +973,122 @@ def test_rccl_track_allgather_one_rank(fpt, orc, tmp_path):
         assert a["interval"] is b["interval"] and np.array_equal(a["stats"], b["stats"], equal_nan=True)
 
 
+def test_cut_count_ingestion(fpt, orc, tmp_path):
+    """alignments -> cut counts on the device.  The offset / strand / filter rule
+    of cutcounts.py:119-145,196-205,231-248 is pinned by hand-derived reads, then checked on random
+    reads against a direct restatement of that rule; the counts feed the fused scan end to end
+    (BAM + FASTA -> padded CSR arrays -> exp / obs) and equal the oracle on the same arrays."""
+    from footprint_tools_amd import cutcounts
+    from footprint_tools_amd.fasta import FastaFile
+    from footprint_tools_amd.scan import FootprintScanner
+    from .bamwriter import write_bam
+
+    class Iv(object):
+        def __init__(self, c, s, e, strand="+"):
+            self.chrom, self.start, self.end, self.strand = c, s, e, strand
+
+    refs = [("chr1", 5000), ("chr2", 3000)]
+    # hand-derived (cutcounts.py:231-248): forward read at pos 100, 36M -> '+' cut at 100;
+    # reverse read at pos 100, 36M: reference_end = 136 -> '-' cut at 135 (offset -1);
+    # reverse with deletion 20M2D16M from 200: reference_end = 238 -> 237; soft clip does not move pos
+    hand = [dict(ref=0, pos=100, cigar="36M", flag=0, mapq=30),
+            dict(ref=0, pos=100, cigar="36M", flag=16, mapq=30),
+            dict(ref=0, pos=100, cigar="36M", flag=0, mapq=30),
+            dict(ref=0, pos=200, cigar="20M2D16M", flag=16, mapq=30),
+            dict(ref=0, pos=210, cigar="5S31M", flag=0, mapq=1),
+            dict(ref=0, pos=220, cigar="36M", flag=0, mapq=0),          # MAPQ < min_qual
+            dict(ref=0, pos=221, cigar="36M", flag=512, mapq=30),       # QC fail
+            dict(ref=0, pos=222, cigar="36M", flag=1024, mapq=30),      # duplicate: kept (remove_dups=False)
+            dict(ref=0, pos=223, cigar="36M", flag=1 + 64, mapq=30),    # paired, not a proper pair
+            dict(ref=0, pos=224, cigar="36M", flag=1 + 2 + 64, mapq=30),            # proper pair, read 1
+            dict(ref=0, pos=225, cigar="36M", flag=1 + 2 + 256 + 64, mapq=30),      # paired + secondary
+            dict(ref=0, pos=226, cigar="36M", flag=256, mapq=30),       # single-end secondary: counted (:190-192)
+            dict(ref=0, pos=227, cigar="36M", flag=1 + 2 + 16 + 128, mapq=30),      # proper pair, reverse mate
+            dict(ref=1, pos=100, cigar="36M", flag=0, mapq=30)]
+    path = str(tmp_path / "hand.bam")
+    write_bam(path, refs, hand)
+    bf = cutcounts.bamfile(path)
+    got = bf[Iv("chr1", 90, 270)]
+    wp, wm = np.zeros(180), np.zeros(180)
+    for x in (100, 100, 210, 222, 224, 226):
+        wp[x - 90] += 1
+    for x in (135, 237, 227 + 36 - 1):
+        wm[x - 90] += 1
+    assert np.array_equal(got["+"], wp) and np.array_equal(got["-"], wm) and got["fragments"] == []
+    flipped = bf[Iv("chr1", 90, 270, "-")]  # cutcounts.py:309-311
+    assert np.array_equal(flipped["+"], wm[::-1]) and np.array_equal(flipped["-"], wp[::-1])
+    assert bf[Iv("chr2", 100, 101)]["+"][0] == 1 and bf[Iv("chrX", 0, 5)]["+"].sum() == 0
+    bf2 = cutcounts.bamfile(path, min_qual=0, remove_dups=True, remove_qcfail=False, offset=(1, 0))
+    g2 = bf2[Iv("chr1", 90, 270)]
+    w2p, w2m = np.zeros(180), np.zeros(180)
+    for x in (100, 100, 210, 220, 221, 224, 226):
+        w2p[x + 1 - 90] += 1
+    for x in (136, 238, 263):
+        w2m[x - 90] += 1
+    assert np.array_equal(g2["+"], w2p) and np.array_equal(g2["-"], w2m)
+    bf.close(); bf2.close()
+
+    # random reads, overlapping / nested / edge intervals, against the rule restated in numpy
+    rs = np.random.RandomState(2)
+    from .test_ingest_cpu import _reads, _ref_span
+    reads = _reads(rs, 40000)
+    path = str(tmp_path / "rand.bam")
+    write_bam(path, refs, reads, block_bytes=60000)
+    bf = cutcounts.bamfile(path, min_qual=1)
+    genome = {(c, s): np.zeros(6000) for c, _ in enumerate(refs) for s in "+-"}  # random positions go up to 5000 + read
+    for r in reads:
+        fl = r["flag"]
+        if fl & 4 or fl & 512 or r["mapq"] < 1 or ((fl & 1) and (not fl & 2 or fl & (256 | 2048))):
+            continue
+        x = r["pos"] + _ref_span(r["cigar"]) - 1 if fl & 16 else r["pos"]
+        genome[(r["ref"], "-" if fl & 16 else "+")][x] += 1
+    ivs = [Iv("chr1", 300, 800), Iv("chr2", 10, 60), Iv("chr1", 350, 420), Iv("chr1", 780, 2000), Iv("chr1", 4800, 4990),
+           Iv("chr2", 1000, 1500), Iv("chr1", 40, 90)]
+    pad = 55
+    cp, cm = bf.cut_counts_dev(ivs, pad)
+    tot = sum(iv.end - iv.start + 2 * pad + 1 for iv in ivs)
+    hp, hm = cp.download(np.float64, tot), cm.download(np.float64, tot)
+    pos = 0
+    for iv in ivs:
+        c = [n for n, _ in refs].index(iv.chrom)
+        a, b = iv.start - pad - 1, iv.end + pad
+        for arr, strand in ((hp, "+"), (hm, "-")):
+            g = genome[(c, strand)]
+            want = np.array([g[x] if 0 <= x < g.size else 0.0 for x in range(a, b)])
+            assert np.array_equal(arr[pos:pos + b - a], want), (iv.chrom, iv.start, strand)
+        pos += b - a
+    assert hp.sum() > 1000
+    # end to end: BAM + FASTA -> the scan, equal to the oracle on the same arrays
+    gseq = {name: "".join(rs.choice(list("ACGT"), n)) for name, n in refs}
+    fa_path = tmp_path / "g.fa"
+    with open(fa_path, "w") as f:
+        for name, s_ in gseq.items():
+            f.write(">%s\n" % name + "\n".join(s_[a:a + 70] for a in range(0, len(s_), 70)) + "\n")
+    fa = FastaFile(str(fa_path))
+    inner = [iv for iv in ivs if iv.start > 100 and iv.end < refs[[n for n, _ in refs].index(iv.chrom)][1] - 100]
+    cp2, cm2 = bf.cut_counts_dev(inner, pad)
+    sq = fa.fetch_batch(inner, pad)
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,))
+    lens = np.array([iv.end - iv.start for iv in inner])
+    off = np.concatenate([[0], np.cumsum(lens)])
+    n_c = int((lens + 2 * pad + 1).sum())
+    out = sc.scan(cp2.download(np.float64, n_c), cm2.download(np.float64, n_c), sq, interval_off=off)
+    pos = 0
+    for j, iv in enumerate(inner):
+        l = lens[j] + 2 * pad + 1
+        e, o, p, wp_ = orc.detect_batch(cp2.download(np.float64, l, pos * 8), cm2.download(np.float64, l, pos * 8),
+                                        sq[pos + 6 * j:pos + 6 * j + l + 6], 1, int(lens[j]), 5, 50, 0.01, table,
+                                        lat["mu_A"], lat["r_A"], np.array([3], np.int32))
+        sl = slice(off[j], off[j + 1])
+        assert np.array_equal(out["exp"][sl], e) and np.array_equal(out["obs"][sl], o)
+        assert rel_err(out["pval"][sl], p) < P_TOL
+        pos += l
+    bf.close()
+    fa.close()
+
+
 def test_exp_obs_histogram(fpt, orc):
     """cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1, out-of-range pairs ignored."""
     sc, lat, out = _scan_small(orc, 40, 500, 77, bump=slice(0, 20000, 13))

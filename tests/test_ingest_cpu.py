@@ -1,0 +1,96 @@
+"""Host side of the cut-count ingestion (no GPU): the library's BGZF/BAM reader on files written by
+tests/bamwriter.py, and the FASTA reader.  The reader's parity with pysam is unpinned (pysam /
+htslib are not in the image); what is pinned here is the record layout of the BAM specification."""
+import numpy as np
+import pytest
+
+from .bamwriter import write_bam
+
+
+def _reads(rs, n, n_ref=2):
+    out = []
+    for k in range(n):
+        cig = rs.choice(["36M", "20M2D16M", "5S31M", "10M100N26M", "30M1I5M", "18=2X16=", "36M4H"])
+        out.append(dict(ref=int(rs.randint(0, n_ref)), pos=int(rs.randint(0, 5000)), cigar=str(cig),
+                        flag=int(rs.choice([0, 16, 99, 147, 83, 163, 1024, 512, 256, 4, 2048 + 16, 1 + 16])),
+                        mapq=int(rs.choice([0, 1, 30, 60, 255]))))
+    out.sort(key=lambda r: (r["ref"], r["pos"]))
+    return out
+
+
+def _ref_span(cigar):
+    span, num = 0, ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            if ch in "MDN=X":
+                span += int(num)
+            num = ""
+    return span
+
+
+def test_bam_reader_roundtrip(tmp_path):
+    from footprint_tools_amd.cutcounts import read_alignments
+    rs = np.random.RandomState(0)
+    refs = [("chr1", 100000), ("chrUn_gl000220", 161802)]
+    reads = _reads(rs, 5000)
+    path = str(tmp_path / "t.bam")
+    write_bam(path, refs, reads, block_bytes=2500)
+    got_refs, rid, st, en, fl, mq = read_alignments(path, batch=777)  # several read calls
+    assert got_refs == refs
+    assert rid.size == len(reads)
+    assert np.array_equal(rid, [r["ref"] for r in reads]) and np.array_equal(st, [r["pos"] for r in reads])
+    assert np.array_equal(fl, [r["flag"] for r in reads]) and np.array_equal(mq, [r["mapq"] for r in reads])
+    assert np.array_equal(en, [r["pos"] + _ref_span(r["cigar"]) for r in reads])  # pysam's reference_end
+    # an empty file body, and a file that is not BAM
+    write_bam(path, refs, [])
+    assert read_alignments(path)[1].size == 0
+    bad = tmp_path / "x.bam"
+    bad.write_bytes(b"not a bam file at all")
+    with pytest.raises(IOError):
+        read_alignments(str(bad))
+    with pytest.raises(IOError):
+        read_alignments(str(tmp_path / "missing.bam"))
+
+
+class _Iv(object):
+    def __init__(self, c, s, e):
+        self.chrom, self.start, self.end = c, s, e
+
+
+def test_fasta_reader(tmp_path):
+    from footprint_tools_amd.fasta import FastaFile
+    rs = np.random.RandomState(1)
+    seqs = {"chr1": "".join(rs.choice(list("ACGTacgtN"), 1234)), "chr2": "".join(rs.choice(list("ACGT"), 61)),
+            "empty": ""}
+    path = tmp_path / "g.fa"
+    with open(path, "w") as f:
+        for name, s in seqs.items():
+            f.write(">%s some description\n" % name)
+            for a in range(0, len(s), 60):
+                f.write(s[a:a + 60] + "\n")
+    for use_fai in (False, True):
+        if use_fai:
+            off = 0
+            with open(str(path) + ".fai", "w") as fai, open(path) as f:
+                text = f.read()
+            pos = 0
+            with open(str(path) + ".fai", "w") as fai:
+                for name, s in seqs.items():
+                    pos = text.index(">" + name) + len(">%s some description\n" % name)
+                    fai.write("%s\t%d\t%d\t60\t61\n" % (name, len(s), pos))
+        fa = FastaFile(str(path))
+        assert fa.references == list(seqs)
+        for chrom, a, b in (("chr1", 0, 1234), ("chr1", 59, 61), ("chr1", 60, 120), ("chr1", 100, 1000),
+                            ("chr2", 0, 61), ("chr2", 10, 11), ("chr1", 1200, 1234)):
+            assert fa.fetch(chrom, a, b) == seqs[chrom][a:b], (chrom, a, b, use_fai)
+        # outside the chromosome: N (the scan then uses the default propensity)
+        assert fa.fetch("chr2", -5, 3) == "NNNNN" + seqs["chr2"][:3]
+        assert fa.fetch("chr2", 58, 66) == seqs["chr2"][58:] + "NNNNN"
+        assert fa.fetch("nope", 0, 4) == "NNNN"
+        ivs = [_Iv("chr1", 200, 300), _Iv("chr2", 5, 20)]
+        batch = fa.fetch_batch(ivs, pad=55)
+        want = "".join(fa.fetch(iv.chrom, iv.start - 55 - 1 - 3, iv.end + 55 + 3) for iv in ivs)
+        assert batch.tobytes().decode() == want and batch.size == sum(iv.end - iv.start + 117 for iv in ivs)
+        fa.close()
