@@ -151,97 +151,106 @@ class dispersion_model(object):
         return vals, pv
 
 
+def _nb_fit_rows(h, cutoff, trim):
+    """Per expected-count row of the histogram: maximum-likelihood NB (p, r) of the observed counts
+    in that row, or NaN where the row holds fewer than `cutoff` observations."""
+    from ..stats.distributions import nbinom
+    n_rows, n_cols = h.shape
+    obs_values = np.arange(n_cols, dtype=np.float64)
+    p = np.full(n_rows, np.nan)
+    r = np.full(n_rows, np.nan)
+    lo_frac, hi_frac = trim[0] / 100.0, trim[1] / 100.0
+    for row in range(n_rows):
+        sample = np.repeat(obs_values, h[row].astype(np.int64))  # ascending by construction
+        if sample.size > 100000:  # keep the root finding tractable (numpy's global RNG, as the reference)
+            sample = np.sort(np.random.choice(sample, size=100000))
+        if sample.size < cutoff:
+            continue
+        kept = sample[int(np.floor(sample.size * lo_frac)):int(np.ceil(sample.size * hi_frac))]
+        mean, variance = np.mean(kept), np.var(kept)
+        # Moment estimate of r as the starting point.  Only a non-positive estimate is replaced:
+        # variance == mean leaves inf (or NaN), the root finder then hands the start back, and
+        # the row drops out of the curve fits below through its non-finite mean -- what the
+        # reference does (dispersion.pyx:417-424).
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r_start = np.float64(mean * mean) / np.float64(variance - mean)
+            if r_start <= 0.0:
+                r_start = 10.0
+            p_start = r_start / (r_start + mean)
+        p[row], r[row] = nbinom.fit(kept, p=p_start, r=r_start)
+    return p, r
+
+
 def learn_dispersion_model(h, cutoff=250, trim=(2.5, 97.5)):
-    """Dispersion model from the (expected, observed) histogram `h` (rows = expected count),
-    following modeling/dispersion.pyx:357-469: a maximum-likelihood NB fit of every row with at
-    least `cutoff` observations (after trimming `trim` percent off both ends), then continuous
+    """Dispersion model from the (expected, observed) histogram `h` (rows = expected count);
+    what modeling/dispersion.pyx:357-469 computes: a maximum-likelihood NB fit of every row with
+    at least `cutoff` observations (after trimming `trim` percent off both ends), then continuous
     piecewise-linear fits of mu(x) (3 segments, forced through the first fitted row) and of
     1/r(x) (5 segments whose breakpoints are optimised, forced through row 1).
 
     The histogram comes from `FootprintScanner.histogram` (device) or the reference's loop
-    (cli/learn_dm.py:276-287).  The piecewise fits use `modeling.piecewise` in place of pwlf."""
+    (cli/learn_dm.py:276-287).  The piecewise fits use `modeling.piecewise` in place of pwlf
+    (an unpinned third-party dependency of the reference: see DESIGN.md)."""
     from scipy import optimize
 
-    from ..stats.distributions import nbinom
     from .piecewise import PiecewiseLinFit
     h = np.asarray(h)
-    size = int(h.shape[0])
-    p, r = np.zeros(size), np.zeros(size)
-    values = np.arange(h.shape[1], dtype=np.float64)
-    for i in range(size):
-        counts = h[i, :].astype(np.int64)
-        x = np.repeat(values, counts)  # the row unpacked, ascending
-        if len(x) > 1e5:  # downsample to keep the root finding tractable (global numpy RNG)
-            x = np.sort(np.random.choice(x, size=int(1e5)))
-        if len(x) < cutoff:
-            p[i] = r[i] = np.nan  # too few points: left out of the curve fits
-            continue
-        lower = int(np.floor(x.shape[0] * (trim[0] / 100.0)))
-        upper = int(np.ceil(x.shape[0] * (trim[1] / 100.0)))
-        core = x[lower:upper]
-        m, v = np.mean(core), np.var(core)
-        r0 = (m * m) / (v - m) if v != m else np.inf
-        if not (r0 > 0.0) or not np.isfinite(r0):
-            r0 = 10.0
-        p[i], r[i] = nbinom.fit(core, p=r0 / (r0 + m), r=r0)
+    p, r = _nb_fit_rows(h, cutoff, trim)
     with np.errstate(all="ignore"):
-        mus = p * r / (1 - p)
-    r[r > 200] = 200.0  # the reference's guard against runaway fits
+        mu_of_row = p * r / (1 - p)
+    r[r > 200] = 200.0  # the reference's guard against runaway fits (dispersion.pyx:437)
 
-    x = np.arange(size)
-    ok = np.isfinite(mus)
-    if ok.sum() < 2:
+    rows = np.arange(h.shape[0])
+    fitted = np.isfinite(mu_of_row)
+    if fitted.sum() < 2:
         raise ValueError("not enough rows with >= %d observations to fit a dispersion model" % cutoff)
-    first_x, last_x = np.min(x[ok]), np.max(x[ok]) * 0.75
+    xs = rows[fitted]
+    x_lo, x_hi = xs.min(), xs.max() * 0.75
 
-    fit_mu = PiecewiseLinFit(x[ok], mus[ok])
-    fit_mu.fit_with_breaks_force_points(np.linspace(first_x, last_x, 4), [x[ok][0]], [mus[ok][0]])
+    mu_curve = PiecewiseLinFit(xs, mu_of_row[fitted])
+    mu_curve.fit_with_breaks_force_points(np.linspace(x_lo, x_hi, 4), [xs[0]], [mu_of_row[fitted][0]])
 
-    fit_r = PiecewiseLinFit(x[ok], 1.0 / r[ok])
-    best = optimize.minimize(fit_r.fit_with_breaks_opt, [3.0, 7.0, 15.0, 25.0])
-    breaks = np.zeros(6)
-    breaks[0], breaks[-1] = first_x, last_x
-    breaks[1:-1] = best.x
-    fit_r.fit_with_breaks_force_points(breaks, [1], [1.0 / r[1]])
+    inv_r_curve = PiecewiseLinFit(xs, 1.0 / r[fitted])
+    inner = optimize.minimize(inv_r_curve.fit_with_breaks_opt, [3.0, 7.0, 15.0, 25.0]).x
+    inv_r_curve.fit_with_breaks_force_points(np.concatenate([[x_lo], inner, [x_hi]]), [1], [1.0 / r[1]])
+
+    def pack(curve):  # (breakpoints after the first, intercepts, slopes): dispersion.pyx:466-467
+        return list(curve.fit_breaks[1:]) + list(curve.intercepts) + list(curve.slopes)
 
     model = dispersion_model()
     model.h, model.p, model.r = h, p, r
-    model.mu_params = list(fit_mu.fit_breaks[1:]) + list(fit_mu.intercepts) + list(fit_mu.slopes)
-    model.r_params = list(fit_r.fit_breaks[1:]) + list(fit_r.intercepts) + list(fit_r.slopes)
+    model.mu_params, model.r_params = pack(mu_curve), pack(inv_r_curve)
     return model
 
 
+# ---- JSON form of a model (the reference's schema, dispersion.pyx:471-549): every array is the
+#      triple [dtype name, base64 of the C-ordered bytes, shape]
+
 def base64encode(x):
-    return [str(x.dtype), base64.b64encode(x), x.shape]
+    x = np.ascontiguousarray(x)
+    return [str(x.dtype), base64.b64encode(x.tobytes()), x.shape]
 
 
 def base64decode(x):
-    dtype = np.dtype(x[0])
-    arr = np.frombuffer(base64.b64decode(x[1]), dtype)
-    if len(x) > 2:
-        return arr.reshape(x[2])
-    return arr
+    flat = np.frombuffer(base64.b64decode(x[1]), dtype=np.dtype(x[0]))
+    return flat.reshape(x[2]) if len(x) > 2 else flat
 
 
 def load_dispersion_model(filename):
-    """dispersion.pyx:483-521 (stdlib json instead of simplejson)"""
+    """Dispersion model from its JSON file or URL (dispersion.pyx:483-521; stdlib json)."""
     import json
-    import urllib.request as request
+    from urllib.request import urlopen
 
-    file = request.urlopen(filename) if filename.startswith('http') else open(filename, 'r')
-    params = json.load(file)
-    file.close()
+    with (urlopen(filename) if filename.startswith("http") else open(filename, "r")) as src:
+        fields = json.load(src)
     model = dispersion_model()
-    model.mu_params = base64decode(params['mu_params'])
-    model.r_params = base64decode(params['r_params'])
-    if 'h' in params:
-        model.h = base64decode(params['h'])
-    if 'p' in params:
-        model.p = base64decode(params['p'])
-    if 'r' in params:
-        model.r = base64decode(params['r'])
-    if 'metadata' in params:
-        model.metadata = params['metadata']
+    for key in ("mu_params", "r_params"):  # required
+        setattr(model, key, base64decode(fields[key]))
+    for key in ("h", "p", "r"):            # optional arrays
+        if key in fields:
+            setattr(model, key, base64decode(fields[key]))
+    if "metadata" in fields:
+        model.metadata = fields["metadata"]
     return model
 
 

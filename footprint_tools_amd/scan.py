@@ -258,6 +258,8 @@ class FootprintScanner(object):
             d_dm = d_n = None
             if dm_ids is not None:
                 ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
+                if ids.size != n_iv or (ids.size and (ids.min() < 0 or ids.max() >= len(self.models))):
+                    raise ValueError("dm_ids needs one valid model index per interval")
                 d_dm = DeviceArray(ctx, max(ids.nbytes, 16)).upload(ids); bufs.append(d_dm)
             if return_null:
                 d_n = DeviceArray(ctx, max(total * times * 8, 16)); bufs.append(d_n)

@@ -254,3 +254,39 @@ def test_learn_dispersion_model_recovers_truth():
     # round trip through the JSON writer / loader
     txt = dispersion.write_dispersion_model(dm)
     assert "mu_params" in txt
+
+
+def test_learn_dm_row_with_variance_equal_to_mean():
+    """The reference replaces the moment estimate of r only when it is <= 0 (dispersion.pyx:417-419):
+    a row whose trimmed sample has variance == mean starts the root finder at (NaN, inf), gets that
+    start back, and drops out of the curve fits through its non-finite mean.  (Checked against the
+    reference's nbinom.fit in the build container: (nan, inf) for this very sample.)"""
+    from footprint_tools_amd.modeling import dispersion
+    h = np.zeros((3, 3), dtype=np.int64)
+    h[0] = [500, 0, 500]      # mean 1, variance 1
+    h[1] = [100, 300, 100]    # under-dispersed: negative estimate -> start r = 10
+    h[2] = [5, 0, 0]          # fewer than `cutoff` observations
+    p, r = dispersion._nb_fit_rows(h, cutoff=250, trim=(0, 100))
+    assert np.isnan(p[0]) and np.isinf(r[0])
+    assert np.isfinite(p[1]) and np.isfinite(r[1])
+    assert np.isnan(p[2]) and np.isnan(r[2])
+
+
+def test_dispersion_model_json_roundtrip(tmp_path):
+    """the reference's JSON schema (dispersion.pyx:471-549): [dtype, base64, shape] per array"""
+    import json
+    from footprint_tools_amd.modeling import dispersion
+    dm = dispersion.dispersion_model()
+    dm.mu_params = [25, 50, 75, 0, 0.5, 1.0, 1.0, 0.98, 0.97]
+    dm.r_params = np.linspace(0.01, 0.15, 15)
+    dm.h = np.arange(12, dtype=np.int64).reshape(3, 4)
+    text = dispersion.write_dispersion_model(dm, extra="unit test")
+    fields = json.loads(text)
+    assert fields["h"][0] == "int64" and fields["h"][2] == [3, 4] and fields["metadata"] == "unit test"
+    path = tmp_path / "dm.json"
+    path.write_text(text)
+    back = dispersion.load_dispersion_model(str(path))
+    assert np.array_equal(back.mu_params, np.asarray(dm.mu_params, dtype=float))
+    assert np.array_equal(back.r_params, dm.r_params) and np.array_equal(back.h, dm.h)
+    enc = dispersion.base64encode(np.array([[1.5, 2.5]]))
+    assert enc[0] == "float64" and tuple(enc[2]) == (1, 2) and np.array_equal(dispersion.base64decode(enc), [[1.5, 2.5]])
