@@ -49,7 +49,7 @@ for name in sorted(per):
 if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
     f, w = agg["FETCH_SIZE"], agg["WRITE_SIZE"]
     print()
-    print("(summed over the k_scan_fused instances of one step)")
+    print("(summed over the scan kernels of one step: k_scan_lean + the redo instance of k_scan_fused)")
     print("HBM traffic per launch (MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB;")
     print("on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read -> doubled):")
     print("  read  = 2 * %.6g KiB = %.4f GB" % (f, 2 * f * 1024 / 1e9))

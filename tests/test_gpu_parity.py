@@ -1089,6 +1089,45 @@ def test_cut_count_ingestion(fpt, orc, tmp_path):
     fa.close()
 
 
+def test_posterior_driver_from_tracks(fpt, tmp_path):
+    """cli/post.py:98-124 on this package: tracks -> _load_data -> priors -> device log-likelihoods
+    -> posterior, equal to the same steps done by hand on the loaded arrays (whose functions the
+    golden posterior.npz pins against the reference)."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.post import posterior_stats
+    from footprint_tools_amd.stats import posterior
+    from .bamwriter import _bgzf_block
+    lat = golden("nb_lattice.npz")
+    rs = np.random.RandomState(9)
+    rows = []
+    for d, key in enumerate("AC"):
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + key], lat["r_" + key]
+        dmp = tmp_path / ("dm%d.json" % d)
+        dmp.write_text(dispersion.write_dispersion_model(dm))
+        lines = []
+        for x in range(2000, 2300):
+            e = float(rs.randint(1, 40))
+            o = float(max(0, int(e * rs.uniform(0.2, 1.5))))
+            lines.append("chr7\t%d\t%d\t%.4f\t%.4f\t0.5\t0.5\t%.4f" % (x, x + 1, e, o, rs.rand() ** 3))
+        path = tmp_path / ("t%d.gz" % d)
+        with open(path, "wb") as fh:
+            fh.write(_bgzf_block(("\n".join(lines) + "\n").encode()))
+            fh.write(_bgzf_block(b""))
+        rows.append(dict(id=str(d), tabix_file=str(path), dm_file=str(dmp), beta_a=2.0, beta_b=5.0 + d))
+    ps = posterior_stats([("chr7", 1990, 2310)], rows, fdr_cutoff=0.05)
+    rec = ps[0]
+    assert rec["stats"].shape == (320, 2) and np.all(rec["stats"] >= 0)
+    obs, exp, fdr, w = ps._load_data(ps.intervals[0])
+    prior = posterior.compute_prior_weighted(fdr, w, cutoff=0.05)
+    delta = posterior.compute_delta_prior(obs, exp, fdr, ps.betas, cutoff=0.05)
+    want = -posterior.posterior(prior, posterior.log_likelihood(obs, exp, ps.disp_models, delta=delta, w=3),
+                                posterior.log_likelihood(obs, exp, ps.disp_models, w=3))
+    want[want <= 0] = 0.0
+    assert np.array_equal(rec["stats"], want.T, equal_nan=True)
+    assert (rec["stats"][10:310] > 0).any()
+
+
 def test_exp_obs_histogram(fpt, orc):
     """cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1, out-of-range pairs ignored."""
     sc, lat, out = _scan_small(orc, 40, 500, 77, bump=slice(0, 20000, 13))

@@ -94,3 +94,53 @@ def test_fasta_reader(tmp_path):
         want = "".join(fa.fetch(iv.chrom, iv.start - 55 - 1 - 3, iv.end + 55 + 3) for iv in ivs)
         assert batch.tobytes().decode() == want and batch.size == sum(iv.end - iv.start + 117 for iv in ivs)
         fa.close()
+
+
+def test_tabix_track_reader_and_load_data(tmp_path):
+    """cli/post.py:57-87 `_load_data` on bgzip-compressed per-nucleotide tracks (the format
+    cli/utils.py:119-144 writes): columns 3 / 4 / 7 -> exp / obs / fdr, w = 1 where a dataset has
+    a row, defaults (0, 0, 1, 0) elsewhere."""
+    import json
+    from footprint_tools_amd.post import posterior_stats
+    from footprint_tools_amd.tabix import TabixFile
+    from footprint_tools_amd.modeling import dispersion
+    from .bamwriter import _bgzf_block
+    rs = np.random.RandomState(5)
+    dm = dispersion.dispersion_model()
+    dm.mu_params = [25, 50, 75, 0, 0.5, 1.0, 1.0, 0.98, 0.97]
+    dm.r_params = [3, 7, 15, 25, 75, 0.05, 0.08, 0.115, 0.16, 0.185, 0.02, 0.01, 0.005, 0.002, 0.001]
+    dm_path = tmp_path / "dm.json"
+    dm_path.write_text(dispersion.write_dispersion_model(dm))
+    truth, rows = [], []
+    for d in range(3):
+        lines, cols = ["#chrom\tstart\tend\texp\tobs\tlnp\twinlnp\tfdr"], {}
+        for chrom, a, b in (("chr1", 1000, 1400), ("chr1", 5000, 5100), ("chr2", 10, 60)):
+            if d == 2 and chrom == "chr2":
+                continue  # this dataset has no hotspot there
+            for x in range(a, b):
+                e, o, f = float(rs.randint(0, 30)), float(rs.randint(0, 40)), float(rs.rand())
+                cols[(chrom, x)] = (e, o, f)
+                lines.append("%s\t%d\t%d\t%.4f\t%.4f\t%.4f\t%.4f\t%.4f" % (chrom, x, x + 1, e, o, rs.rand(), rs.rand(), f))
+        data = ("\n".join(lines) + "\n").encode()
+        path = tmp_path / ("d%d.bedgraph.gz" % d)
+        with open(path, "wb") as fh:
+            for k in range(0, len(data), 5000):
+                fh.write(_bgzf_block(data[k:k + 5000]))
+            fh.write(_bgzf_block(b""))
+        truth.append(cols)
+        rows.append(dict(id="s%d" % d, tabix_file=str(path), dm_file=str(dm_path), beta_a=1.0 + d, beta_b=2.0))
+    t = TabixFile(rows[0]["tabix_file"])
+    pos, vals = t.fetch_columns("chr1", 1390, 5003)
+    assert list(pos) == list(range(1390, 1400)) + [5000, 5001, 5002] and vals.shape == (13, 7)
+    assert [r[1] for r in t.fetch("chr2", 58, 70)] == ["58", "59"]
+    ps = posterior_stats([("chr1", 1350, 1450), ("chr2", 0, 70)], rows, fdr_cutoff=0.05)
+    ps._open_tabix_files()
+    for iv in ps.intervals:
+        obs, exp, fdr, w = ps._load_data(iv)
+        assert obs.shape == (3, len(iv))
+        for d in range(3):
+            for j in range(len(iv)):
+                e, o, f = truth[d].get((iv.chrom, iv.start + j), (0.0, 0.0, 1.0))
+                assert abs(exp[d, j] - e) < 1e-9 and abs(obs[d, j] - o) < 1e-9 and abs(fdr[d, j] - round(f, 4)) < 1e-9
+                assert w[d, j] == float((iv.chrom, iv.start + j) in truth[d])
+    ps.cleanup()
