@@ -493,32 +493,34 @@ FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndt
 // instructions).  Here, for t = |a| < 26,
 //     Phi(-t) = exp(-t^2/2) * g(t),   g(t) = Phi(-t) exp(t^2/2)   (half the scaled complementary
 //                                                                   error function, smooth, ~1/t)
-// with g a degree-17 polynomial in 1/(t+5) (shifted to the centre of its range) and exp
-// by the usual reduction to |r| <= ln2/2 and a degree-10 polynomial: ~47 instructions, no
+// with g a degree-14 polynomial in 1/(t+5) (shifted to the centre of its range) and exp
+// by the usual reduction to |r| <= ln2/2 and a degree-8 polynomial: ~40 instructions, no
 // division, no branch.  Coefficients: tools/fit_ndtr_fast.py (Chebyshev series of the functions in
-// 60-digit arithmetic, truncated); measured against 60-digit values: relative error <= 2.5e-13
-// over |a| < 26 (<= 2e-14 for |a| < 8), against the contract of 1e-6.  |a| >= 26 (where the
+// 60-digit arithmetic, truncated); measured against 60-digit values: relative error <= 4.5e-12
+// over |a| < 26, against the contract of 1e-6 (degrees 17 / 10 give 2.5e-13 for six more
+// instructions per evaluation; the scan evaluates this five times per base).  |a| >= 26 (where the
 // reference's exp(-a^2) leaves the normal range and its value degrades, ndtr.c:49 / expx2.c),
 // infinities and NaN take ndtr() above, unchanged.
 constexpr double kNdtrFastLimit = 26.0;
 // g as a polynomial in v = 1/(t+5) - kNdtrR0 (highest power first) and exp(r) on |r| <= ln2/2
+#define FPT_NDTR_G_N 14
+#define FPT_NDTR_E_N 8
 #define FPT_NDTR_G_LIST                                                                                    \
-    -3.26604337552876651e+08, 8.15002226258950830e+08, 3.97188768134408370e+07, -8.87980925451137275e+07,  \
-        -6.83395857208489906e+06, 7.32657135714256205e+06, 1.32626037720134528e+06,                        \
-        -4.97107352772716549e+05, -2.26533562941670069e+05, -4.44113235120385980e+03,                      \
-        2.50634717617242968e+04, 1.17812358042428295e+04, 3.34532871217322145e+03,                         \
-        7.06038092613871299e+02, 1.18661330139268586e+02, 1.63755034045534558e+01,                         \
-        1.88100183563785173e+00, 1.03451588220061952e-01
+    -6.58660840143728033e+07, -5.92359197785998415e+06, 7.06444012539418600e+06, 1.31713778471659194e+06,  \
+        -4.95547112766888516e+05, -2.26485841202956974e+05, -4.44627700314815502e+03,                      \
+        2.50633366749226661e+04, 1.17812450160460648e+04, 3.34532890951772060e+03,                         \
+        7.06038084514002662e+02, 1.18661330011759532e+02, 1.63755034072666597e+01,                         \
+        1.88100183566173196e+00, 1.03451588219912849e-01
 #define FPT_NDTR_E_LIST                                                                                    \
-    2.76326406754302347e-07, 2.76401822473621876e-06, 2.48014854792164305e-05, 1.98411702665183209e-04,   \
-        1.38888889523180450e-03, 8.33333338567131612e-03, 4.16666666664880780e-02,                         \
-        1.66666666665543917e-01, 5.00000000000001887e-01, 1.00000000000000666e+00, 1.00000000000000000e+00
+    2.48844616385603601e-05, 1.99158691913895353e-04, 1.38888017451240203e-03, 8.33326609318958168e-03,   \
+        4.16666670405859349e-02, 1.66666668910743637e-01, 4.99999999994385103e-01,                         \
+        9.99999999979780840e-01, 1.00000000000001354e+00
 constexpr double kNdtrR0 = 0.11612903225806452;          // centre of 1/(t+5) over t in [0, 26]
 constexpr double kNdtrNegHalfLog2e = -0.7213475204444817;  // -0.5 * log2(e)
 constexpr double kNdtrLn2Hi = 0.6931471803691238, kNdtrLn2Lo = 1.9082149292705877e-10;
 FPT_HD double ndtr_fast(double a) {
-    const double kG[18] = {FPT_NDTR_G_LIST};
-    const double kE[11] = {FPT_NDTR_E_LIST};
+    const double kG[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST};
+    const double kE[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
     const double t = fabs(a);
     const double d = t + 5.0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -527,12 +529,12 @@ FPT_HD double ndtr_fast(double a) {
 #else
     const double r = 1.0 / d;
 #endif
-    const double g = horner<17>(r - kNdtrR0, kG);
+    const double g = horner<FPT_NDTR_G_N>(r - kNdtrR0, kG);
     const double t2 = t * t;
     const double n = rint(t2 * kNdtrNegHalfLog2e);
     double rr = fma(n, -kNdtrLn2Hi, -0.5 * t2);  // ln2 in two parts: the first has 32 significant bits
     rr = fma(n, -kNdtrLn2Lo, rr);
-    const double e = horner<10>(rr, kE);
+    const double e = horner<FPT_NDTR_E_N>(rr, kE);
     const double y = ldexp(e * g, (int)n);
     return a > 0.0 ? 1.0 - y : y;
 }

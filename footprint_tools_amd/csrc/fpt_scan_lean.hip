@@ -51,8 +51,8 @@ constexpr u32 kCountMax = 6553;  // 10 of them fit 16 bits
 // fp64 constants that the kernel wants in scalar registers: they travel in the kernel-argument
 // segment, which the compiler cannot fold back into literals
 struct lean_coef {
-    double g[18];  // FPT_NDTR_G_LIST
-    double e[11];  // FPT_NDTR_E_LIST
+    double g[FPT_NDTR_G_N + 1];  // FPT_NDTR_G_LIST divided by its first entry (monic form)
+    double e[FPT_NDTR_E_N + 1];  // FPT_NDTR_E_LIST times that entry
     double neg_r0, neg_half_log2e, neg_ln2_hi, neg_ln2_lo;
     double c99, band, limit;
 };
@@ -110,30 +110,32 @@ typedef const __attribute__((address_space(4))) lean_coef kcoef;        // in th
 typedef const __attribute__((address_space(4))) double kdouble;
 
 #define FPT_HSTEP(n) "v_fma_f64 %0, %0, %1, %" #n "\n\t"
-// degree-17 and degree-10 Horner chains, coefficients highest power first in scalar registers
-__device__ __forceinline__ double horner17_s(double x, kdouble *c) {
+// Horner chains with the coefficients in scalar registers.  g is evaluated in monic form
+// (x^14 + c[1] x^13 + ... + c[14], the leading coefficient folded into e's on the host), which
+// opens the chain with one v_add instead of a v_mov + v_fma; e opens with a move.
+__device__ __forceinline__ double horner_g_s(double x, kdouble *c) {
+    static_assert(FPT_NDTR_G_N == 14, "asm operand list is written for degree 14");
     double acc;
-    asm("v_mov_b64 %0, %2\n\t" FPT_HSTEP(3) FPT_HSTEP(4) FPT_HSTEP(5) FPT_HSTEP(6) FPT_HSTEP(7) FPT_HSTEP(8)
+    asm("v_add_f64 %0, %1, %2\n\t" FPT_HSTEP(3) FPT_HSTEP(4) FPT_HSTEP(5) FPT_HSTEP(6) FPT_HSTEP(7) FPT_HSTEP(8)
             FPT_HSTEP(9) FPT_HSTEP(10) FPT_HSTEP(11) FPT_HSTEP(12) FPT_HSTEP(13) FPT_HSTEP(14) FPT_HSTEP(15)
-                FPT_HSTEP(16) FPT_HSTEP(17) FPT_HSTEP(18) FPT_HSTEP(19)
         : "=&v"(acc)
-        : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]),
-          "s"(c[9]), "s"(c[10]), "s"(c[11]), "s"(c[12]), "s"(c[13]), "s"(c[14]), "s"(c[15]), "s"(c[16]), "s"(c[17]));
+        : "v"(x), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]), "s"(c[9]),
+          "s"(c[10]), "s"(c[11]), "s"(c[12]), "s"(c[13]), "s"(c[14]));
     return acc;
 }
-__device__ __forceinline__ double horner10_s(double x, kdouble *c) {
+__device__ __forceinline__ double horner_e_s(double x, kdouble *c) {
+    static_assert(FPT_NDTR_E_N == 8, "asm operand list is written for degree 8");
     double acc;
     asm("v_mov_b64 %0, %2\n\t" FPT_HSTEP(3) FPT_HSTEP(4) FPT_HSTEP(5) FPT_HSTEP(6) FPT_HSTEP(7) FPT_HSTEP(8)
-            FPT_HSTEP(9) FPT_HSTEP(10) FPT_HSTEP(11) FPT_HSTEP(12)
+            FPT_HSTEP(9) FPT_HSTEP(10)
         : "=&v"(acc)
-        : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]),
-          "s"(c[9]), "s"(c[10]));
+        : "v"(x), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]));
     return acc;
 }
 #undef FPT_HSTEP
 
 // fptm::ndtr_fast with the constants in scalar registers (same operations, same coefficients).
-// The 18 + 11 coefficient pairs do not fit the scalar register file next to the kernel's own
+// The 14 + 9 coefficient pairs do not fit the scalar register file next to the kernel's own
 // state, and left alone the compiler loads them all before the loop over the scales and spills
 // them through v_writelane / v_readlane (32 vector instructions per evaluation).  Passing the
 // pointer through an empty asm that depends on the argument, and again on the first chain's
@@ -144,13 +146,13 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     const double d = t + 5.0;
     double r = __builtin_amdgcn_rcp(d);  // 2^-24 (measured 4.6e-8); one Newton step: 2.2e-15
     r = fma(fma(-d, r, 1.0), r, r);
-    const double g = horner17_s(add_vs(r, c->neg_r0), c->g);
+    const double g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient
     asm volatile("" : "+s"(c) : "v"(g));
     const double t2 = t * t;
     const double n = rint(mul_vs(t2, c->neg_half_log2e));
     double rr = fma_svv(c->neg_ln2_hi, n, -0.5 * t2);
     rr = fma_svv(c->neg_ln2_lo, n, rr);
-    const double e = horner10_s(rr, c->e);
+    const double e = horner_e_s(rr, c->e);                      // e * that coefficient
     const double y = ldexp(e * g, (int)n);
     return a > 0.0 ? 1.0 - y : y;
 }
@@ -550,9 +552,9 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.miss_stride = sl.memo2_stride;
     a.dm_ids = sl.dm_ids;
     a.stop = sl.ablate;
-    const double g[18] = {FPT_NDTR_G_LIST}, e[11] = {FPT_NDTR_E_LIST};
-    for (int i = 0; i < 18; ++i) a.c.g[i] = g[i];
-    for (int i = 0; i < 11; ++i) a.c.e[i] = e[i];
+    const double g[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST}, e[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
+    for (int i = 0; i <= FPT_NDTR_G_N; ++i) a.c.g[i] = g[i] / g[0];
+    for (int i = 0; i <= FPT_NDTR_E_N; ++i) a.c.e[i] = e[i] * g[0];
     a.c.neg_r0 = -fptm::kNdtrR0;
     a.c.neg_half_log2e = fptm::kNdtrNegHalfLog2e;
     a.c.neg_ln2_hi = -fptm::kNdtrLn2Hi;

@@ -1,80 +1,76 @@
-import mpmath as mp, numpy as np
-from numpy.polynomial import chebyshev as C, polynomial as P
+#!/usr/bin/env python3
+"""Coefficients of fptm::ndtr_fast (footprint_tools_amd/csrc/fpt_math.hpp).
+
+    Phi(-t) = exp(-t^2/2) * g(t),   g(t) = Phi(-t) exp(t^2/2),   t in [0, 26]
+
+g is approximated by a polynomial of degree N in v = 1/(t+K) - r0 (r0 = centre of 1/(t+K) over the
+range), exp(r) by a polynomial of degree NE on |r| <= ln2/2: truncated Chebyshev series of the
+functions evaluated with mpmath at 60 digits, converted to the monomial basis in exact arithmetic.
+Prints the macro bodies and the measured relative error against 60-digit values.
+
+    python tools/fit_ndtr_fast.py [N NE K]        (defaults 14 8 5: 4.5e-12; 17 10 5: 2.5e-13)
+"""
+import sys
+
+import mpmath as mp
+import numpy as np
+
 mp.mp.dps = 60
+N, NE, K = (int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (14, 8, 5.0)
+T = 26.0
+
+
 def g(t):
     t = mp.mpf(t)
-    return mp.ncdf(-t) * mp.exp(t*t/2)
-def cheb_fit(f, n, m=None):
-    m = m or n+1
-    k = np.arange(m)
-    xs = [mp.cos(mp.pi*(2*kk+1)/(2*m)) for kk in k]
+    return mp.ncdf(-t) * mp.exp(t * t / 2)
+
+
+def cheb_fit(f, n, m):
+    """first n+1 Chebyshev coefficients of f on [-1, 1] from m Gauss-Chebyshev nodes"""
+    xs = [mp.cos(mp.pi * (2 * k + 1) / (2 * m)) for k in range(m)]
     fs = [f(x) for x in xs]
-    c = []
-    for j in range(n+1):
-        s = mp.fsum(fs[kk]*mp.cos(mp.pi*j*(2*kk+1)/(2*m)) for kk in k)
-        c.append(2*s/m)
+    c = [2 * mp.fsum(fs[k] * mp.cos(mp.pi * j * (2 * k + 1) / (2 * m)) for k in range(m)) / m for j in range(n + 1)]
     c[0] /= 2
     return c
+
+
 def cheb2mono(c):
-    # exact (mp) conversion of Chebyshev coeffs to monomial coeffs
-    n = len(c)-1
-    T = [[mp.mpf(1)], [mp.mpf(0), mp.mpf(1)]]
-    for j in range(2, n+1):
-        a = [mp.mpf(0)] + [2*x for x in T[j-1]]
-        b = T[j-2] + [mp.mpf(0)]*(len(a)-len(T[j-2]))
-        T.append([x-y for x,y in zip(a,b)])
-    out = [mp.mpf(0)]*(n+1)
-    for j in range(n+1):
-        for i,x in enumerate(T[j]): out[i] += c[j]*x
+    n = len(c) - 1
+    Tn = [[mp.mpf(1)], [mp.mpf(0), mp.mpf(1)]]
+    for j in range(2, n + 1):
+        a = [mp.mpf(0)] + [2 * x for x in Tn[j - 1]]
+        b = Tn[j - 2] + [mp.mpf(0)] * (len(a) - len(Tn[j - 2]))
+        Tn.append([x - y for x, y in zip(a, b)])
+    out = [mp.mpf(0)] * (n + 1)
+    for j in range(n + 1):
+        for i, x in enumerate(Tn[j]):
+            out[i] += c[j] * x
     return out
-T, K, N = 26.0, 5.0, 17
-wlo, whi = 1/(mp.mpf(T)+K), 1/mp.mpf(K)
-alpha = 2/(whi-wlo); beta = -(whi+wlo)/(whi-wlo)
-def f(u):
-    w = (u - beta)/alpha
-    return g(1/w - K)
-c = cheb_fit(f, N, 64)   # truncated Chebyshev series from 64 nodes (near-minimax)
-mono = cheb2mono(c)
-mono_f = np.array([float(x) for x in mono])
-print("alpha", repr(float(alpha)), "beta", repr(float(beta)))
-print("mono", [repr(x) for x in mono_f])
-# exp poly on [-ln2/2, ln2/2]
-h = mp.log(2)/2
-ce = cheb_fit(lambda u: mp.exp(h*u), 10, 40)
-me = cheb2mono(ce)
-me = [me[i]/h**i for i in range(len(me))]   # poly in r
-me_f = np.array([float(x) for x in me])
-print("exp", [repr(x) for x in me_f])
-# test in float64
-rng = np.random.default_rng(1)
-ts = np.concatenate([rng.uniform(0, 26, 200000), rng.uniform(0, 3, 100000), np.linspace(0,26,5001), [0.0, 25.999999]])
-def ndtr_fast(a):
-    t = np.abs(a)
-    d = t + K
-    r = 1.0/d
-    u = float(alpha)*r + float(beta)
-    p = np.zeros_like(u)
-    for cc in mono_f[::-1]: p = p*u + cc
-    s = -0.5*t*t
-    n = np.rint(s*1.4426950408889634)
-    rr = s + n*(-0.6931471803691238) 
-    rr = rr + n*(-1.9082149292705877e-10)
-    q = np.zeros_like(rr)
-    for cc in me_f[::-1]: q = q*rr + cc
-    y = np.ldexp(q*p, n.astype(int))
-    return np.where(a > 0, 1.0 - y, y)
-ex = np.array([float(mp.ncdf(-mp.mpf(t))) for t in ts[:60000]])
-ap = ndtr_fast(-ts[:60000])
-rel = np.abs(ap/ex-1)
-print("neg side max rel", rel.max(), "at t", ts[:60000][rel.argmax()])
-ex2 = np.array([float(mp.ncdf(mp.mpf(t))) for t in ts[:20000]])
-ap2 = ndtr_fast(ts[:20000])
-print("pos side max rel", np.abs(ap2/ex2-1).max())
-import scipy.special as sp
-allr = np.abs(ndtr_fast(-ts)/sp.ndtr(-ts)-1)
-print("vs scipy all:", allr.max())
-# emit C arrays (highest power first for horner<>) 
-def carr(name, arr):
-    print("const double %s[%d] = {" % (name, len(arr)) + ", ".join("%.17e" % x for x in arr[::-1]) + "};")
-carr("kNdG", mono_f); carr("kNdE", me_f)
-print("%.17e %.17e" % (float(alpha), float(beta)))
+
+
+wlo, whi = 1 / (mp.mpf(T) + K), 1 / mp.mpf(K)
+alpha, beta = 2 / (whi - wlo), -(whi + wlo) / (whi - wlo)  # u = alpha / (t + K) + beta in [-1, 1]
+mono_u = cheb2mono(cheb_fit(lambda u: g(alpha / (u - beta) - K), N, 64))
+r0 = -beta / alpha
+gv = [float(mono_u[j] * alpha ** j) for j in range(N + 1)]  # polynomial in v = 1/(t+K) - r0
+h = mp.log(2) / 2
+me = cheb2mono(cheb_fit(lambda u: mp.exp(h * u), NE, 40))
+ev = [float(me[i] / h ** i) for i in range(NE + 1)]
+
+print("kNdtrR0 = %.17g   (K = %g)" % (float(r0), K))
+print("FPT_NDTR_G_LIST (degree %d, highest power first):\n  " % N + ", ".join("%.17e" % x for x in gv[::-1]))
+print("FPT_NDTR_E_LIST (degree %d):\n  " % NE + ", ".join("%.17e" % x for x in ev[::-1]))
+
+rng = np.random.default_rng(3)
+ts = np.concatenate([rng.uniform(0, T, 60000), rng.uniform(0, 4, 40000), np.linspace(0, T, 4001)])
+exact = np.array([float(mp.ncdf(-mp.mpf(float(t)))) for t in ts])
+v = 1.0 / (ts + K) - float(r0)
+p = np.zeros_like(v)
+for c in gv[::-1]:
+    p = p * v + c
+n = np.rint(ts * ts * (-0.5 * 1.4426950408889634))
+rr = (-0.5 * ts * ts + n * -0.6931471803691238) + n * -1.9082149292705877e-10
+q = np.zeros_like(rr)
+for c in ev[::-1]:
+    q = q * rr + c
+print("max relative error on %d points of [0, %g]: %.2e" % (ts.size, T, np.abs(np.ldexp(q * p, n.astype(int)) / exact - 1).max()))
