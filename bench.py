@@ -39,6 +39,9 @@ CONFIGS = {
     # BASELINE.json configs[3] shape, scaled to one GPU's share (1/8 of ~3.5M intervals):
     # variable-length intervals, lognormal lengths clipped to [50, 2000], mean ~171 bp
     "4": dict(name="437500xragged171bp_1scale", n_iv=437500, L=0, scales=(3,)),
+    # BASELINE.json configs[4]: the same set through the full `detect` statistics -- per-interval NB
+    # dispersion models (4 models, chosen per interval) + empirical FDR with 100 null draws per base
+    "5": dict(name="437500xragged171bp_4models_fdr100", n_iv=437500, L=0, scales=(3,), fdr_times=100, n_models=4),
     # small shapes for quick checks
     "1": dict(name="1000x500bp_5scales", n_iv=1000, L=500, scales=(3, 5, 10, 20, 40)),
 }
@@ -121,6 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="3", choices=sorted(CONFIGS))
+    ap.add_argument("--intervals", type=int, default=0, help="override the number of intervals per GPU")
     ap.add_argument("--nb-mode", default="memo", choices=["memo", "direct"],
                     help="per-base NB p-value: exact (exp,obs) memo table rebuilt inside every step, "
                          "or direct incbet per base; at N=1 the other mode is timed too and reported")
@@ -147,7 +151,10 @@ def main():
                  "torch.distributed.run --nproc-per-node %d ... (only RANK / LOCAL_RANK / WORLD_SIZE / "
                  "MASTER_PORT are read; no torch is imported)" % (args.gpus, args.gpus))
     cfg = CONFIGS[args.config]
+    if args.intervals:
+        cfg = dict(cfg, n_iv=args.intervals, name=cfg["name"].replace(str(cfg["n_iv"]), str(args.intervals), 1))
     n_iv, L, scales = cfg["n_iv"], cfg["L"], cfg["scales"]
+    fdr_times, n_models = cfg.get("fdr_times", 0), cfg.get("n_models", 1)
     S = len(scales)
     table, DM = load_models()
 
@@ -160,7 +167,16 @@ def main():
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
 
     ctx = _lib.Context(0 if args.share_gpu else local_rank)
-    sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
+    models = DM
+    if n_models > 1:  # per-interval dispersion models: DM-SYNTH-A and variants with scaled 1/r
+        lat = np.load(os.path.join(ROOT, "tests", "golden", "nb_lattice.npz"))
+
+        def variant(k):
+            r = np.array(lat["r_A"], dtype=np.float64)
+            r[5:] *= 1.0 + 0.15 * k  # intercepts and slopes of the 1/r fit
+            return type("DMv", (), dict(mu_params=lat["mu_A"], r_params=r))
+        models = [variant(k) for k in range(n_models)]
+    sc = FootprintScanner(table, models, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
     comm = None
     do_gather = (world > 1 and not args.no_allgather and not args.share_gpu) or (world == 1 and args.allgather)
     if (world > 1 and not args.share_gpu) or do_gather:
@@ -203,10 +219,15 @@ def main():
     d_p = None if do_gather else DeviceArray(ctx, total * 8)
     p_p = d_gather.ptr + my_off if do_gather else d_p.ptr
     p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
-    d_off = None
+    d_off = d_dm = d_efdr = None
     if ragged:
         _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1, pos0_counts, n_counts, p_cp, p_cm, pos0_seq, n_seq, p_sq))
         d_off = DeviceArray(ctx, off.nbytes).upload(off)
+        if n_models > 1:  # model of an interval = hash of its GLOBAL index: independent of the sharding
+            ids = ((np.arange(a_iv, b_iv, dtype=np.int64) * 2654435761) >> 7) % n_models
+            d_dm = DeviceArray(ctx, max(n_iv, 1) * 4).upload(ids.astype(np.int32))
+        if fdr_times:
+            d_efdr = DeviceArray(ctx, total * 8) if not do_gather else None
     else:
         # rank r owns intervals [r*n_iv, (r+1)*n_iv) of the global synthetic job
         sc.synth_dev(1, n_iv, L, p_cp, p_cm, p_sq, first_interval=rank * n_iv)
@@ -216,11 +237,21 @@ def main():
 
     t8 = total * 8
 
+    # config 5: the gathered track is the empirical FDR; the p-values go to a plain buffer
+    if fdr_times:
+        d_pv = DeviceArray(ctx, total * 8)
+        p_track = d_gather.ptr + my_off if do_gather else d_efdr.ptr
+        p_p = d_pv.ptr
+        bases_before = int(lens_all[:a_iv].sum())
+
     def step():
         sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_out, obs_out=p_out + t8,
                     pval_out=p_p, winp_out=p_out + 2 * t8 if S else None,
                     interval_len=None if ragged else L, interval_off_dev=d_off.ptr if ragged else None,
-                    interval_off_host=off if ragged else None)
+                    interval_off_host=off if ragged else None, dm_ids_dev=d_dm.ptr if d_dm else None)
+        if fdr_times:  # detect.py:132-135; null draws keyed by the GLOBAL base index
+            sc.fdr_dev(n_iv, p_out, p_out + 2 * t8, p_track, times=fdr_times, seed=1, half_win_width=scales[0],
+                       interval_off_dev=d_off.ptr, base_index0=bases_before, dm_ids_dev=d_dm.ptr if d_dm else None)
 
     def sync():
         ctx.synchronize()
@@ -230,7 +261,7 @@ def main():
     def gather_track():
         """The one collective of the job: every rank ends up with the whole p-value track."""
         if do_gather:
-            comm.allgather_dev(p_p, counts, d_gather.ptr)
+            comm.allgather_dev(p_track if fdr_times else p_p, counts, d_gather.ptr)
 
     def measure(steps, warmup):
         for _ in range(warmup):
@@ -289,14 +320,24 @@ def main():
                 oracle.synth_hotspots(cm, 1, g0 * l, 1, l, args.hotspots)
             sq = oracle.synth_bases(1, g0 * (l + 6), l + 6)
             o0 = iv * L
-        e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, Li, HW, SHW, CLIP, table, DM.mu_params,
-                                          DM.r_params, scales)
+        m_last = models[int(((a_iv + iv) * 2654435761 >> 7) % n_models)] if n_models > 1 else DM
+        e, o, p, wp = oracle.detect_batch(cp, cm, sq, 1, Li, HW, SHW, CLIP, table, m_last.mu_params,
+                                          m_last.r_params, scales)
         ge = d_out.download(np.float64, Li, o0 * 8)
-        src = d_gather if do_gather else d_p
-        gp = src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
+        if fdr_times:
+            gp = d_pv.download(np.float64, Li, o0 * 8)
+        else:
+            src = d_gather if do_gather else d_p
+            gp = src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
         rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
         parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
-        if do_gather and world > 1:  # the gathered track holds the other ranks' slices too
+        if fdr_times:  # the empirical FDR of that interval against the oracle's restatement of the sampler
+            ef_src = d_gather if do_gather else d_efdr
+            ef = ef_src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
+            ef_want = oracle.fdr_null(m_last.mu_params, m_last.r_params, e, wp[0], scales[0], fdr_times, seed=1,
+                                      base0=bases_before + o0)
+            parity["efdr_max_abs_err"] = float(np.max(np.abs(ef - ef_want)))
+        if do_gather and world > 1 and not fdr_times:  # the gathered track holds the other ranks' slices too
             r2 = world - 1
             if ragged:
                 a2, b2 = bounds[r2]
@@ -382,7 +423,8 @@ def main():
                        "interval_bp": L if not ragged else "lognormal, mean %.0f, [50,2000]" % (total_all / lens_all.size),
                        "half_win_width": HW, "smoothing_half_win_width": SHW, "smoothing_clip": CLIP,
                        "stouffer_half_widths": list(scales), "bias_model": "vierstra_et_al.6mer",
-                       "dispersion_model": "DM-SYNTH-A",
+                       "dispersion_model": "DM-SYNTH-A" if n_models == 1 else "%d per-interval variants of DM-SYNTH-A" % n_models,
+                       "empirical_fdr_null_draws_per_base": fdr_times or None,
                        "nb_pvalue": ("exact (exp,obs)->(p,z) memo table, 256x256, rebuilt by the device "
                                      "incbet inside every step; second-level table / direct incbet outside it"
                                      if args.nb_mode == "memo" else "direct incbet per base"),

@@ -92,6 +92,7 @@ class TrackComm(object):
         try:
             os.dup2(2, 1)
             rc = self.L.fpt_comm_init(ctx.h, ident, self.world, self.rank, C.byref(h))
+            C.CDLL(None).fflush(None)  # the banner sits in the C library's buffer: push it out now
         finally:
             os.dup2(saved, 1)
             os.close(saved)
