@@ -1383,6 +1383,100 @@ def test_fused_scan_fuzz(fpt, orc, seed):
             assert rel_err(out["winp"][s_i, sl][okw], wp[s_i][okw]) < (1e-4 if kind == "huge" else P_TOL), tag
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "16"))))
+def test_lean_kernel_fuzz(fpt, orc, seed):
+    """The lean first pass at the borders of its case (`detect` window widths, memo mode): counts at
+    and beyond its 6553 limit, fractional and negative counts, constant non-zero runs (the
+    smoothing.h:61-69 rule the kernel must hand on), sparse data with single cuts, hotspots beyond
+    both (exp, obs) tables, N / lower-case bases, every tile class and multi-tile intervals, up to
+    seven scales incl. wide ones, several dispersion models -- whatever it keeps and whatever it
+    hands to the general kernel must equal the oracle."""
+    from footprint_tools_amd.scan import FootprintScanner
+    rs = np.random.RandomState(7000 + seed)
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    hw, shw, clip, pad = 5, 50, 0.01, 55
+    n_sc = int(rs.choice([1, 1, 2, 5, 5, 7]))
+    scales = tuple(int(x) for x in rs.choice([1, 3, 3, 5, 8, 10, 20, 40, 70, 150], n_sc, replace=False))
+    if rs.rand() < 0.3:
+        scales = (3, 5, 10, 20, 40)
+    dm = str(rs.choice(["A", "A", "B", "C"]))
+    n_iv = int(rs.randint(4, 20))
+    lens = rs.choice([3, 40, 64, 130, 256, 257, 400, 500, 512, 900, 1000, 1024, 1025, 1800], n_iv)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n_c = int(off[-1] + n_iv * (2 * pad + 1))
+    n_s = int(off[-1] + n_iv * (2 * pad + 7))
+    kind = str(rs.choice(["dense", "sparse", "single", "runs", "limit", "over", "float", "neg", "hot", "zero"]))
+    cp, cm = rs.randint(0, 20, n_c).astype(float), rs.randint(0, 20, n_c).astype(float)
+    if kind == "sparse":
+        cp, cm = rs.poisson(0.03, n_c).astype(float), rs.poisson(0.2, n_c).astype(float)
+    elif kind == "single":  # isolated cuts on an empty background: windows of 100 zeros and one value
+        cp, cm = np.zeros(n_c), np.zeros(n_c)
+        cp[rs.randint(0, n_c, max(1, n_c // 400))] = rs.randint(1, 50, max(1, n_c // 400))
+        cm[rs.randint(0, n_c, max(1, n_c // 900))] = 3.0
+    elif kind == "runs":  # constant non-zero stretches longer than the smoothing window
+        cp = np.repeat(rs.randint(0, 4, n_c // 230 + 1), 230)[:n_c].astype(float)
+        cm = np.repeat(rs.randint(1, 3, n_c // 500 + 1), 500)[:n_c].astype(float)
+    elif kind == "limit":  # exactly at the packed-count limit: still the lean kernel's case
+        cp[rs.randint(0, n_c, 20)] = 6553.0
+        cm[rs.randint(0, n_c, 20)] = 6553.0
+    elif kind == "over":   # one past it, and far past it
+        cp[rs.randint(0, n_c, 10)] = 6554.0
+        cm[rs.randint(0, n_c, 5)] = 70000.0
+    elif kind == "float":
+        cp[rs.randint(0, n_c, 30)] += rs.rand(30)
+    elif kind == "neg":
+        cm[rs.randint(0, n_c, 10)] = -1.0
+    elif kind == "hot":    # hotspots beyond the first-level table, one beyond the second-level one
+        for c0 in rs.randint(200, max(201, n_c - 200), 6):
+            cp[c0:c0 + 120] += rs.randint(100, 600)
+            cm[c0:c0 + 120] += rs.randint(100, 600)
+        cp[rs.randint(0, n_c)] = 5000.0
+    elif kind == "zero":
+        cp, cm = np.zeros(n_c), np.zeros(n_c)
+    alphabet = b"ACGT" if rs.rand() < 0.6 else b"ACGTACGTACGTacgtN"
+    sq = rs.choice(np.frombuffer(alphabet, np.uint8), n_s)
+    if rs.rand() < 0.3:
+        sq[rs.randint(0, n_s - 40):][:40] = ord("A")  # homopolymer: P/Q = 1/10 exactly, ties possible
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales, nb_mode="memo")
+    out = sc.scan(cp, cm, sq, interval_off=off)
+    tiles, redone, miss = sc.ctx.scan_stats()
+    tag = (seed, kind, scales, dm, lens.tolist(), tiles, redone)
+    if kind in ("over", "float", "neg"):
+        assert redone > 0, tag
+    for i, L in enumerate(lens):
+        a, b = off[i] + i * (2 * pad + 1), off[i + 1] + (i + 1) * (2 * pad + 1)
+        sa, sb = off[i] + i * (2 * pad + 7), off[i + 1] + (i + 1) * (2 * pad + 7)
+        e, o, p, wp = orc.detect_batch(cp[a:b], cm[a:b], sq[sa:sb], 1, int(L), hw, shw, clip, table,
+                                       lat["mu_" + dm], lat["r_" + dm], np.array(scales, np.int32))
+        sl = slice(off[i], off[i + 1])
+        assert np.array_equal(out["obs"][sl], o), tag
+        got_e = out["exp"][sl]
+        bad = np.flatnonzero(~((got_e == e) | (np.isnan(got_e) & np.isnan(e))))
+        ok = np.ones(int(L), bool)
+        if bad.size:  # admissible only at verified half-integer ties of P/Q*W' (DESIGN.md 2)
+            assert bad.size <= max(3, L // 20), tag
+            fwd, rev = orc.kmer_probs(sq[sa:sb], table)[:2]
+            l = b - a
+            tie = np.zeros(int(L), bool)
+            for c, pr, shift in ((cp[a:b], fwd[:l], pad + 1), (cm[a:b], rev[:l], pad)):
+                _, w = orc.fast_predict(c, pr, hw, shw, clip)
+                for t in bad:
+                    v = shift + t
+                    q = sum(pr[v + j] for j in range(-hw, hw))
+                    prod = pr[v] / q * w[v]
+                    tie[t] |= abs(abs(prod - np.floor(prod)) - 0.5) < 1e-9
+            assert tie[bad].all(), tag
+            assert np.all(np.abs(got_e[bad] - e[bad]) <= 2.0), tag
+            ok[bad] = False
+        assert rel_err(out["pval"][sl][ok], p[ok]) < P_TOL, tag
+        for s_i, hs in enumerate(scales):
+            okw = ok.copy()
+            for t in bad:
+                okw[max(0, t - hs):t + hs + 1] = False
+            assert rel_err(out["winp"][s_i, sl][okw], wp[s_i][okw]) < (1e-4 if kind in ("over", "hot") else P_TOL), tag
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
 def test_fdr_fuzz(fpt, orc, seed):
     """random interval lengths (LDS and global-buffer sizes), window widths, draw counts, expected
