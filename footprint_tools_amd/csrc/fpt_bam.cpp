@@ -43,6 +43,7 @@ struct fpt_bam {
                 in_pos = 0;
                 if (in_len == 0) {
                     eof = true;
+                    if (zs_live) error = "truncated BGZF block at the end of the file";
                     return false;
                 }
             }

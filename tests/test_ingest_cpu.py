@@ -46,6 +46,12 @@ def test_bam_reader_roundtrip(tmp_path):
     # an empty file body, and a file that is not BAM
     write_bam(path, refs, [])
     assert read_alignments(path)[1].size == 0
+    write_bam(path, refs, reads[:50])
+    whole = open(path, "rb").read()
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(whole[:len(whole) // 2])  # a file cut in the middle of a block is an error, not an early end
+    with pytest.raises((IOError, ValueError)):
+        read_alignments(str(cut))
     bad = tmp_path / "x.bam"
     bad.write_bytes(b"not a bam file at all")
     with pytest.raises(IOError):
