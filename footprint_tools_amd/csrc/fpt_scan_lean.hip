@@ -138,8 +138,9 @@ __device__ __forceinline__ double horner_e_s(double x, kdouble *c) {
 // The 14 + 9 coefficient pairs do not fit the scalar register file next to the kernel's own
 // state, and left alone the compiler loads them all before the loop over the scales and spills
 // them through v_writelane / v_readlane (32 vector instructions per evaluation).  Passing the
-// pointer through an empty asm that depends on the argument, and again on the first chain's
-// result, keeps each set's loads (four s_load_dwordx16) next to its use.
+// pointer through an empty asm that depends on the argument keeps the loads (three
+// s_load_dwordx16) inside the evaluation; both sets fit at degrees 14 / 8, so one wait covers them
+// (measured against a second hand-over between the chains: 25.1 vs 25.6 ms on config 3).
 __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     asm volatile("" : "+s"(c) : "v"(a));
     const double t = fabs(a);
@@ -147,7 +148,6 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     double r = __builtin_amdgcn_rcp(d);  // 2^-24 (measured 4.6e-8); one Newton step: 2.2e-15
     r = fma(fma(-d, r, 1.0), r, r);
     const double g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient
-    asm volatile("" : "+s"(c) : "v"(g));
     const double t2 = t * t;
     const double n = rint(mul_vs(t2, c->neg_half_log2e));
     double rr = fma_svv(c->neg_ln2_hi, n, -0.5 * t2);
