@@ -35,7 +35,9 @@
 #include "fpt_kernels.hpp"
 
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "fpt_device.hpp"
 
@@ -81,12 +83,24 @@ struct lean_args {
     int32_t miss_rows, miss_stride;  // ... as far as the second-level table could hold them
     const int32_t *dm_ids;
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
+    int64_t *trace;  // -DFPT_ABLATE builds: per-workgroup timestamps (FPT_LEAN_TRACE)
     lean_coef c;
 };
 #ifdef FPT_ABLATE
 #define LEAN_STOP(n) (a.stop == (n))
+// word 0: HW_ID | XCC_ID << 32; words 1..6: 100 MHz clock of the first wavefront at the start, after
+// the wait for the loads, after barriers 1 and 2, after phase D, at the end; word 7: end of the last
+#define LEAN_TRACE(n)                                                                              \
+    if (a.trace && (threadIdx.x == 0 || ((n) == 6 && threadIdx.x == blockDim.x - 64))) {           \
+        int64_t *tr = a.trace + (int64_t)blockIdx.x * 8;                                            \
+        if ((n) == 1)                                                                              \
+            tr[0] = (int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                           \
+                    ((int64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                   \
+        tr[threadIdx.x == 0 ? (n) : 7] = (int64_t)wall_clock64();                                  \
+    }
 #else
 #define LEAN_STOP(n) false
+#define LEAN_TRACE(n)
 #endif
 
 // ---- fp64 arithmetic with one operand in scalar registers (VOP3, one instruction each)
@@ -336,6 +350,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int64_t tile = a.tile_first + blockIdx.x;
+    LEAN_TRACE(1);
     const lean_tile g = lean_geometry(a, tile);
     const int t0 = g.t0, tl = g.tl, L = g.L, ta = g.ta, nt = g.nt, ncs = g.ncs;
     const int64_t out_off = g.out_off;
@@ -345,6 +360,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     lean_inputs in;
     lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
     bool bad = lean_stage<NT>(in, ncs, tid, pk, bits0, bits1);  // outside the case this kernel handles?
+    LEAN_TRACE(2);
     if (tid == 0) {
         Z[15] = 0.0;
         Z[kEdge] = -1e4;
@@ -352,6 +368,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         C[NROW + 2] = 0.0;
     }
     __syncthreads();
+    LEAN_TRACE(3);
     if (LEAN_STOP(1)) return;
 
     // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums
@@ -389,6 +406,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         PM[v] = tt.y;
     }
     __syncthreads();
+    LEAN_TRACE(4);
     if (LEAN_STOP(2)) return;
 
     // ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands
@@ -441,6 +459,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         }
     }
 
+    LEAN_TRACE(5);
     // ---- E: Stouffer windows (windowing.h:53-84)
     if (a.n_scales == 0 || LEAN_STOP(3)) {
     } else if (a.n_scales == 1 && a.max_scale <= 8) {
@@ -484,6 +503,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         }
     }
     if (bad) a.redo[tile] = 1;
+    LEAN_TRACE(6);
 }
 
 typedef void (*lean_kernel_t)(const lean_args);
@@ -552,6 +572,15 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.miss_stride = sl.memo2_stride;
     a.dm_ids = sl.dm_ids;
     a.stop = sl.ablate;
+    a.trace = nullptr;
+#ifdef FPT_ABLATE
+    static int64_t *d_trace = nullptr;
+    const char *trace_path = getenv("FPT_LEAN_TRACE");
+    if (trace_path) {
+        if (!d_trace) (void)hipMalloc(&d_trace, (size_t)1 << 26);  // 2^20 workgroups x 8 words
+        if (grid <= (1 << 20)) a.trace = d_trace;
+    }
+#endif
     const double g[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST}, e[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
     for (int i = 0; i <= FPT_NDTR_G_N; ++i) a.c.g[i] = g[i] / g[0];
     for (int i = 0; i <= FPT_NDTR_E_N; ++i) a.c.e[i] = e[i] * g[0];
@@ -563,6 +592,17 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.c.band = 1e-13;
     a.c.limit = fptm::kNdtrFastLimit;
     hipLaunchKernelGGL(lean_kernel(nt), dim3(grid), dim3(nt), scan_lean_lds_bytes(nt), st, a);
+#ifdef FPT_ABLATE
+    if (a.trace) {  // the last launch's record: 8 words per workgroup (see LEAN_TRACE)
+        std::vector<int64_t> h((size_t)grid * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), a.trace, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(trace_path, "wb")) {
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
 }
 
 // The bias table in the order the lean kernel indexes it: entry F = plane0 | plane1 << 6, where bit
