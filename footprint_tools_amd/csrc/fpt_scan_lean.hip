@@ -322,13 +322,19 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
     return bad;
 }
 
-// One tile per workgroup; the hardware dispatcher overlaps the load phase of one workgroup with the
-// arithmetic of the other one resident on the compute unit.  Persistent workgroups walking the
-// tiles with the next tile's inputs prefetched into registers (before phase E, with and without
-// all of a tile's stores held back behind the wait for them) were measured on config 3 at
-// 29.4-30.0 ms against 27.3 ms for this form, and 22.9 against 19.8 ms with loads and stores
-// ablated: workgroups that start together stay in step, so both residents of a compute unit
-// reach their barriers and their memory phases at the same time.
+// One tile per workgroup.  Per-workgroup timelines (tools/lean_trace.py, config 3): 12.1 us of life,
+// of which 2.6 us from the first instruction to the inputs being staged, and 2.8 us between the
+// last store being issued and the successor's first instruction -- the slot (half of the compute
+// unit's wavefronts) is not released until every store is acknowledged.  Workgroups that stay and
+// walk the tiles were built four ways to hide both; the last one ordered an iteration so that no
+// wait on the vector-memory counter (in order across loads AND stores on gfx9) meets a young
+// operation: stage(k) | issue loads(k+1) | issue table gather(k) | stores + windows of tile k-1 |
+// scans(k) | smoothing, memo gather(k), z(k) -> LDS.  It is correct (whole GPU suite) and hides
+// more of the memory time (4.6 ms exposed instead of 6.3), but its arithmetic alone is slower the
+// longer a workgroup lives -- 21.1 ms with the loads and stores ablated at 4 or 244 tiles per
+// workgroup, 23.2 ms at 1,953 (one-shot: 19.3) -- and the whole kernel never beat this form:
+// 26.0 / 25.2 / 25.5 / 25.8 / 27.0 / 27.8 ms at 1 / 4 / 30 / 244 / 977 / 1,953 tiles per workgroup
+// against 25.0.  Start offsets between the workgroups of a CU (by hardware slot) changed nothing.
 template <int NT>
 __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     typedef lean_lds<NT> LY;
