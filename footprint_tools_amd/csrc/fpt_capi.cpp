@@ -75,7 +75,7 @@ struct fpt_ctx {
     std::vector<int64_t> plan_off;
     int plan_H = -1;
     int64_t plan_tiles = 0;
-    int64_t plan_cls_count[3] = {0, 0, 0};
+    int64_t plan_cls_count[fptk::kLeanClasses] = {};  // tiles per workgroup-size class, in table order
     int64_t last_tiles = 0;      // tiles of the most recent memo-mode scan (fpt_scan_stats)
     bool last_has_redo = false;
 };
@@ -475,14 +475,22 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     sl.status_out = d->status_out;
     sl.dm_ids = d->dm_ids;
 
+    // Tiles are grouped by the workgroup size that holds them.  The general kernel has three sizes
+    // (256 / 512 / 1024 lanes); the lean first pass of memo mode has seven (fptk::kLeanNT), each a
+    // sub-range of one of the three, so that short intervals leave fewer lanes idle.
     struct launch_t {
         int nt;
         int64_t first, count;
         int tile_len;
     };
-    std::vector<launch_t> launches;
+    std::vector<launch_t> launches, lean_launches;
 
     auto nt_class = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : 1024); };
+    auto lean_class = [](int n) {
+        int k = 0;
+        while (fptk::kLeanNT[k] < n) ++k;
+        return k;
+    };
 
     if (!d->interval_off) {
         const int L = d->interval_len;
@@ -494,6 +502,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         sl.tiles_per_interval = tpi;
         int nt_needed = tpi == 1 ? L : std::min(L, tile_len + 2 * H);
         launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len});
+        lean_launches.push_back({fptk::kLeanNT[lean_class(nt_needed)], 0, d->n_intervals * (int64_t)tpi, tile_len});
     } else {
         // ragged batch: tile table binned by workgroup size
         std::vector<int64_t> off_host;
@@ -510,14 +519,15 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         const bool cached = c->plan_H == H && c->plan_off.size() == n_off && c->ws[9] != nullptr &&
                             std::memcmp(c->plan_off.data(), off, n_off * sizeof(int64_t)) == 0;
         if (!cached) {
-            std::vector<int32_t> tiv[3], tt0[3], ttl[3];
+            constexpr int NC = fptk::kLeanClasses;
+            std::vector<int32_t> tiv[NC], tt0[NC], ttl[NC];
             for (int64_t i = 0; i < d->n_intervals; ++i) {
                 int64_t L64 = off[i + 1] - off[i];
                 if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
                 int L = (int)L64;
                 if (L == 0) continue;
                 if (L <= 1024) {
-                    int cls = L <= 256 ? 0 : (L <= 512 ? 1 : 2);
+                    int cls = lean_class(L);
                     tiv[cls].push_back((int32_t)i);
                     tt0[cls].push_back(0);
                     ttl[cls].push_back(L);
@@ -526,7 +536,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
                         int tl = std::min(split_len, L - t0);
                         int ta = std::max(0, t0 - H), tb = std::min(L, t0 + tl + H);
                         int n = tb - ta;
-                        int cls = n <= 256 ? 0 : (n <= 512 ? 1 : 2);
+                        int cls = lean_class(n);
                         tiv[cls].push_back((int32_t)i);
                         tt0[cls].push_back(t0);
                         ttl[cls].push_back(tl);
@@ -534,11 +544,12 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
                 }
             }
             std::vector<int32_t> flat;
-            int64_t n_tiles = (int64_t)(tiv[0].size() + tiv[1].size() + tiv[2].size());
+            int64_t n_tiles = 0;
+            for (int cls = 0; cls < NC; ++cls) n_tiles += (int64_t)tiv[cls].size();
             flat.reserve((size_t)n_tiles * 3);
-            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
-            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
-            for (int cls = 0; cls < 3; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
+            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
+            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
+            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
             void *d_new;
             c->plan_H = -1;  // invalid while the table is being replaced
             if (int rc = ws_get(c, 9, flat.size() * 4, &d_new)) return rc;
@@ -547,7 +558,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
             c->plan_off.assign(off, off + n_off);
             c->plan_tiles = n_tiles;
-            for (int cls = 0; cls < 3; ++cls) c->plan_cls_count[cls] = (int64_t)tiv[cls].size();
+            for (int cls = 0; cls < NC; ++cls) c->plan_cls_count[cls] = (int64_t)tiv[cls].size();
             c->plan_H = H;
         }
         sl.total_bases = off[d->n_intervals];
@@ -556,11 +567,15 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         sl.tile_t0 = sl.tile_iv + c->plan_tiles;
         sl.tile_tl = sl.tile_t0 + c->plan_tiles;
         int64_t first = 0;
-        const int cls_nt[3] = {256, 512, 1024};
-        for (int cls = 0; cls < 3; ++cls) {
-            if (c->plan_cls_count[cls] > 0)
-                launches.push_back({cls_nt[cls], first, c->plan_cls_count[cls], split_len});
-            first += c->plan_cls_count[cls];
+        for (int cls = 0; cls < fptk::kLeanClasses; ++cls) {
+            const int64_t n = c->plan_cls_count[cls];
+            if (n > 0) {
+                lean_launches.push_back({fptk::kLeanNT[cls], first, n, split_len});
+                const int nt = nt_class(fptk::kLeanNT[cls]);
+                if (!launches.empty() && launches.back().nt == nt) launches.back().count += n;
+                else launches.push_back({nt, first, n, split_len});
+            }
+            first += n;
         }
     }
 
@@ -619,13 +634,19 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         const bool memo_only = pass == 0;
         const bool main_pass = memo_only || !d_redo;
         if (rec && main_pass) HIP_TRY(hipEventRecord(c->tev[c->tev_used + 1], c->stream));
-        for (const launch_t &ln : launches) {
+        // first pass of memo mode: the lean kernel where it applies (the `detect` window widths)
+        bool lean_pass = false;
+        if (memo_only && c->use_lean) {
+            fptk::scan_launch s2 = sl;
+            s2.redo = (int32_t *)d_redo;
+            lean_pass = fptk::scan_lean_applies(s2);
+        }
+        for (const launch_t &ln : lean_pass ? lean_launches : launches) {
             fptk::scan_launch s2 = sl;
             s2.tile_len = ln.tile_len;
             s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
             s2.redo = (int32_t *)d_redo;
-            // first pass of memo mode: the lean kernel where it applies (the `detect` window widths)
-            const bool lean = memo_only && c->use_lean && fptk::scan_lean_applies(s2);
+            const bool lean = lean_pass;
             size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt)
                               : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)

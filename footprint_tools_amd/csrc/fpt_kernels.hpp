@@ -45,6 +45,8 @@ struct scan_launch {
 };
 
 // fpt_scan_lean.hip: the first pass of memo mode for the `detect` defaults (hw 5, shw 50, clip 0.01)
+constexpr int kLeanClasses = 7;
+constexpr int kLeanNT[kLeanClasses] = {128, 192, 256, 384, 512, 768, 1024};  // its workgroup sizes
 bool scan_lean_applies(const scan_launch &sl);
 bool scan_lean_applies_hw(int hw, int shw, int k_trim);
 size_t scan_lean_lds_bytes(int nt);

@@ -514,7 +514,15 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
 
 typedef void (*lean_kernel_t)(const lean_args);
 lean_kernel_t lean_kernel(int nt) {
-    return nt == 256 ? k_scan_lean<256> : (nt == 512 ? k_scan_lean<512> : k_scan_lean<1024>);
+    switch (nt) {
+        case 128: return k_scan_lean<128>;
+        case 192: return k_scan_lean<192>;
+        case 256: return k_scan_lean<256>;
+        case 384: return k_scan_lean<384>;
+        case 512: return k_scan_lean<512>;
+        case 768: return k_scan_lean<768>;
+        default: return k_scan_lean<1024>;
+    }
 }
 
 }  // namespace
@@ -522,7 +530,15 @@ lean_kernel_t lean_kernel(int nt) {
 namespace fptk {
 
 size_t scan_lean_lds_bytes(int nt) {
-    return nt == 256 ? lean_lds<256>::bytes : (nt == 512 ? lean_lds<512>::bytes : lean_lds<1024>::bytes);
+    switch (nt) {
+        case 128: return lean_lds<128>::bytes;
+        case 192: return lean_lds<192>::bytes;
+        case 256: return lean_lds<256>::bytes;
+        case 384: return lean_lds<384>::bytes;
+        case 512: return lean_lds<512>::bytes;
+        case 768: return lean_lds<768>::bytes;
+        default: return lean_lds<1024>::bytes;
+    }
 }
 
 hipError_t scan_lean_set_lds(int nt) {
@@ -603,7 +619,9 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
         std::vector<int64_t> h((size_t)grid * 8);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), a.trace, h.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE *f = fopen(trace_path, "wb")) {
+        char path[1024];
+        snprintf(path, sizeof path, "%s.%d", trace_path, nt);  // one file per workgroup size
+        if (FILE *f = fopen(path, "wb")) {
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
         }

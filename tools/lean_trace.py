@@ -5,7 +5,8 @@ import sys
 import numpy as np
 
 raw = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 8)
-slots = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # workgroups resident per CU
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 1024  # workgroup size -> workgroups resident per CU
+slots = {128: 10, 192: 8, 256: 6, 384: 5, 512: 4, 768: 2, 1024: 2}.get(nt, 2)
 hw = raw[:, 0] & 0xffffffff
 xcc = (raw[:, 0] >> 32) & 0xf
 cu = (xcc << 8) | ((hw >> 8) & 0xff)  # xcc, se, sh, cu
