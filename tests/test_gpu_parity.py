@@ -388,7 +388,7 @@ def test_fused_scan_ragged(fpt, orc):
     table = golden("kmer_probs.npz")["table"]
     hw, shw, clip, scales = 5, 50, 0.01, (3, 10)
     rs = np.random.RandomState(4)
-    lens = np.concatenate([[50, 1, 2000, 256, 257, 512, 513, 1024, 1025, 3100],
+    lens = np.concatenate([[50, 1, 2000, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 3100],
                            np.clip(rs.lognormal(5.0, 0.6, 40).astype(int), 50, 2000)])
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     pad = hw + shw
@@ -1402,7 +1402,8 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
         scales = (3, 5, 10, 20, 40)
     dm = str(rs.choice(["A", "A", "B", "C"]))
     n_iv = int(rs.randint(4, 20))
-    lens = rs.choice([3, 40, 64, 130, 256, 257, 400, 500, 512, 900, 1000, 1024, 1025, 1800], n_iv)
+    lens = rs.choice([3, 40, 64, 128, 129, 130, 192, 193, 256, 257, 384, 385, 400, 500, 512, 513, 600, 768, 769,
+                      900, 1000, 1024, 1025, 1800], n_iv)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     n_c = int(off[-1] + n_iv * (2 * pad + 1))
     n_s = int(off[-1] + n_iv * (2 * pad + 7))
