@@ -743,7 +743,17 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     // buffers are sized by the largest interval of a launch, so one 2,000-base interval in a
     // launch of 150-base ones would leave a single workgroup per compute unit (measured on the
     // whole-genome shape: 398 -> 69 ms per 7.1e7 bases)
-    constexpr int kClasses = 7;  // 64, 128, ..., 4096
+    // and by the workgroup size that leaves the fewest lanes idle in the draw loop (one lane per
+    // base and null track, intervals longer than the workgroup in several passes)
+    constexpr int kClasses = 9;
+    static const int cls_len[kClasses] = {64, 128, 192, 256, 384, 512, 1024, 2048, 4096};  // longest interval
+    static const int cls_n2[kClasses] = {64, 128, 256, 256, 512, 512, 1024, 2048, 4096};   // LDS buffers
+    static const int cls_nt[kClasses] = {64, 128, 192, 256, 192, 256, 256, 256, 256};      // lanes
+    auto cls_of = [&](int L) {
+        int k = 0;
+        while (cls_len[k] < L) ++k;
+        return k;
+    };
     std::vector<int32_t> cls_list[kClasses], longs;
     if (d->interval_off) {
         if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
@@ -761,9 +771,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
             if (L > kLdsMax) {
                 longs.push_back((int32_t)i);
             } else {
-                int k = 0;
-                while ((64 << k) < L) ++k;
-                cls_list[k].push_back((int32_t)i);
+                cls_list[cls_of((int)L)].push_back((int32_t)i);
             }
         }
     } else if (lmax <= 0) {
@@ -819,6 +827,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     if (!d->interval_off) {  // uniform batch
         if (lmax > kLdsMax) return launch_long(nullptr, 0);
         fl.n2_max = pow2(lmax);
+        fl.nt = cls_nt[cls_of(lmax)];
         HIP_TRY(fptk::launch_fdr(c->stream, fl));
         return launch_ok("k_fdr_null");
     }
@@ -842,7 +851,8 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the lists are pageable host memory
     for (int k = 0; k < kClasses; ++k) {
         if (cls_list[k].empty()) continue;
-        fl.n2_max = 64 << k;
+        fl.n2_max = cls_n2[k];
+        fl.nt = cls_nt[k];
         fl.iv_list = d_cls[k];
         fl.n_list = (int64_t)cls_list[k].size();
         HIP_TRY(fptk::launch_fdr(c->stream, fl));

@@ -12,6 +12,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -147,7 +148,9 @@ int fpt_allgather_track(fpt_ctx *c, fpt_comm *k, const double *send, const int64
     }
     if (!send && counts[k->rank] > 0) return fpt_internal_fail(FPT_ERR_INVALID, "null send buffer");
     hipStream_t st = fpt_internal_stream(c);
-    if (equal) {
+    // FPT_COMM_RAGGED=1 sends equal shards down the ragged path too (a one-GPU box can then run it)
+    const char *force = getenv("FPT_COMM_RAGGED");
+    if (equal && !(force && force[0] == '1')) {
         if (counts[0] == 0) return FPT_OK;
         NCCL_TRY(api().AllGather(send, recv, (size_t)counts[0], kNcclFloat64, k->comm, st));
         return FPT_OK;

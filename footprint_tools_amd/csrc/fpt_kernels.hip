@@ -1552,6 +1552,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 template __global__ void k_fdr_null<256, false>(const fdr_args);
 template __global__ void k_fdr_null<128, false>(const fdr_args);  // size classes of short intervals: fewer idle lanes
 template __global__ void k_fdr_null<64, false>(const fdr_args);
+template __global__ void k_fdr_null<192, false>(const fdr_args);  // 129..192 bases in one pass, 257..384 in two
 template __global__ void k_fdr_null<256, true>(const fdr_args);
 
 // ===========================================================================
@@ -1969,8 +1970,10 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.dbuf = fdr_lds_bytes(fl.n2_max, true) <= 40 * 1024 ? 1 : 0;
     size_t lds = fdr_lds_bytes(fl.n2_max, a.dbuf != 0);
     // one lane per base and null track: intervals of up to 64 / 128 bases get workgroups of that size
-    const int nt = fl.n2_max <= 64 ? 64 : (fl.n2_max <= 128 ? 128 : 256);
-    void (*kern)(const fdr_args) = nt == 64 ? k_fdr_null<64, false> : (nt == 128 ? k_fdr_null<128, false> : k_fdr_null<256, false>);
+    const int nt = fl.nt ? fl.nt : (fl.n2_max <= 64 ? 64 : (fl.n2_max <= 128 ? 128 : 256));
+    void (*kern)(const fdr_args) = nt == 64 ? k_fdr_null<64, false>
+                                   : nt == 128 ? k_fdr_null<128, false>
+                                   : nt == 192 ? k_fdr_null<192, false> : k_fdr_null<256, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {

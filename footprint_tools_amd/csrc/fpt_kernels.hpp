@@ -72,6 +72,7 @@ struct fdr_launch {
     const int32_t *dm_ids;
     int32_t ablate;
     int32_t n2_max;
+    int32_t nt;              // lanes per workgroup: 64 / 128 / 192 / 256 (0: chosen from n2_max)
     const int32_t *iv_list;  // optional DEVICE list of the intervals to process (n_list of them)
     int64_t n_list;
     void *gws;               // non-null: global-memory buffers, gws_stride bytes per workgroup,
