@@ -458,8 +458,57 @@ def g8():
     save("nbfit.npz", **out)
 
 
+# ---------------------------------------------------------------- G9: output writers
+def g9():
+    """Text written by the reference's own writer functions (cli/utils.py:86-210) for fixed inputs.
+    The module is executed from its file with a stand-in for pysam, which it imports at module
+    scope and uses only in the file checks."""
+    import importlib.util
+    import io
+    import types
+    sys.modules.setdefault("pysam", types.ModuleType("pysam"))
+    spec = importlib.util.spec_from_file_location(
+        "footprint_tools_cli_utils", os.path.join(ref_import.REF, "footprint_tools", "cli", "utils.py"))
+    cu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cu)
+    iv = ref_import.genomic_interval("chr7", 1000, 1012)
+    rs = np.random.RandomState(5)
+    stats = np.array([[3.0, 2.0, 0.123456, np.nan, 1.0],
+                      [0.0, 10.0, 33.3, 0.00004, 0.5],
+                      [-1.5, 1e-300, 0.99995, 0.00005, np.inf],
+                      [12345.678951, 0.5, 0.25, 1e-5, -np.inf],
+                      [7.0, 7.0, 0.00005000001, 0.99994999, 2.5e-5]])
+    stats = np.vstack([stats, rs.rand(7, 5) * np.array([30, 30, 1, 1, 1])])
+    fdr_cols = {
+        "a": np.array([1, 1, .001, .001, .002, 1, 1, 1, .0005, 1.0, 1.0, 1.0]),
+        "b": np.array([.001, .001, 1, 1, 1, 1, 1, 1, 1, .002, .003, .004]),
+        "c": np.array([np.nan, .001, .001, np.nan, 1, 1, .001, 1, 1, 1, 1, .001]),
+        "d": np.ones(12),
+        "e": np.array([.2, .3, .001, .5, .001, .6, .7, .8, .9, .001, .001, .95]),
+    }
+    out = {"stats": stats, "interval": np.array(["chr7", "1000", "1012"])}
+
+    def text(fn, *a, **kw):
+        buf = io.StringIO()
+        fn(*a, file=buf, **kw)
+        return buf.getvalue()
+
+    out["stats_all"] = np.array(text(cu.write_stats_to_output, iv, stats))
+    out["stats_filtered"] = np.array(text(cu.write_stats_to_output, iv, stats, filter_fn=lambda x: x[:, 1] >= 5))
+    out["stats_fmt6e_comma"] = np.array(text(cu.write_stats_to_output, iv, stats, delim=",", fmt_string="0.6e"))
+    for k, col in fdr_cols.items():
+        out["fdr_" + k] = col
+        out["seg_dec_" + k] = np.array(text(cu.write_segments_to_output, iv, col, 0.01, decreasing=True))
+        out["seg_inc_" + k] = np.array(text(cu.write_segments_to_output, iv, col, 0.5, name="fp", score_fn=np.max))
+    out["header_full"] = np.array(text(cu.write_output_header, ["exp", "obs", "-log(pval)", "-log(winpval)", "fdr"],
+                                       extra=["a", "b"]))
+    out["header_noname"] = np.array(text(cu.write_output_header, ["score"], include_name=False, extra="x=1"))
+    out["header_plain"] = np.array(text(cu.write_output_header, ["score"], delim=" "))
+    save("writers.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -475,3 +524,5 @@ if __name__ == "__main__":
         g7()
     if "8" in which:
         g8()
+    if "9" in which:
+        g9()

@@ -152,28 +152,36 @@ def test_shard_intervals_balanced():
 
 
 def test_output_writers_text_format():
-    """bedGraph / BED text of cli/utils.py:86-210: "%.4f" scores, merged segments."""
+    """bedGraph / BED text of cli/utils.py:86-210 against what the reference's own writer functions
+    wrote for the same inputs (tests/golden/writers.npz, made by make_golden.py g9): "%.4f" scores,
+    nan / inf spelling, filters, other delimiters and formats, merged segments both ways."""
     import io
     from footprint_tools_amd import detect
+    g = np.load(os.path.join(ROOT, "tests", "golden", "writers.npz"))
 
     class IV(object):
-        chrom, start, end = "chr7", 1000, 1004
+        chrom, start, end = str(g["interval"][0]), int(g["interval"][1]), int(g["interval"][2])
 
-    stats = np.array([[3.0, 2.0, 0.123456, np.nan, 1.0], [0.0, 10.0, 33.3, 0.00004, 0.5]])
-    buf = io.StringIO()
-    detect.write_stats_to_output(IV, stats, file=buf)
-    assert buf.getvalue() == ("chr7\t1000\t1001\t3.0000\t2.0000\t0.1235\tnan\t1.0000\n"
-                              "chr7\t1001\t1002\t0.0000\t10.0000\t33.3000\t0.0000\t0.5000\n")
-    buf = io.StringIO()
-    detect.write_stats_to_output(IV, stats, file=buf, filter_fn=lambda x: x[:, 1] >= 5)
-    assert buf.getvalue().count("\n") == 1 and buf.getvalue().startswith("chr7\t1001\t1002")
-    fdr_col = np.array([1, 1, .001, .001, .002, 1, 1, 1, .0005, 1.0])
-    buf = io.StringIO()
-    detect.write_segments_to_output(IV, fdr_col, 0.01, file=buf, decreasing=True)
-    assert buf.getvalue() == "chr7\t1000\t1011\t.\t0.0005\n"
-    buf = io.StringIO()
-    detect.write_output_header(["exp", "obs"], file=buf, include_name=False, extra=["a", "b"])
-    assert buf.getvalue().splitlines()[1:] == ["# a", "# b", "# chrom\tstart\tend\texp\tobs"]
+    def text(fn, *a, **kw):
+        buf = io.StringIO()
+        fn(*a, file=buf, **kw)
+        return buf.getvalue()
+
+    stats = g["stats"]
+    assert text(detect.write_stats_to_output, IV, stats) == str(g["stats_all"])
+    assert text(detect.write_stats_to_output, IV, stats, filter_fn=lambda x: x[:, 1] >= 5) == str(g["stats_filtered"])
+    assert text(detect.write_stats_to_output, IV, stats, delim=",", fmt_string="0.6e") == str(g["stats_fmt6e_comma"])
+    for k in "abcde":
+        col = g["fdr_" + k]
+        assert text(detect.write_segments_to_output, IV, col, 0.01, decreasing=True) == str(g["seg_dec_" + k]), k
+        assert text(detect.write_segments_to_output, IV, col, 0.5, name="fp", score_fn=np.max) == str(g["seg_inc_" + k]), k
+    # the first header line names the package and its version: everything after it is the reference's
+    hdr = text(detect.write_output_header, ["exp", "obs", "-log(pval)", "-log(winpval)", "fdr"], extra=["a", "b"])
+    assert hdr.startswith("# generated by ") and hdr.splitlines()[1:] == str(g["header_full"]).splitlines()[1:]
+    hdr = text(detect.write_output_header, ["score"], include_name=False, extra="x=1")
+    assert hdr.splitlines()[1:] == str(g["header_noname"]).splitlines()[1:] and hdr.endswith("\n")
+    hdr = text(detect.write_output_header, ["score"], delim=" ")
+    assert hdr.splitlines()[1:] == str(g["header_plain"]).splitlines()[1:]
 
 
 # ---------------------------------------------------------------- learn_dm: NB fit, piecewise fit, model
