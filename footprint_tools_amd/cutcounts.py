@@ -17,8 +17,11 @@ Differences, on purpose: the file is read sequentially by the library's own BGZF
 (htslib / pysam are not available here; no index, no CRAM), all alignments are kept on the device
 after the first pass, and 'fragments' (the fragment intervals the reference also returns; unused
 on this path) is always empty.  Unmapped reads carrying a position are skipped.  Parity of the
-reader is unpinned (no pysam to compare with); the rule itself is pinned by hand-derived vectors
-in tests/.
+file reader is unpinned (no pysam to compare with); the counting rule is pinned: tests compare
+`lookup` with what the reference's own `bamfile.lookup` returned for 6,000 alignments under five
+filter / offset settings (tests/golden/cutcounts.npz), and with hand-derived vectors.  One case of
+malformed input is not reproduced: two alignments that share a name and are both flagged read 1 (or
+both read 2) -- the reference's pairing dictionary (cutcounts.py:196-215) then drops the earlier one.
 """
 import ctypes as C
 

@@ -507,8 +507,110 @@ def g9():
     save("writers.npz", **out)
 
 
+# ---------------------------------------------------------------- G10: cut counts
+def g10():
+    """What the reference's own cutcounts.bamfile.lookup (cutcounts.py:119-313) returns for a fixed
+    list of alignments.  pysam is not installed here, so the module is executed from its file
+    over a stand-in that serves the alignments the way AlignmentFile.fetch does (mapped reads
+    overlapping the region, in coordinate order); the counting, pairing, filter and offset rules
+    that run are the reference's."""
+    import importlib.util
+    import types
+
+    def span(cigar):
+        n, num = 0, ""
+        for ch in cigar:
+            if ch.isdigit():
+                num += ch
+            else:
+                n += int(num) if ch in "MDN=X" else 0
+                num = ""
+        return n
+
+    class Read(object):
+        def __init__(self, chrom, r):
+            f = r["flag"]
+            self.reference_name, self.query_name = chrom, r["name"]
+            self.reference_start, self.reference_end = r["pos"], r["pos"] + span(r["cigar"])
+            self.mapping_quality, self.template_length = r["mapq"], r.get("tlen", 0)
+            self.is_paired, self.is_proper_pair = bool(f & 1), bool(f & 2)
+            self.is_reverse, self.is_read1, self.is_read2 = bool(f & 16), bool(f & 64), bool(f & 128)
+            self.is_secondary, self.is_qcfail = bool(f & 256), bool(f & 512)
+            self.is_duplicate, self.is_supplementary = bool(f & 1024), bool(f & 2048)
+
+    files = {}
+
+    class AlignmentFile(object):
+        def __init__(self, filepath, mode="rb", **kw):
+            self.refs, self.reads = files[filepath]
+
+        def fetch(self, chrom, start, end):
+            for r in self.reads:
+                if self.refs[r["ref"]][0] == chrom:
+                    x = Read(chrom, r)
+                    if x.reference_start < end and x.reference_end > start:
+                        yield x
+
+        def close(self):
+            pass
+
+    fake = types.ModuleType("pysam")
+    fake.AlignmentFile = AlignmentFile
+    fake.VariantRecord = type("VariantRecord", (), {})
+    saved = sys.modules.get("pysam")
+    sys.modules["pysam"] = fake
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "footprint_tools_cutcounts", os.path.join(ref_import.REF, "footprint_tools", "cutcounts.py"))
+        cc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cc)
+    finally:
+        if saved is not None:
+            sys.modules["pysam"] = saved
+    rs = np.random.RandomState(21)
+    refs = [("chr1", 6000), ("chr2", 4000)]
+    reads = []
+    for k in range(6000):
+        cig = str(rs.choice(["36M", "20M2D16M", "5S31M", "10M100N26M", "30M1I5M", "18=2X16=", "36M4H", "50M", "1M"]))
+        flag = int(rs.choice([0, 16, 99, 147, 83, 163, 1024, 1024 + 16, 512, 256, 256 + 16, 2048 + 16, 1 + 16,
+                              1 + 2 + 64 + 256, 1 + 2 + 128 + 2048, 1 + 64, 1 + 2 + 16 + 128 + 1024]))
+        r = dict(ref=int(rs.randint(0, 2)), pos=int(rs.randint(0, 3900)), cigar=cig, flag=flag,
+                 mapq=int(rs.choice([0, 1, 2, 30, 60, 255])), name="q%d" % k)
+        reads.append(r)
+        if flag in (99, 83) and rs.rand() < 0.7:  # its mate (read 2, other strand), same name, near by
+            reads.append(dict(r, flag=147 if flag == 99 else 163, pos=min(3900, r["pos"] + int(rs.randint(0, 300))),
+                              mapq=int(rs.choice([0, 30, 60]))))
+    reads.sort(key=lambda r: (r["ref"], r["pos"]))
+    files["x.bam"] = (refs, reads)
+    ivs = [("chr1", 300, 800, "+"), ("chr2", 10, 60, "+"), ("chr1", 350, 420, "-"), ("chr1", 780, 2000, "+"),
+           ("chr1", 3800, 3990, "+"), ("chr2", 1000, 1500, "-"), ("chr1", 0, 90, "+"), ("chr2", 3900, 3999, "+"),
+           ("chr1", 5, 6, "+")]
+    params = [dict(), dict(min_qual=0), dict(min_qual=31, remove_dups=True), dict(remove_qcfail=False, offset=(4, -5)),
+              dict(min_qual=2, remove_dups=True, remove_qcfail=False, offset=(1, 0))]
+    out = {"refs_name": np.array([r[0] for r in refs]), "refs_len": np.array([r[1] for r in refs]),
+           "read_ref": np.array([r["ref"] for r in reads]), "read_pos": np.array([r["pos"] for r in reads]),
+           "read_flag": np.array([r["flag"] for r in reads]), "read_mapq": np.array([r["mapq"] for r in reads]),
+           "read_cigar": np.array([r["cigar"] for r in reads]), "read_name": np.array([r["name"] for r in reads]),
+           "iv_chrom": np.array([v[0] for v in ivs]), "iv_start": np.array([v[1] for v in ivs]),
+           "iv_end": np.array([v[2] for v in ivs]), "iv_strand": np.array([v[3] for v in ivs]),
+           "params": np.array([[p.get("min_qual", 1), int(p.get("remove_dups", False)), int(p.get("remove_qcfail", True)),
+                                p.get("offset", (0, -1))[0], p.get("offset", (0, -1))[1]] for p in params])}
+    total = 0
+    for j, p in enumerate(params):
+        bf = cc.bamfile("x.bam", **p)
+        plus, minus = [], []
+        for c, a, b, st in ivs:
+            got = bf.lookup(ref_import.genomic_interval(c, a, b, strand=st))
+            plus.append(np.asarray(got["+"], np.float64))
+            minus.append(np.asarray(got["-"], np.float64))
+        out["plus_%d" % j], out["minus_%d" % j] = np.concatenate(plus), np.concatenate(minus)
+        total += out["plus_%d" % j].sum() + out["minus_%d" % j].sum()
+    assert total > 3000
+    save("cutcounts.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -526,3 +628,5 @@ if __name__ == "__main__":
         g8()
     if "9" in which:
         g9()
+    if "10" in which:
+        g10()

@@ -1042,6 +1042,25 @@ def test_cut_count_ingestion(fpt, orc, tmp_path):
     assert np.array_equal(g2["+"], w2p) and np.array_equal(g2["-"], w2m)
     bf.close(); bf2.close()
 
+    # the reference's own bamfile.lookup on 6,000 alignments (tests/golden/cutcounts.npz: made by
+    # executing cutcounts.py over a stand-in for pysam's fetch): five filter / offset settings,
+    # both strands of interest, intervals at chromosome ends
+    g = golden("cutcounts.npz")
+    grefs = [(str(n), int(l)) for n, l in zip(g["refs_name"], g["refs_len"])]
+    greads = [dict(ref=int(a), pos=int(b), cigar=str(c), flag=int(d), mapq=int(e), name=str(f))
+              for a, b, c, d, e, f in zip(g["read_ref"], g["read_pos"], g["read_cigar"], g["read_flag"], g["read_mapq"],
+                                          g["read_name"])]
+    path = str(tmp_path / "golden.bam")
+    write_bam(path, grefs, greads, block_bytes=20000)
+    givs = [Iv(str(c), int(a), int(b), str(s_)) for c, a, b, s_ in zip(g["iv_chrom"], g["iv_start"], g["iv_end"], g["iv_strand"])]
+    for j, (mq, rd, rq, o0, o1) in enumerate(g["params"]):
+        bfg = cutcounts.bamfile(path, min_qual=int(mq), remove_dups=bool(rd), remove_qcfail=bool(rq), offset=(int(o0), int(o1)))
+        gp = np.concatenate([bfg[iv]["+"] for iv in givs])
+        gm = np.concatenate([bfg[iv]["-"] for iv in givs])
+        assert np.array_equal(gp, g["plus_%d" % j]) and np.array_equal(gm, g["minus_%d" % j]), j
+        assert gp.sum() > 100
+        bfg.close()
+
     # random reads, overlapping / nested / edge intervals, against the rule restated in numpy
     rs = np.random.RandomState(2)
     from .test_ingest_cpu import _reads, _ref_span
