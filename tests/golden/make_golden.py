@@ -609,8 +609,124 @@ def g10():
     save("cutcounts.npz", **out)
 
 
+# ---------------------------------------------------------------- G11: the detect driver (cli/detect.py:43-145)
+def g11():
+    """Per-interval statistics from the reference's own driver class, cli/detect.py `deviation_stats`
+    (`__getitem__`: cutcounts.bamfile -> prediction.compute -> strand merge -> p_values ->
+    stouffers_z(3) -> sample / emperical_fdr -> column_stack), on the alignments of cutcounts.npz
+    and a random genome.  The module is executed from its file; what is absent from this image is
+    stood in for: pysam (alignments and sequence served from memory), genome_tools' `dataset`
+    base class (empty), click_option_group's decorators (identity)."""
+    import importlib.util
+    import tempfile
+    import types
+    g = np.load(os.path.join(HERE, "cutcounts.npz"))
+    refs = [(str(n), int(l)) for n, l in zip(g["refs_name"], g["refs_len"])]
+    reads = [dict(ref=int(a), pos=int(b), cigar=str(c), flag=int(d), mapq=int(e), name=str(f))
+             for a, b, c, d, e, f in zip(g["read_ref"], g["read_pos"], g["read_cigar"], g["read_flag"],
+                                         g["read_mapq"], g["read_name"])]
+    rs = np.random.RandomState(33)
+    genome = {name: "".join(rs.choice(list("ACGT"), n)) for name, n in refs}
+    genome["chr1"] = genome["chr1"][:2000] + genome["chr1"][2000:2100].lower() + "NNNN" + genome["chr1"][2104:]
+
+    def span(cigar):
+        n, num = 0, ""
+        for ch in cigar:
+            if ch.isdigit():
+                num += ch
+            else:
+                n += int(num) if ch in "MDN=X" else 0
+                num = ""
+        return n
+
+    class Read(object):
+        def __init__(self, chrom, r):
+            f = r["flag"]
+            self.reference_name, self.query_name = chrom, r["name"]
+            self.reference_start, self.reference_end = r["pos"], r["pos"] + span(r["cigar"])
+            self.mapping_quality, self.template_length = r["mapq"], 0
+            self.is_paired, self.is_proper_pair = bool(f & 1), bool(f & 2)
+            self.is_reverse, self.is_read1, self.is_read2 = bool(f & 16), bool(f & 64), bool(f & 128)
+            self.is_secondary, self.is_qcfail = bool(f & 256), bool(f & 512)
+            self.is_duplicate, self.is_supplementary = bool(f & 1024), bool(f & 2048)
+
+    class AlignmentFile(object):
+        def __init__(self, filepath, mode="rb", **kw):
+            pass
+
+        def fetch(self, chrom, start, end):
+            for r in reads:
+                if refs[r["ref"]][0] == chrom:
+                    x = Read(chrom, r)
+                    if x.reference_start < end and x.reference_end > start:
+                        yield x
+
+        def close(self):
+            pass
+
+    class FastaFile(object):
+        def __init__(self, filepath, **kw):
+            pass
+
+        def fetch(self, chrom, start, end):
+            return genome[chrom][start:end]
+
+    fake = types.ModuleType("pysam")
+    fake.AlignmentFile, fake.FastaFile = AlignmentFile, FastaFile
+    fake.VariantRecord = type("VariantRecord", (), {})
+    fake.set_verbosity = lambda v: None
+    cog = types.ModuleType("click_option_group")
+    ident = lambda *a, **k: (lambda f: f)
+    cog.optgroup = types.SimpleNamespace(group=ident, option=ident)
+    gtd = types.ModuleType("genome_tools.data")
+    gtds = types.ModuleType("genome_tools.data.dataset")
+    gtds.dataset = type("dataset", (), {})
+    saved = {k: sys.modules.get(k) for k in ("pysam", "click_option_group", "genome_tools.data", "genome_tools.data.dataset")}
+    sys.modules.update({"pysam": fake, "click_option_group": cog, "genome_tools.data": gtd,
+                        "genome_tools.data.dataset": gtds})
+    cli = types.ModuleType("footprint_tools.cli")
+    cli.__path__ = [os.path.join(ref_import.REF, "footprint_tools", "cli")]
+    sys.modules["footprint_tools.cli"] = cli
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "footprint_tools.cli.detect", os.path.join(ref_import.REF, "footprint_tools", "cli", "detect.py"))
+        det = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(det)
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+    ivs = [("chr1", 300, 800), ("chr1", 1900, 2300), ("chr2", 100, 237), ("chr1", 2500, 3750), ("chr2", 1000, 1064)]
+    bm = bias.kmer_model(os.path.join(ref_import.REF, "data", "vierstra_et_al.6mer-model.txt"))
+    dm = make_dm("A")
+    kw = dict(min_qual=1, remove_dups=True, remove_qcfail=True, offset=(0, -1), half_win_width=5, is_cram=False,
+              fasta_reference_filepath="g.fa", smoothing_half_win_width=50, smoothing_clip=0.01, fdr_shuffle_n=50)
+    with tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False) as f:
+        for c, a, b in ivs:
+            f.write("%s\t%d\t%d\n" % (c, a, b))
+        bed = f.name
+    try:
+        np.random.seed(7)  # cli/detect.py:348-352
+        ds = det.deviation_stats(bed, "x.bam", "g.fa", bm, dm, **kw)
+        out = {"genome_" + n: np.frombuffer(sq.encode(), np.uint8) for n, sq in genome.items()}
+        out["iv_chrom"] = np.array([v[0] for v in ivs])
+        out["iv_start"] = np.array([v[1] for v in ivs])
+        out["iv_end"] = np.array([v[2] for v in ivs])
+        assert len(ds) == len(ivs)
+        for i in range(len(ivs)):
+            rec = ds[i]
+            assert (rec["interval"].chrom, rec["interval"].start, rec["interval"].end) == ivs[i]
+            out["stats_%d" % i] = np.asarray(rec["stats"], np.float64)
+        ds_nodm = det.deviation_stats(bed, "x.bam", "g.fa", bm, None, **kw)  # no dispersion model: two columns
+        out["stats_nodm_0"] = np.asarray(ds_nodm[0]["stats"], np.float64)
+    finally:
+        os.remove(bed)
+    assert out["stats_0"].shape == (500, 5) and out["stats_0"][:, 1].sum() > 20
+    save("detect_driver.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -630,3 +746,5 @@ if __name__ == "__main__":
         g9()
     if "10" in which:
         g10()
+    if "11" in which:
+        g11()

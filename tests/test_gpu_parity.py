@@ -915,6 +915,70 @@ def test_deviation_stats_driver(fpt, orc, tmp_path):
     assert np.all(rec["stats"][:, 2:4] == 0.0) and np.all(rec["stats"][:, 4] == 1.0)
 
 
+def test_detect_driver_against_the_reference_driver(fpt, tmp_path):
+    """BAM + FASTA files -> cutcounts.bamfile / FastaFile -> detect.deviation_stats, against the records
+    the reference's own cli/detect.py `deviation_stats.__getitem__` produced for the same alignments,
+    genome (lower-case stretch, Ns) and intervals (tests/golden/detect_driver.npz, make_golden.py g11):
+    expected / observed counts bit for bit, -log p and -log window p to 1e-6, the empirical FDR --
+    other random draws than numpy's -- statistically."""
+    import itertools
+    from footprint_tools_amd import cutcounts, detect
+    from footprint_tools_amd.fasta import FastaFile
+    from footprint_tools_amd.modeling import bias, dispersion
+    from .bamwriter import write_bam
+    g, gc = golden("detect_driver.npz"), golden("cutcounts.npz")
+    refs = [(str(n), int(l)) for n, l in zip(gc["refs_name"], gc["refs_len"])]
+    reads = [dict(ref=int(a), pos=int(b), cigar=str(c), flag=int(d), mapq=int(e), name=str(f))
+             for a, b, c, d, e, f in zip(gc["read_ref"], gc["read_pos"], gc["read_cigar"], gc["read_flag"], gc["read_mapq"],
+                                         gc["read_name"])]
+    bam = str(tmp_path / "x.bam")
+    write_bam(bam, refs, reads, block_bytes=30000)
+    fa_path = str(tmp_path / "g.fa")
+    with open(fa_path, "w") as f:
+        for name, _ in refs:
+            sq = g["genome_" + name].tobytes().decode()
+            f.write(">%s\n" % name + "\n".join(sq[a:a + 60] for a in range(0, len(sq), 60)) + "\n")
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    bm = bias.bias_model()
+    for j, kk in enumerate(itertools.product("ACGT", repeat=6)):
+        bm["".join(kk)] = float(table[j])
+    dm = dispersion.dispersion_model()
+    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
+
+    class Interval(object):
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end = c, s, e
+
+        def widen(self, w):
+            return Interval(self.chrom, self.start - w, self.end + w)
+
+    ivs = [Interval(str(c), int(a), int(b)) for c, a, b in zip(g["iv_chrom"], g["iv_start"], g["iv_end"])]
+    bf, fa = cutcounts.bamfile(bam, min_qual=1, remove_dups=True, remove_qcfail=True, offset=(0, -1)), FastaFile(fa_path)
+    kw = dict(half_win_width=5, smoothing_half_win_width=50, smoothing_clip=0.01)
+    recs = detect.deviation_stats(ivs, bf, fa, bm, dm, fdr_shuffle_n=50, seed=7, **kw).compute(range(len(ivs)))
+    n_called = 0
+    for i, rec in enumerate(recs):
+        want, got = g["stats_%d" % i], rec["stats"]
+        assert got.shape == want.shape, i
+        assert np.array_equal(got[:, 0], want[:, 0]) and np.array_equal(got[:, 1], want[:, 1]), i
+        assert want[:, 1].sum() > 5
+        with np.errstate(all="ignore"):
+            assert rel_err(np.exp(-got[:, 2]), np.exp(-want[:, 2])) < P_TOL, i
+            assert rel_err(np.exp(-got[:, 3]), np.exp(-want[:, 3])) < P_TOL, i
+        d = np.abs(got[:, 4] - want[:, 4])
+        assert d.mean() < 0.02 and d.max() < 0.12, (i, d.mean(), d.max())
+        n_called += int((want[:, 4] < 0.05).sum())
+        # footprints at FDR 0.05 overlap: bases called by one and far from being called by the other are rare
+        far = ((got[:, 4] < 0.05) & (want[:, 4] > 0.15)) | ((want[:, 4] < 0.05) & (got[:, 4] > 0.15))
+        assert far.sum() <= 0.01 * got.shape[0], i
+    assert n_called > 50
+    nodm = detect.deviation_stats(ivs[:1], bf, fa, bm, None, **kw)[0]["stats"]
+    assert np.array_equal(nodm, g["stats_nodm_0"])
+    bf.close()
+    fa.close()
+
+
 def test_rccl_track_allgather_one_rank(fpt, orc, tmp_path):
     """The directly bound RCCL collective (fpt_comm_*, fpt_allgather_track) on a one-rank
     communicator -- all a one-GPU box can run: equal and in-place forms, the host conveniences
