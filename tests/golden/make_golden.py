@@ -725,8 +725,115 @@ def g11():
     save("detect_driver.npz", **out)
 
 
+# ---------------------------------------------------------------- G12: the posterior driver (cli/post.py:40-124)
+def g12():
+    """Records of the reference's own `posterior_stats.__getitem__` (tracks -> _load_data -> priors ->
+    windowed log-likelihoods -> posterior) for three datasets, and the JSON the reference's
+    write_dispersion_model wrote for their models.  Stand-ins as in g11; pysam.TabixFile serves the
+    track rows from memory the way fetch(..., parser=asTuple()) does."""
+    import importlib.util
+    import tempfile
+    import types
+    import pandas as pd
+    rs = np.random.RandomState(44)
+    keys = ["A", "C", "B"]
+    tracks, out = {}, {}
+    for d, key in enumerate(keys):
+        rows = []
+        for x in range(2000, 2400):
+            if rs.rand() < (0.0, 0.1, 0.3)[d]:
+                continue  # this dataset has no row here (w = 0)
+            e = float(rs.randint(0, 40))
+            o = float(max(0, int(e * rs.uniform(0.1, 1.6))))
+            f = float(rs.rand() ** 4)
+            rows.append(("chr7", x, "%.4f" % e, "%.4f" % o, "%.4f" % f))
+        tracks["t%d.gz" % d] = rows
+        out["track%d_pos" % d] = np.array([r[1] for r in rows])
+        out["track%d_exp" % d] = np.array([float(r[2]) for r in rows])
+        out["track%d_obs" % d] = np.array([float(r[3]) for r in rows])
+        out["track%d_fdr" % d] = np.array([float(r[4]) for r in rows])
+
+    class TabixFile(object):
+        def __init__(self, fn):
+            self.rows = tracks[os.path.basename(fn)]
+
+        def fetch(self, chrom, start, end, parser=None):
+            for c, x, e, o, f in self.rows:
+                if c == chrom and x < end and x + 1 > start:
+                    yield (c, str(x), str(x + 1), e, o, "0.5000", "0.5000", f)
+
+        def close(self):
+            pass
+
+    fake = types.ModuleType("pysam")
+    fake.TabixFile, fake.asTuple = TabixFile, (lambda: None)
+    fake.set_verbosity = lambda v: None
+    cog = types.ModuleType("click_option_group")
+    ident = lambda *a, **k: (lambda f: f)
+    cog.optgroup = types.SimpleNamespace(group=ident, option=ident)
+    gtd = types.ModuleType("genome_tools.data")
+    gtds = types.ModuleType("genome_tools.data.dataset")
+    gtds.dataset = type("dataset", (), {})
+    names = ("pysam", "click_option_group", "genome_tools.data", "genome_tools.data.dataset", "footprint_tools.cli")
+    saved = {k: sys.modules.get(k) for k in names}
+    cli = types.ModuleType("footprint_tools.cli")
+    cli.__path__ = [os.path.join(ref_import.REF, "footprint_tools", "cli")]
+    sys.modules.update({"pysam": fake, "click_option_group": cog, "genome_tools.data": gtd,
+                        "genome_tools.data.dataset": gtds, "footprint_tools.cli": cli})
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "footprint_tools.cli.post", os.path.join(ref_import.REF, "footprint_tools", "cli", "post.py"))
+        post = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(post)
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+    tmp = tempfile.mkdtemp()
+    dm_files = []
+    # simplejson (absent here) writes bytes values as utf-8 text, which is what makes the
+    # reference's base64 fields serialisable; the stdlib module standing in for it is told to
+    import json as _json
+    sj = types.ModuleType("simplejson")
+    sj.load, sj.loads = _json.load, _json.loads
+    sj.dumps = lambda o, **kw: _json.dumps(o, default=lambda v: v.decode("utf-8"), **kw)
+    sys.modules["simplejson"] = sj
+    for d, key in enumerate(keys):
+        model = make_dm(key)  # a learned model also carries its histogram and the per-row fits
+        model.h = rs.randint(0, 50, (6, 9)).astype(np.float64)
+        model.p, model.r = rs.rand(6), rs.rand(6) * 10
+        text = dispersion.write_dispersion_model(model, extra="dataset %d" % d)
+        out["dm_json_%d" % d] = np.array(text)
+        out["dm_h_%d" % d], out["dm_p_%d" % d], out["dm_r_%d" % d] = np.array(model.h), np.array(model.p), np.array(model.r)
+        fn = os.path.join(tmp, "dm%d.json" % d)
+        with open(fn, "w") as f:
+            f.write(text)
+        dm_files.append(fn)
+    betas = [(2.0, 5.0), (2.0, 6.5), (1.5, 4.0)]
+    samples = pd.DataFrame({"id": ["s%d" % d for d in range(3)], "tabix_file": [os.path.join(tmp, "t%d.gz" % d) for d in range(3)],
+                            "dm_file": dm_files, "beta_a": [b[0] for b in betas], "beta_b": [b[1] for b in betas]})
+    ivs = [("chr7", 1990, 2310), ("chr7", 2350, 2420), ("chr7", 2100, 2101), ("chr8", 10, 40)]
+    bed = os.path.join(tmp, "iv.bed")
+    with open(bed, "w") as f:
+        f.write("# comment line\n")
+        for c, a, b in ivs:
+            f.write("%s\t%d\t%d\n" % (c, a, b))
+    ps = post.posterior_stats(bed, samples, 0.05)
+    assert len(ps) == len(ivs)
+    out["betas"], out["fdr_cutoff"] = np.array(betas), np.array(0.05)
+    out["iv_chrom"] = np.array([v[0] for v in ivs])
+    out["iv_start"], out["iv_end"] = np.array([v[1] for v in ivs]), np.array([v[2] for v in ivs])
+    for i in range(len(ivs)):
+        rec = ps[i]
+        out["stats_%d" % i] = np.asarray(rec["stats"], np.float64)
+    assert out["stats_0"].shape == (320, 3) and (out["stats_0"] > 0).any()
+    save("post_driver.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -748,3 +855,5 @@ if __name__ == "__main__":
         g10()
     if "11" in which:
         g11()
+    if "12" in which:
+        g12()

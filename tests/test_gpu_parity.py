@@ -1225,6 +1225,42 @@ def test_posterior_driver_from_tracks(fpt, tmp_path):
     assert (rec["stats"][10:310] > 0).any()
 
 
+def test_posterior_driver_against_the_reference_driver(fpt, tmp_path):
+    """Track files + dispersion-model JSON written by the reference -> post.posterior_stats, against the
+    records of the reference's own cli/post.py `posterior_stats.__getitem__` (tests/golden/post_driver.npz,
+    make_golden.py g12): three datasets with gaps, an interval past the data, one of a single base,
+    one on a chromosome no track has."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.post import posterior_stats
+    from .bamwriter import _bgzf_block
+    g = golden("post_driver.npz")
+    rows = []
+    for d in range(3):
+        dmp = tmp_path / ("dm%d.json" % d)
+        dmp.write_text(str(g["dm_json_%d" % d]))
+        dm = dispersion.load_dispersion_model(str(dmp))  # the reference's own JSON (dispersion.pyx:523-549)
+        assert np.array_equal(dm.h, g["dm_h_%d" % d]) and np.array_equal(dm.p, g["dm_p_%d" % d])
+        assert np.array_equal(dm.r, g["dm_r_%d" % d]) and dm.metadata == "dataset %d" % d
+        lines = ["chr7\t%d\t%d\t%.4f\t%.4f\t0.5000\t0.5000\t%.4f" % (x, x + 1, e, o, f)
+                 for x, e, o, f in zip(g["track%d_pos" % d], g["track%d_exp" % d], g["track%d_obs" % d], g["track%d_fdr" % d])]
+        path = tmp_path / ("t%d.gz" % d)
+        with open(path, "wb") as fh:
+            data = ("\n".join(lines) + "\n").encode()
+            for a in range(0, len(data), 5000):
+                fh.write(_bgzf_block(data[a:a + 5000]))
+            fh.write(_bgzf_block(b""))
+        rows.append(dict(id="s%d" % d, tabix_file=str(path), dm_file=str(dmp), beta_a=float(g["betas"][d, 0]),
+                         beta_b=float(g["betas"][d, 1])))
+    ivs = [(str(c), int(a), int(b)) for c, a, b in zip(g["iv_chrom"], g["iv_start"], g["iv_end"])]
+    ps = posterior_stats(ivs, rows, fdr_cutoff=float(g["fdr_cutoff"]))
+    for i in range(len(ivs)):
+        want, got = g["stats_%d" % i], ps[i]["stats"]
+        assert got.shape == want.shape, i
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9, equal_nan=True), (i, np.nanmax(np.abs(got - want)))
+        assert np.array_equal(got > 0, want > 0) or np.abs(got - want)[(got > 0) != (want > 0)].max() < 1e-9
+    assert (g["stats_0"] > 1).any()
+
+
 def test_exp_obs_histogram(fpt, orc):
     """cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1, out-of-range pairs ignored."""
     sc, lat, out = _scan_small(orc, 40, 500, 77, bump=slice(0, 20000, 13))
