@@ -687,12 +687,20 @@ def g11():
     cli = types.ModuleType("footprint_tools.cli")
     cli.__path__ = [os.path.join(ref_import.REF, "footprint_tools", "cli")]
     sys.modules["footprint_tools.cli"] = cli
+    gtdu = types.ModuleType("genome_tools.data.utils")
+    gtdu.numpy_collate_concat = lambda x: np.concatenate(x)
+    sys.modules["genome_tools.data.utils"] = gtdu
     try:
         spec = importlib.util.spec_from_file_location(
             "footprint_tools.cli.detect", os.path.join(ref_import.REF, "footprint_tools", "cli", "detect.py"))
         det = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(det)
+        spec = importlib.util.spec_from_file_location(
+            "footprint_tools.cli.learn_dm", os.path.join(ref_import.REF, "footprint_tools", "cli", "learn_dm.py"))
+        ldm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ldm)
     finally:
+        sys.modules.pop("genome_tools.data.utils", None)
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
@@ -719,6 +727,11 @@ def g11():
             out["stats_%d" % i] = np.asarray(rec["stats"], np.float64)
         ds_nodm = det.deviation_stats(bed, "x.bam", "g.fa", bm, None, **kw)  # no dispersion model: two columns
         out["stats_nodm_0"] = np.asarray(ds_nodm[0]["stats"], np.float64)
+        # cli/learn_dm.py:30-107: the same chain with the predictor's class defaults (no smoothing)
+        ec = ldm.expected_counts(bed, "x.bam", "g.fa", bm, min_qual=1, remove_dups=True, remove_qcfail=True,
+                                 offset=(0, -1), half_win_width=5)
+        for i in range(len(ivs)):
+            out["learn_cnts_%d" % i] = np.asarray(ec[i], np.float64)
     finally:
         os.remove(bed)
     assert out["stats_0"].shape == (500, 5) and out["stats_0"][:, 1].sum() > 20

@@ -975,6 +975,15 @@ def test_detect_driver_against_the_reference_driver(fpt, tmp_path):
     assert n_called > 50
     nodm = detect.deviation_stats(ivs[:1], bf, fa, bm, None, **kw)[0]["stats"]
     assert np.array_equal(nodm, g["stats_nodm_0"])
+    # cli/learn_dm.py `expected_counts.__getitem__` (no smoothing) on the same files, and its histogram loop
+    from footprint_tools_amd import learn
+    ec = learn.expected_counts(ivs, bf, fa, bm, half_win_width=5, batch_size=2)
+    want_hist = np.zeros((200, 1000), dtype=np.int64)
+    for i, rec in enumerate(ec.compute(range(len(ivs)))):
+        assert np.array_equal(rec, g["learn_cnts_%d" % i]), i
+        for a_, b_ in g["learn_cnts_%d" % i]:  # cli/learn_dm.py:281-287
+            want_hist[int(a_), int(b_)] += 1
+    assert np.array_equal(ec.histogram(), want_hist)
     bf.close()
     fa.close()
 
