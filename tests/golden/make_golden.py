@@ -813,6 +813,15 @@ def g12():
     sj.load, sj.loads = _json.load, _json.loads
     sj.dumps = lambda o, **kw: _json.dumps(o, default=lambda v: v.decode("utf-8"), **kw)
     sys.modules["simplejson"] = sj
+    import datetime as _dt
+    real_datetime = _dt.datetime
+
+    class _frozen(real_datetime):  # the writer stamps the file with datetime.now(): keep the fixture reproducible
+        @classmethod
+        def now(cls, tz=None):
+            return cls(2024, 1, 1, 0, 0, 0)
+
+    _dt.datetime = _frozen
     for d, key in enumerate(keys):
         model = make_dm(key)  # a learned model also carries its histogram and the per-row fits
         model.h = rs.randint(0, 50, (6, 9)).astype(np.float64)
@@ -824,6 +833,7 @@ def g12():
         with open(fn, "w") as f:
             f.write(text)
         dm_files.append(fn)
+    _dt.datetime = real_datetime
     betas = [(2.0, 5.0), (2.0, 6.5), (1.5, 4.0)]
     samples = pd.DataFrame({"id": ["s%d" % d for d in range(3)], "tabix_file": [os.path.join(tmp, "t%d.gz" % d) for d in range(3)],
                             "dm_file": dm_files, "beta_a": [b[0] for b in betas], "beta_b": [b[1] for b in betas]})
