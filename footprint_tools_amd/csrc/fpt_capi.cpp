@@ -64,6 +64,7 @@ struct fpt_ctx {
     // computed), 16 bytes per entry and model; batches with more models than memo2_models skip it
     int memo2_rows = 1024, memo2_stride = 4096, memo2_models = 4;
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
+    bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
     // the 1e-4 tail of the widest rows is hit in every batch.
@@ -179,6 +180,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
                     device_id, prop.gcnArchName);
     fpt_ctx *c = new fpt_ctx();
     if (const char *e = getenv("FPT_SCAN_LEAN")) c->use_lean = atoi(e) != 0;
+    if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     // any failure below releases what was created so far (fpt_ctx_destroy skips null members)
@@ -595,9 +597,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
 #endif
     // bias-table placement: through the L1/L2 caches by default (measured 25 % faster than a
     // per-workgroup LDS copy, which costs 33 KB of LDS and a third of the occupancy);
-    // FPT_TABLE_LDS=1 selects the LDS-staged variant
-    sl.table_global = 1;
-    if (const char *e = getenv("FPT_TABLE_LDS")) sl.table_global = atoi(e) ? 0 : 1;
+    // a context created under FPT_TABLE_LDS=1 uses the LDS-staged variant
+    sl.table_global = c->table_lds ? 0 : 1;
     sl.memo = d_memo;
     sl.memo_exp = c->memo_exp;
     sl.memo_obs = c->memo_obs;

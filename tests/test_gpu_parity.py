@@ -16,6 +16,11 @@ P_TOL = 1e-6   # the contract
 TIGHT = 1e-9   # what the kernels are expected to reach (device libm, FMA contraction)
 
 
+def _lean_on():
+    """the lean first pass is what runs unless the suite is run under one of the diagnostic switches"""
+    return os.environ.get("FPT_SCAN_LEAN", "1") != "0" and os.environ.get("FPT_TABLE_LDS", "0") == "0"
+
+
 @pytest.fixture(scope="module")
 def fpt():
     if not has_gpu():
@@ -589,8 +594,9 @@ def test_heavy_tailed_workload(fpt, orc):
     sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr, d_out.ptr + t8, d_out.ptr + 2 * t8,
                 d_out.ptr + 3 * t8, interval_len=L)
     tiles, redone, miss = ctx.scan_stats()
-    assert tiles == n_iv and 0.05 * n_iv < redone < 0.2 * n_iv, (tiles, redone)
-    assert miss[0] >= 256 or miss[1] >= 256, miss
+    if _lean_on():  # what the first pass flags and records is specific to the lean kernel
+        assert tiles == n_iv and 0.05 * n_iv < redone < 0.2 * n_iv, (tiles, redone)
+        assert miss[0] >= 256 or miss[1] >= 256, miss
     cp = orc.synth_hotspots(orc.synth_counts(5, 0, n_iv * l, 0), 5, 0, 0, l, per_mille)
     cm = orc.synth_hotspots(orc.synth_counts(5, 0, n_iv * l, 1), 5, 0, 1, l, per_mille)
     sq = orc.synth_bases(5, 0, n_iv * (l + 6))
@@ -1580,7 +1586,8 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
     out = sc.scan(cp, cm, sq, interval_off=off)
     tiles, redone, miss = sc.ctx.scan_stats()
     tag = (seed, kind, scales, dm, lens.tolist(), tiles, redone)
-    if kind in ("over", "float", "neg"):
+    lean_on = _lean_on()
+    if kind in ("over", "float", "neg") and lean_on:
         assert redone > 0, tag
     for i, L in enumerate(lens):
         a, b = off[i] + i * (2 * pad + 1), off[i + 1] + (i + 1) * (2 * pad + 1)
