@@ -625,8 +625,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     int64_t tiles_total = 0;
     for (const launch_t &ln : launches) tiles_total = std::max(tiles_total, ln.first + ln.count);
     void *d_redo = nullptr;
+    void *d_redo_list = nullptr;
     if (use_memo && sl.table_global) {
         if (int rc = ws_get(c, 7, (size_t)tiles_total * sizeof(int32_t), &d_redo)) return rc;
+        if (int rc = ws_get(c, 11, (size_t)tiles_total * sizeof(int32_t), &d_redo_list)) return rc;
         HIP_TRY(hipMemsetAsync(d_redo, 0, (size_t)tiles_total * sizeof(int32_t), c->stream));
     }
     // pass 0 (memo mode only): memo-only instance over every tile; pass 1: full instance (over
@@ -647,6 +649,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             s2.tile_len = ln.tile_len;
             s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
             s2.redo = (int32_t *)d_redo;
+            s2.redo_list = (int32_t *)d_redo_list;
+            s2.redo_cursor = c->d_flags + 10;  // [10], [11]: count and cursor of the second pass
             const bool lean = lean_pass;
             size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt)
                               : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);

@@ -273,6 +273,8 @@ struct scan_args {
     int64_t tile_end;            // second pass: one past the last tile of the launch
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
+    const int32_t *redo_list;    // second pass: the flagged tiles of the launch (relative to tile_first) ...
+    int32_t *redo_cursor;        // ... [0] how many, [1] the next one to hand out (k_redo_compact fills, workgroups take)
     const int32_t *dm_ids;       // per interval: dispersion-model slot relative to `model` (or nullptr)
     // second-level (exp, obs) table of the redo pass: rows of memo2_stride entries, valid for
     // exp <= memo2_max[0] and obs <= memo2_max[1] (device values: the largest pair the first pass
@@ -1018,11 +1020,25 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     }
 }
 
+// The tiles the first pass of memo mode flagged, as a list (order does not matter): one lane per
+// tile, one atomic per wavefront.
+__global__ void __launch_bounds__(256) k_redo_compact(const int32_t *__restrict__ flags, int64_t n,
+                                                      int32_t *__restrict__ list, int32_t *__restrict__ cursor) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long m = __ballot(f);
+    if (m == 0) return;
+    int base = 0;
+    if ((threadIdx.x & (kWave - 1)) == 0) base = atomicAdd(&cursor[0], __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (f) list[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (int32_t)i;
+}
+
 // One tile per workgroup, except in the second pass of memo mode (REDO: the full instance over the
-// tiles the memo-only pass flagged): there a workgroup walks kRedoGroup consecutive tiles and
-// processes the flagged ones, so a pass in which nothing is flagged costs 1/kRedoGroup of the
-// workgroup launches instead of one early exit per tile.
-constexpr int kRedoGroup = 16;
+// tiles the memo-only pass flagged): there as many workgroups as the GPU holds at once take the
+// flagged tiles off k_redo_compact's list one by one (an atomic cursor), so a pass in which
+// nothing is flagged costs one short launch (it used to be one workgroup per 16 tiles: 0.31 ms
+// of wavefront launches per 10^6 tiles), and a pass with hotspots is balanced dynamically.
 template <int NT, int HWC, int SHWC, bool TBLG, bool MO, bool REDO>
 __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused(const scan_args a) {
     if constexpr (!REDO) {
@@ -1032,20 +1048,16 @@ __global__ void __launch_bounds__(NT, FPT_SCAN_WAVES(NT, TBLG, MO)) k_scan_fused
         // scalar loads) whose pointer is re-laundered every iteration, so that the argument loads
         // are not hoisted out of the loop either
         kernarg_scan_args *ap = (kernarg_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
-        // the group's flags first (independent scalar loads, one wait), then only the flagged tiles
-        const int64_t first = ap->tile_first + (int64_t)blockIdx.x * kRedoGroup;
-        const int32_t *flags = ap->redo + first;
-        const int64_t left = ap->tile_end - first;
-        unsigned todo = 0;
-#pragma unroll
-        for (int i = 0; i < kRedoGroup; ++i)
-            if (i < left && flags[i] != 0) todo |= 1u << i;
-        while (todo) {
-            const int i = __builtin_ctz(todo);
-            todo &= todo - 1;
+        __shared__ int next_tile;
+        for (;;) {
             asm volatile("" : "+s"(ap));  // argument loads stay inside the iteration that needs them
-            __syncthreads();              // a previous tile of this workgroup is done with LDS
-            scan_tile<NT, HWC, SHWC, TBLG, false, true>(*ap, first + i);
+            __syncthreads();              // the previous tile of this workgroup is done with LDS
+            if (threadIdx.x == 0) next_tile = atomicAdd(&ap->redo_cursor[1], 1);
+            __syncthreads();
+            const int j = __builtin_amdgcn_readfirstlane(next_tile);
+            if (j >= ((const __attribute__((address_space(4))) int32_t *)ap->redo_cursor)[0]) break;
+            const int64_t tile = ap->tile_first + ((const __attribute__((address_space(4))) int32_t *)ap->redo_list)[j];
+            scan_tile<NT, HWC, SHWC, TBLG, false, true>(*ap, tile);
         }
     }
 }
@@ -1896,9 +1908,22 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
     a.tile_end = sl.tile_first + (int64_t)grid;
     const bool second_pass = sl.redo && !memo_only;
-    if (second_pass) grid = (grid + kRedoGroup - 1) / kRedoGroup;  // see k_scan_fused
-    hipLaunchKernelGGL(scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only, second_pass), dim3(grid),
-                       dim3(nt), lds, st, a);
+    a.redo_list = nullptr;
+    a.redo_cursor = nullptr;
+    void (*kern)(const scan_args) = scan_kernel(nt, sl.hw, sl.shw, sl.table_global != 0, memo_only, second_pass);
+    if (second_pass) {  // the flagged tiles as a list, then as many workgroups as are resident at once
+        a.redo_list = sl.redo_list + sl.tile_first;
+        a.redo_cursor = sl.redo_cursor;
+        (void)hipMemsetAsync(sl.redo_cursor, 0, 2 * sizeof(int32_t), st);
+        hipLaunchKernelGGL(k_redo_compact, dim3((grid + 255) / 256), dim3(256), 0, st, sl.redo + sl.tile_first,
+                           (int64_t)grid, sl.redo_list + sl.tile_first, sl.redo_cursor);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, nt, lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        const int64_t resident = (int64_t)per_cu * (sl.n_cu > 0 ? sl.n_cu : 256);
+        if (grid > resident) grid = (int)resident;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, a);
 }
 
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs,

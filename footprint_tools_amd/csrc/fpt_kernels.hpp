@@ -34,6 +34,8 @@ struct scan_launch {
     int32_t counts_only;
     int32_t ablate;
     int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
+    int32_t *redo_list;    // second pass: room for the flagged tiles of all launches (one int32 per tile) ...
+    int32_t *redo_cursor;  // ... and two device ints (count, next), zeroed by launch_scan
     const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
     const void *table2;    // bias table in the lean kernel's order (build_lean_table), or nullptr
