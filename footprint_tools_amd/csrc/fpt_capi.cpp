@@ -615,11 +615,6 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         sl.memo2_stride = c->memo2_stride;
     }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used] : c->ev0, c->stream));
-    if (d_memo2) HIP_TRY(hipMemsetAsync(d_miss, 0xff, 2 * sizeof(int32_t), c->stream));  // -1, -1
-    if (use_memo) {  // rebuilt on every call: part of the timed work, never reused across calls
-        fptk::launch_nb_memo(c->stream, sl.model, n_dm, c->memo_exp, c->memo_obs, d_memo);
-        if (int rc = launch_ok("k_nb_memo")) return rc;
-    }
     // memo mode runs two passes per size class: the light memo-only instance over every tile,
     // then the full instance over the tiles it flagged (early exit for the others)
     int64_t tiles_total = 0;
@@ -629,7 +624,14 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     if (use_memo && sl.table_global) {
         if (int rc = ws_get(c, 7, (size_t)tiles_total * sizeof(int32_t), &d_redo)) return rc;
         if (int rc = ws_get(c, 11, (size_t)tiles_total * sizeof(int32_t), &d_redo_list)) return rc;
-        HIP_TRY(hipMemsetAsync(d_redo, 0, (size_t)tiles_total * sizeof(int32_t), c->stream));
+    }
+    if (use_memo) {
+        // the table is rebuilt on every call: part of the timed work, never reused across calls.  The
+        // same launch zeroes the redo flags and resets d_flags[8..15]: the largest missed pair
+        // (-1, -1) and the (count, cursor) pairs of the second pass, one per workgroup size
+        fptk::launch_nb_memo(c->stream, sl.model, n_dm, c->memo_exp, c->memo_obs, d_memo, (int32_t *)d_redo,
+                             d_redo ? tiles_total : 0, d_miss);
+        if (int rc = launch_ok("k_nb_memo")) return rc;
     }
     // pass 0 (memo mode only): memo-only instance over every tile; pass 1: full instance (over
     // the flagged tiles in memo mode, over everything in direct mode)
@@ -650,7 +652,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             s2.nc_max = (ln.nt + 2 * pad + 1 + 63) & ~63;  // whole 64-position tiles
             s2.redo = (int32_t *)d_redo;
             s2.redo_list = (int32_t *)d_redo_list;
-            s2.redo_cursor = c->d_flags + 10;  // [10], [11]: count and cursor of the second pass
+            // count and cursor of the second pass: a pair of d_flags[10..15] per workgroup size
+            s2.redo_cursor = c->d_flags + 10 + 2 * (ln.nt <= 256 ? 0 : (ln.nt <= 512 ? 1 : 2));
             const bool lean = lean_pass;
             size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt)
                               : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
@@ -661,6 +664,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
                 int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
                 s2.tile_first = ln.first + done;
+                s2.redo_cursor_clear = done > 0 ? 1 : 0;  // a second chunk of the same size class reuses the pair
                 if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
                 else fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
                 if (int rc = launch_ok("k_scan_fused")) return rc;

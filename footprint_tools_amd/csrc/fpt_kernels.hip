@@ -306,8 +306,18 @@ constexpr long long kZeroDivZBits = 0x7ff800005a440000ll;
 
 // (p, z) for every integer pair (exp, obs) of the table: the same device functions the
 // direct path calls, so a lookup returns bit-identical values.
+// It is the first kernel of a scan call, so it also resets the call's device state (fewer stream
+// operations per call: launch gaps are what a small batch costs): the per-tile redo flags, the
+// largest missed pair (-1, -1) and the cursors of the second pass.
 __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ models, int memo_exp,
-                                                    int memo_obs, double2 *__restrict__ memos) {
+                                                    int memo_obs, double2 *__restrict__ memos,
+                                                    int32_t *__restrict__ clear, int64_t n_clear,
+                                                    int32_t *__restrict__ state) {
+    if (blockIdx.y == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_clear; i += (int64_t)gridDim.x * blockDim.x)
+            clear[i] = 0;
+        if (state && blockIdx.x == 0 && threadIdx.x < 8) state[threadIdx.x] = threadIdx.x < 2 ? -1 : 0;
+    }
     // blockIdx.y = model slot: one table per dispersion model in use
     __shared__ double par[24];
     const double *model = models + (size_t)blockIdx.y * 24;
@@ -1914,7 +1924,7 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     if (second_pass) {  // the flagged tiles as a list, then as many workgroups as are resident at once
         a.redo_list = sl.redo_list + sl.tile_first;
         a.redo_cursor = sl.redo_cursor;
-        (void)hipMemsetAsync(sl.redo_cursor, 0, 2 * sizeof(int32_t), st);
+        if (sl.redo_cursor_clear) (void)hipMemsetAsync(sl.redo_cursor, 0, 2 * sizeof(int32_t), st);
         hipLaunchKernelGGL(k_redo_compact, dim3((grid + 255) / 256), dim3(256), 0, st, sl.redo + sl.tile_first,
                            (int64_t)grid, sl.redo_list + sl.tile_first, sl.redo_cursor);
         int per_cu = 0;
@@ -1927,10 +1937,10 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
 }
 
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs,
-                    void *memo) {
+                    void *memo, int32_t *clear, int64_t n_clear, int32_t *state) {
     int n = memo_exp * memo_obs;
     hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256, n_models), dim3(256), 0, st, models, memo_exp,
-                       memo_obs, (double2 *)memo);
+                       memo_obs, (double2 *)memo, clear, n_clear, state);
 }
 
 void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,

@@ -35,7 +35,8 @@ struct scan_launch {
     int32_t ablate;
     int32_t *redo;         // per-tile redo flags (memo mode), or nullptr
     int32_t *redo_list;    // second pass: room for the flagged tiles of all launches (one int32 per tile) ...
-    int32_t *redo_cursor;  // ... and two device ints (count, next), zeroed by launch_scan
+    int32_t *redo_cursor;  // ... and two device ints (count, next): zero when the launch starts ...
+    int32_t redo_cursor_clear;  // ... or zeroed by launch_scan when this is set
     const int32_t *dm_ids; // per-interval model slot relative to `model`, or nullptr
     int32_t table_global;  // bias table read through the L1/L2 caches (default) instead of an LDS copy
     const void *table2;    // bias table in the lean kernel's order (build_lean_table), or nullptr
@@ -116,7 +117,10 @@ void launch_window_rows(hipStream_t st, int op, const double *x, const double *w
 size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only);
 hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, bool second_pass, size_t lds);
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
-void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo);
+// clear / n_clear: int32 words set to 0; state: 8 ints set to (-1, -1, 0 x 6) -- the largest missed pair
+// and three (count, cursor) pairs of the second pass; both optional
+void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo,
+                    int32_t *clear = nullptr, int64_t n_clear = 0, int32_t *state = nullptr);
 void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
                      int memo_obs, int rows, int stride, void *memo2);
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
