@@ -1018,6 +1018,13 @@ int fpt_dev_free(fpt_ctx *c, void *dev) {
     return FPT_OK;
 }
 
+int fpt_dev_zero(fpt_ctx *c, void *dev, int64_t bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (bytes < 0 || (!dev && bytes > 0)) return fail(FPT_ERR_INVALID, "bad arguments");
+    if (bytes > 0) HIP_TRY(hipMemsetAsync(dev, 0, (size_t)bytes, c->stream));
+    return FPT_OK;
+}
+
 int fpt_memcpy_h2d(fpt_ctx *c, void *dev, const void *host, int64_t bytes) {
     if (int rc = check_ctx(c)) return rc;
     if (bytes < 0 || ((!dev || !host) && bytes > 0)) return fail(FPT_ERR_INVALID, "bad arguments");

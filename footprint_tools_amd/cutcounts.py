@@ -153,10 +153,7 @@ class bamfile(object):
         off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
         total = int(off[-1])
         if counts_plus is None:
-            counts_plus, counts_minus = DeviceArray(ctx, max(total, 1) * 8), DeviceArray(ctx, max(total, 1) * 8)
-            zeros = np.zeros(max(total, 1))
-            counts_plus.upload(zeros)
-            counts_minus.upload(zeros)
+            counts_plus, counts_minus = DeviceArray(ctx, max(total, 1) * 8).zero(), DeviceArray(ctx, max(total, 1) * 8).zero()
         rid = np.array([self._ref_index.get(c, -1) for c in chroms], dtype=np.int64)
         known = rid >= 0  # a chromosome the file does not have: all zeros, like an empty fetch
         key = (rid << 32) | np.clip(starts, 0, None)

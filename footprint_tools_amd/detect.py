@@ -73,6 +73,69 @@ class deviation_stats(object):
             seq = seq.encode("ascii", "replace")
         return cp, cm, np.frombuffer(bytes(seq), dtype=np.uint8)
 
+    def _device_inputs(self):
+        """True when the two readers can hand a whole batch over without a round trip per interval:
+        a `cutcounts.bamfile` (its alignments live on the device, `cut_counts_dev` fills the padded
+        count arrays there in one launch) and a `fasta.FastaFile` (`fetch_batch`)."""
+        return (hasattr(self.read_func, "cut_counts_dev") and hasattr(self.fasta_func, "fetch_batch")
+                and self.bm.offset() == 3 and getattr(self.read_func, "_ctx", None) in (None, self._scanner().ctx))
+
+    def _runs(self, indices):
+        """maximal runs of consecutive indices: one FDR call each keeps the RNG counters global"""
+        runs, start = [], 0
+        for j in range(1, len(indices) + 1):
+            if j == len(indices) or indices[j] != indices[j - 1] + 1:
+                runs.append((start, j))
+                start = j
+        if self._bases_before is None:
+            # global base index of an interval = bases of all intervals before it in the full list,
+            # so the null draws do not depend on how the list is batched or sharded
+            all_len = np.array([iv.end - iv.start for iv in self.intervals], dtype=np.int64)
+            self._bases_before = np.concatenate([[0], np.cumsum(all_len)])
+        return runs
+
+    def _compute_on_device(self, indices, ivs, lens, off):
+        """The batch without leaving the GPU between the steps: cut counts from the alignments on
+        the device, one upload of the sequence bytes, scan, FDR, one download of the tracks."""
+        from .scan import DeviceArray
+        sc = self._scanner()
+        ctx = sc.ctx
+        if getattr(self.read_func, "_ctx", None) is None:
+            self.read_func._ctx = ctx
+        total, n_iv = int(off[-1]), len(ivs)
+        S = len(sc.scales)
+        n_tracks = 3 + S + (1 if self.dm else 0)
+        d_cp, d_cm = self.read_func.cut_counts_dev(ivs, self.padding)
+        bufs = [d_cp, d_cm]
+        try:
+            sq = self.fasta_func.fetch_batch(ivs, self.padding)
+            if sq.size != total + n_iv * (2 * self.padding + 7):
+                raise ValueError("fasta_func returned sequence of the wrong length")
+            d_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq); bufs.append(d_sq)
+            d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
+            d_out = DeviceArray(ctx, max(n_tracks * total * 8, 16)); bufs.append(d_out)
+            d_st = DeviceArray(ctx, max(n_iv * 4, 16)).upload(np.zeros(max(n_iv, 1), np.int32)); bufs.append(d_st)
+            t8 = total * 8
+            sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, exp_out=d_out.ptr, obs_out=d_out.ptr + t8,
+                        pval_out=d_out.ptr + 2 * t8, winp_out=(d_out.ptr + 3 * t8) if S else None,
+                        interval_off_dev=d_off.ptr, interval_off_host=off, status_out=d_st.ptr)
+            if self.dm:
+                for a, b in self._runs(indices):
+                    roff = np.ascontiguousarray(off[a:b + 1] - off[a])
+                    d_roff = DeviceArray(ctx, roff.nbytes).upload(roff); bufs.append(d_roff)
+                    sc.fdr_dev(b - a, d_out.ptr + int(off[a]) * 8, d_out.ptr + 3 * t8 + int(off[a]) * 8,
+                               d_out.ptr + (3 + S) * t8 + int(off[a]) * 8, times=self.fdr_shuffle_n, seed=self.seed,
+                               half_win_width=3, interval_off_dev=d_roff.ptr,
+                               base_index0=int(self._bases_before[indices[a]]))
+            ctx.synchronize()
+            flat = d_out.download(np.float64, n_tracks * total).reshape(n_tracks, total)
+            status = d_st.download(np.int32, n_iv)
+        finally:
+            for x in bufs:
+                x.free()
+        res = dict(exp=flat[0], obs=flat[1], pval=flat[2], winp=flat[3:3 + S], status=status)
+        return res, (flat[3 + S] if self.dm else None)
+
     def compute(self, indices):
         """statistics of intervals `indices` (one GPU batch); list of {"interval", "stats"}"""
         indices = list(indices)
@@ -81,44 +144,33 @@ class deviation_stats(object):
             return []
         lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
-        for L, cp, sq in zip(lens, cps, sqs):
-            if cp.size != L + 2 * self.padding + 1 or sq.size != cp.size + 6:
-                raise ValueError("read_func / fasta_func returned arrays of the wrong length")
         sc = self._scanner()
-        res = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
+        if self._device_inputs() and not any(getattr(iv, "strand", None) == "-" for iv in ivs):
+            res, efdr = self._compute_on_device(indices, ivs, lens, off)
+        else:
+            cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
+            for L, cp, sq in zip(lens, cps, sqs):
+                if cp.size != L + 2 * self.padding + 1 or sq.size != cp.size + 6:
+                    raise ValueError("read_func / fasta_func returned arrays of the wrong length")
+            res = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
+            efdr = None
         if not self.dm:
             return [{"interval": iv, "stats": np.column_stack((res["exp"][a:b], res["obs"][a:b]))}
                     for iv, a, b in zip(ivs, off[:-1], off[1:])]
-        # global base index of each interval = bases of all intervals before it in the full list,
-        # so the null draws do not depend on how the list is batched or sharded
-        if self._bases_before is None:
-            all_len = np.array([iv.end - iv.start for iv in self.intervals], dtype=np.int64)
-            self._bases_before = np.concatenate([[0], np.cumsum(all_len)])
-        efdr = np.empty(off[-1])
-        # one FDR call per run of consecutive indices keeps the RNG counters global
-        runs, start = [], 0
-        for j in range(1, len(indices) + 1):
-            if j == len(indices) or indices[j] != indices[j - 1] + 1:
-                runs.append((start, j))
-                start = j
-        for a, b in runs:
-            sl = slice(off[a], off[b])
-            efdr[sl] = sc.fdr(res["exp"][sl], res["winp"][0][sl], times=self.fdr_shuffle_n, seed=self.seed,
-                              half_win_width=3, interval_off=off[a:b + 1] - off[a],
-                              base_index0=int(self._bases_before[indices[a]]))
-        out = []
+        if efdr is None:
+            efdr = np.empty(off[-1])
+            for a, b in self._runs(indices):
+                sl = slice(off[a], off[b])
+                efdr[sl] = sc.fdr(res["exp"][sl], res["winp"][0][sl], times=self.fdr_shuffle_n, seed=self.seed,
+                                  half_win_width=3, interval_off=off[a:b + 1] - off[a],
+                                  base_index0=int(self._bases_before[indices[a]]))
+        # the five columns for the whole batch at once; a record's `stats` is its block of rows
+        pv, wp, ef = np.array(res["pval"], copy=True), np.array(res["winp"][0], copy=True), np.array(efdr, copy=True)
+        for j in np.nonzero(res["status"])[0]:  # the reference's `except Exception` branch (detect.py:136-140)
+            pv[off[j]:off[j + 1]] = wp[off[j]:off[j + 1]] = ef[off[j]:off[j + 1]] = 1.0
         with np.errstate(all="ignore"):  # detect.py:41 np.seterr(all="ignore")
-            for j, iv in enumerate(ivs):
-                sl = slice(off[j], off[j + 1])
-                exp, obs = res["exp"][sl], res["obs"][sl]
-                if res["status"][j]:  # the reference's `except Exception` branch
-                    pv = wp = ef = np.ones(lens[j])
-                else:
-                    pv, wp, ef = res["pval"][sl], res["winp"][0][sl], efdr[sl]
-                out.append({"interval": iv,
-                            "stats": np.column_stack((exp, obs, -np.log(pv), -np.log(wp), ef))})
-        return out
+            table = np.column_stack((res["exp"], res["obs"], -np.log(pv), -np.log(wp), ef))
+        return [{"interval": iv, "stats": table[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])]
 
     def __getitem__(self, index):
         return self.compute([index])[0]

@@ -77,6 +77,26 @@ class FastaFile(object):
 
     def fetch_batch(self, intervals, pad, context=3):
         """ASCII bytes of every interval's [start - pad - 1 - context, end + pad + context), back to
-        back: the `seq` array of FootprintScanner.scan / scan_dev."""
-        return np.concatenate([self._bytes(iv.chrom, iv.start - pad - 1 - context, iv.end + pad + context)
-                               for iv in intervals]) if len(intervals) else np.zeros(0, np.uint8)
+        back: the `seq` array of FootprintScanner.scan / scan_dev.  One vectorised gather from the
+        mapped file for the whole list (no work per interval in Python)."""
+        ivs = list(intervals)
+        if not ivs:
+            return np.zeros(0, np.uint8)
+        starts = np.array([iv.start for iv in ivs], dtype=np.int64) - (pad + 1 + context)
+        ends = np.array([iv.end for iv in ivs], dtype=np.int64) + (pad + context)
+        par = np.array([self.index.get(iv.chrom, (0, 0, 0, 1)) for iv in ivs], dtype=np.int64)  # length, offset, lb, lw
+        n = np.maximum(ends - starts, 0)
+        off = np.concatenate([[0], np.cumsum(n)])
+        total = int(off[-1])
+        which = np.repeat(np.arange(len(ivs)), n)
+        g = np.arange(total, dtype=np.int64) - off[:-1][which] + starts[which]  # genomic position of every byte
+        length, offset, lb, lw = (par[which, k] for k in range(4))
+        inside = (g >= 0) & (g < length) & (lb > 0)
+        gi = np.where(inside, g, 0)
+        lbs = np.where(lb > 0, lb, 1)
+        pos = offset + (gi // lbs) * lw + gi % lbs
+        out = np.full(total, ord("N"), dtype=np.uint8)
+        if inside.any():
+            data = np.frombuffer(self._mm, dtype=np.uint8)
+            out[inside] = data[pos[inside]]
+        return out

@@ -45,14 +45,26 @@ class expected_counts(object):
         ivs = [self.intervals[i] for i in indices]
         lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
-        for L, cp, sq in zip(lens, cps, sqs):
-            if cp.size != L + 2 * self.padding + 1 or sq.size != cp.size + 6:
-                raise ValueError("read_func / fasta_func returned arrays of the wrong length")
         ctx = self._sc.ctx
-        cp, cm, sq = np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs)
-        bufs = [DeviceArray(ctx, max(cp.nbytes, 16)).upload(cp), DeviceArray(ctx, max(cm.nbytes, 16)).upload(cm),
-                DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq), DeviceArray(ctx, off.nbytes).upload(off),
+        if (hasattr(self.read_func, "cut_counts_dev") and hasattr(self.fasta_func, "fetch_batch")
+                and self.bm.offset() == 3 and getattr(self.read_func, "_ctx", None) in (None, ctx)
+                and not any(getattr(iv, "strand", None) == "-" for iv in ivs)):
+            # a cutcounts.bamfile and a fasta.FastaFile: the count arrays are filled on the device
+            # from the alignments held there, no round trip per interval (see detect.deviation_stats)
+            if getattr(self.read_func, "_ctx", None) is None:
+                self.read_func._ctx = ctx
+            d_cp, d_cm = self.read_func.cut_counts_dev(ivs, self.padding)
+            sq = self.fasta_func.fetch_batch(ivs, self.padding)
+            if sq.size != int(off[-1]) + len(ivs) * (2 * self.padding + 7):
+                raise ValueError("fasta_func returned sequence of the wrong length")
+        else:
+            cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
+            for L, cp, sq in zip(lens, cps, sqs):
+                if cp.size != L + 2 * self.padding + 1 or sq.size != cp.size + 6:
+                    raise ValueError("read_func / fasta_func returned arrays of the wrong length")
+            cp, cm, sq = np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs)
+            d_cp, d_cm = DeviceArray(ctx, max(cp.nbytes, 16)).upload(cp), DeviceArray(ctx, max(cm.nbytes, 16)).upload(cm)
+        bufs = [d_cp, d_cm, DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq), DeviceArray(ctx, off.nbytes).upload(off),
                 DeviceArray(ctx, max(2 * int(off[-1]) * 8, 16))]
         return off, bufs
 

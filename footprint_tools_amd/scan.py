@@ -35,6 +35,11 @@ class DeviceArray(object):
         _lib.check(self.ctx.L.fpt_memcpy_h2d(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
         return self
 
+    def zero(self):
+        """all bytes 0, on the context's stream"""
+        _lib.check(self.ctx.L.fpt_dev_zero(self.ctx.h, self.ptr, self.nbytes))
+        return self
+
     def download(self, dtype, count, offset_bytes=0):
         out = np.empty(int(count), dtype=dtype)
         if int(offset_bytes) < 0 or int(offset_bytes) + out.nbytes > self.nbytes:

@@ -355,6 +355,8 @@ int fpt_checksum_dev(fpt_ctx *ctx, const double *dev, int64_t n, uint64_t *host_
 /* device memory helpers for hosts that have no allocator of their own (ctypes callers) */
 int fpt_dev_alloc(fpt_ctx *ctx, int64_t bytes, void **dev_out);
 int fpt_dev_free(fpt_ctx *ctx, void *dev);
+/* bytes of device memory set to zero on the context's stream (not synchronised) */
+int fpt_dev_zero(fpt_ctx *ctx, void *dev, int64_t bytes);
 int fpt_memcpy_h2d(fpt_ctx *ctx, void *dev, const void *host, int64_t bytes);
 int fpt_memcpy_d2h(fpt_ctx *ctx, void *host, const void *dev, int64_t bytes);
 

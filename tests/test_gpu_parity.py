@@ -962,7 +962,24 @@ def test_detect_driver_against_the_reference_driver(fpt, tmp_path):
     ivs = [Interval(str(c), int(a), int(b)) for c, a, b in zip(g["iv_chrom"], g["iv_start"], g["iv_end"])]
     bf, fa = cutcounts.bamfile(bam, min_qual=1, remove_dups=True, remove_qcfail=True, offset=(0, -1)), FastaFile(fa_path)
     kw = dict(half_win_width=5, smoothing_half_win_width=50, smoothing_clip=0.01)
-    recs = detect.deviation_stats(ivs, bf, fa, bm, dm, fdr_shuffle_n=50, seed=7, **kw).compute(range(len(ivs)))
+    ds = detect.deviation_stats(ivs, bf, fa, bm, dm, fdr_shuffle_n=50, seed=7, **kw)
+    assert ds._device_inputs()  # these two readers hand the batch over on the device
+    recs = ds.compute(range(len(ivs)))
+
+    class OnlyLookup(object):   # the same readers behind the reference's per-interval interface only
+        def __getitem__(self, iv):
+            return bf[iv]
+
+    class OnlyFetch(object):
+        def fetch(self, chrom, s_, e_):
+            return fa.fetch(chrom, s_, e_)
+
+    ds_host = detect.deviation_stats(ivs, OnlyLookup(), OnlyFetch(), bm, dm, fdr_shuffle_n=50, seed=7, **kw)
+    assert not ds_host._device_inputs()
+    for r1, r2 in zip(recs, ds_host.compute([0, 1]) + ds_host.compute([2, 3, 4])):
+        assert np.array_equal(r1["stats"], r2["stats"], equal_nan=True)
+    for r1, r2 in zip(recs[1:4], ds.compute([1, 2, 3])):  # a sub-batch on the device: same records
+        assert np.array_equal(r1["stats"], r2["stats"], equal_nan=True)
     n_called = 0
     for i, rec in enumerate(recs):
         want, got = g["stats_%d" % i], rec["stats"]
