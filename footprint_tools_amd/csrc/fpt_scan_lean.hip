@@ -25,7 +25,7 @@
 //     33 equal values, hence 16 equal non-zero values in an aligned row of 16 lanes -- two ballots
 //     and a few scalar instructions per tile, and such a tile goes to the general kernel;
 //   * expected = round(P/Q * t/99): Q is summed in the reference's order, the two divisions are
-//     replaced by one reciprocal with two Newton steps, and a base whose product lies within
+//     replaced by one reciprocal with one Newton step, and a base whose product lies within
 //     1e-13 (relative) of a half-integer -- where the rounding of the exact operations could
 //     decide -- sends its tile to the general kernel;
 //   * Stouffer windows from one workgroup-wide prefix sum of z; the normal cdf by the one-formula
