@@ -21,7 +21,7 @@ EXPORTS = [
     "fpt_ctx_set_stream", "fpt_ctx_use_own_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
-    "fpt_dev_zero", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
+    "fpt_dev_zero", "fpt_format_stats", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_cut_counts_dev",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
     "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
@@ -140,6 +140,7 @@ def load():
         L.fpt_dev_alloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.fpt_dev_free.argtypes = [vp, vp]
         L.fpt_dev_zero.argtypes = [vp, vp, i64]
+        L.fpt_format_stats.argtypes = [C.c_char_p, i64, vp, i64, i32, vp, i64, C.c_char, i32, vp, i64, C.POINTER(i64)]
         L.fpt_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.fpt_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.fpt_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]

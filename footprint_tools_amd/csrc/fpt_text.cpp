@@ -1,0 +1,125 @@
+// fpt_text.cpp -- host-side text of the per-nucleotide output (cli/utils.py:119-163,
+// write_stats_to_output): once the statistics take milliseconds, formatting "{:0.4f}" of five
+// columns per base in Python is what a `detect` run waits for.
+//
+// "{:0.Nf}".format(v) is the correctly rounded decimal expansion of the double's exact value
+// (round-half-even on exact ties), sign kept for negative zero and for negatives that round to
+// zero, "nan" / "inf" / "-inf" otherwise.  For N <= 9 and |v| * 10^N < 9e18 that is integer arithmetic:
+// v = m * 2^e exactly, so v * 10^N = (m * 10^N) >> -e with the remainder deciding the rounding --
+// 128-bit integers hold it.  Everything else goes through snprintf, which glibc also rounds
+// correctly.  Tested against Python's own formatting on random and boundary values.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/fpt.h"
+
+int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
+
+namespace {
+
+const uint64_t kPow10[10] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull,
+                             100000000ull, 1000000000ull};
+
+inline char *put_uint(char *p, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+inline char *put_int(char *p, int64_t v) {
+    if (v < 0) {
+        *p++ = '-';
+        return put_uint(p, (uint64_t)0 - (uint64_t)v);
+    }
+    return put_uint(p, (uint64_t)v);
+}
+
+// appends "{:0.<prec>f}".format(v); at most 40 bytes on the fast path
+inline char *put_fixed(char *p, char *end, double v, int prec) {
+    if (std::isnan(v)) {
+        memcpy(p, "nan", 3);
+        return p + 3;
+    }
+    if (std::signbit(v)) *p++ = '-';
+    const double a = std::fabs(v);
+    if (std::isinf(a)) {
+        memcpy(p, "inf", 3);
+        return p + 3;
+    }
+    if (prec <= 9 && a < 4503599627370496.0 && a * (double)kPow10[prec] < 9.0e18) {  // < 2^52, and the scaled integer fits 64 bits
+        int e;
+        const double fr = std::frexp(a, &e);             // a = fr * 2^e, fr in [0.5, 1) (or 0)
+        const uint64_t m = (uint64_t)std::ldexp(fr, 53);  // 53-bit integer: a = m * 2^(e - 53)
+        const int sh = 53 - e;                            // >= 1 here: a < 2^52
+        unsigned __int128 x = (unsigned __int128)m * kPow10[prec];
+        uint64_t q;
+        if (sh >= 128) {
+            q = 0;  // m * 10^prec < 2^83: far below half a unit
+        } else {
+            const unsigned __int128 one = (unsigned __int128)1 << sh, rem = x & (one - 1), half = one >> 1;
+            q = (uint64_t)(x >> sh);
+            if (rem > half || (rem == half && (q & 1))) ++q;
+        }
+        p = put_uint(p, q / kPow10[prec]);
+        if (prec > 0) {
+            *p++ = '.';
+            uint64_t f = q % kPow10[prec];
+            for (int i = prec - 1; i >= 0; --i) {
+                p[i] = (char)('0' + f % 10);
+                f /= 10;
+            }
+            p += prec;
+        }
+        return p;
+    }
+    const int n = snprintf(p, (size_t)(end - p), "%.*f", prec, a);
+    return (n < 0 || n >= end - p) ? nullptr : p + n;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int64_t n_rows, int32_t n_cols,
+                     const int64_t *rows, int64_t n_sel, char delim, int32_t precision, char *buf, int64_t cap,
+                     int64_t *len_out) {
+    if (!chrom || !len_out || n_rows < 0 || n_cols < 0 || precision < 0 || precision > 30 || cap < 0 || (!buf && cap > 0))
+        return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
+    if ((!stats && n_rows > 0 && n_cols > 0) || (rows && n_sel < 0)) return fpt_internal_fail(FPT_ERR_INVALID, "null matrix");
+    const size_t lc = strlen(chrom);
+    const int64_t count = rows ? n_sel : n_rows;
+    char *p = buf, *end = buf + cap;
+    for (int64_t r = 0; r < count; ++r) {
+        const int64_t i = rows ? rows[r] : r;
+        if (i < 0 || i >= n_rows) return fpt_internal_fail(FPT_ERR_INVALID, "row %lld outside the matrix", (long long)i);
+        if ((size_t)(end - p) < lc + 48) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+        memcpy(p, chrom, lc);
+        p += lc;
+        *p++ = delim;
+        p = put_int(p, start + i);
+        *p++ = delim;
+        p = put_int(p, start + i + 1);
+        *p++ = delim;
+        const double *row = stats + i * (int64_t)n_cols;
+        for (int32_t c = 0; c < n_cols; ++c) {
+            if (end - p < 48) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+            if (c) *p++ = delim;
+            p = put_fixed(p, end - 2, row[c], precision);
+            if (!p) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+        }
+        *p++ = '\n';
+    }
+    *len_out = p - buf;
+    return FPT_OK;
+}
+
+#pragma GCC visibility pop
+}

@@ -16,11 +16,13 @@ the reference's fallback row pvals = win_pvals = efdr = 1 (detect.py:136-140).
 genome_tools.genomic_interval has.  The output writers produce the reference's bedGraph / BED
 text (cli/utils.py:86-210).
 """
+import ctypes as C
+import re
 import sys
 
 import numpy as np
 
-from . import __version__
+from . import __version__, _lib
 from .scan import FootprintScanner
 from .stats import utils
 
@@ -194,13 +196,47 @@ def write_output_header(columns, file=sys.stdout, delim="\t", include_name=True,
     file.flush()
 
 
+_FIXED = re.compile(r"^0?\.(\d{1,2})f$")
+
+
+def _native_stats_text(chrom, start, stats, rows, delim, precision):
+    """the lines through the library's formatter (fpt_format_stats: the same correctly rounded
+    decimals, ~50x the speed of formatting value by value in Python); None if it does not apply"""
+    if len(delim) != 1 or not delim.isascii() or not str(chrom).isascii() or stats.ndim != 2:
+        return None
+    m = np.ascontiguousarray(stats, dtype=np.float64)
+    n, k = m.shape
+    sel = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+    count = n if sel is None else sel.size
+    if count == 0:
+        return ""
+    with np.errstate(all="ignore"):
+        largest = float(np.abs(m).max()) if m.size else 0.0
+        if not np.isfinite(largest):  # nan / inf somewhere: the largest finite magnitude
+            finite = np.abs(m[np.isfinite(m)])
+            largest = float(finite.max()) if finite.size else 0.0
+    digits = int(np.floor(np.log10(max(largest, 1.0)))) + 1
+    cap = count * (len(str(chrom)) + 1 + 2 * (len(str(int(start) + n)) + 1) + k * (digits + precision + 4) + 1) + 64
+    buf = np.empty(cap, dtype=np.uint8)
+    used = C.c_int64()
+    L = _lib.load()
+    _lib.check(L.fpt_format_stats(str(chrom).encode(), int(start), m.ctypes.data, n, k,
+                                  sel.ctypes.data if sel is not None else None, count, delim.encode(), precision,
+                                  buf.ctypes.data, cap, C.byref(used)))
+    return buf[:used.value].tobytes().decode("ascii")
+
+
 def write_stats_to_output(interval, stats, file=sys.stdout, delim="\t", filter_fn=None, fmt_string="0.4f"):
-    rows = np.nonzero(filter_fn(stats))[0] if filter_fn else range(stats.shape[0])
-    fmt = "{0:" + fmt_string + "}"
+    rows = np.nonzero(filter_fn(stats))[0] if filter_fn else None
     chrom, start = interval.chrom, interval.start
-    file.write("".join(
-        delim.join([str(chrom), str(start + i), str(start + i + 1)] + [fmt.format(v) for v in stats[i, :]])
-        + "\n" for i in rows))
+    fixed = _FIXED.match(fmt_string)
+    text = _native_stats_text(chrom, start, stats, rows, delim, int(fixed.group(1))) if fixed else None
+    if text is None:  # any other format string: value by value, as the reference does
+        fmt = "{0:" + fmt_string + "}"
+        text = "".join(
+            delim.join([str(chrom), str(start + i), str(start + i + 1)] + [fmt.format(v) for v in stats[i, :]])
+            + "\n" for i in (range(stats.shape[0]) if rows is None else rows))
+    file.write(text)
 
 
 def write_segment_batch_to_output(intervals, segments, name=".", file=sys.stdout, delim="\t", fmt_string="0.4f"):

@@ -355,6 +355,18 @@ int fpt_checksum_dev(fpt_ctx *ctx, const double *dev, int64_t n, uint64_t *host_
 /* device memory helpers for hosts that have no allocator of their own (ctypes callers) */
 int fpt_dev_alloc(fpt_ctx *ctx, int64_t bytes, void **dev_out);
 int fpt_dev_free(fpt_ctx *ctx, void *dev);
+/* ---- output text (host only) -------------------------------------------------
+ * The bedGraph lines of `write_stats_to_output` (cli/utils.py:119-163): for every selected row i of
+ * the n_rows x n_cols matrix `stats` (row-major),
+ *     chrom <d> start+i <d> start+i+1 <d> "{:0.<precision>f}".format(v) of each column joined by <d> "\n"
+ * into `buf` (cap bytes; *len_out = bytes written; FPT_ERR_INVALID when it does not fit -- a value
+ * needs at most 1 + 17 + 1 + precision bytes while |v| < 1e17, up to 311 + precision beyond).
+ * rows = NULL selects every row (the reference's filter_fn is applied by the caller).  The decimal
+ * expansion is the correctly rounded one Python prints; nan / inf / -inf as Python spells them. */
+int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int64_t n_rows, int32_t n_cols,
+                     const int64_t *rows, int64_t n_sel, char delim, int32_t precision, char *buf, int64_t cap,
+                     int64_t *len_out);
+
 /* bytes of device memory set to zero on the context's stream (not synchronised) */
 int fpt_dev_zero(fpt_ctx *ctx, void *dev, int64_t bytes);
 int fpt_memcpy_h2d(fpt_ctx *ctx, void *dev, const void *host, int64_t bytes);

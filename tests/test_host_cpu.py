@@ -184,6 +184,48 @@ def test_output_writers_text_format():
     assert hdr.splitlines()[1:] == str(g["header_plain"]).splitlines()[1:]
 
 
+def test_native_stats_formatter_equals_python():
+    """fpt_format_stats against Python's own "{:0.Nf}" (what cli/utils.py:155-161 prints) on random
+    values over 40 decades and on the cases where the rounding could go either way."""
+    import io
+    from footprint_tools_amd import detect
+    rs = np.random.RandomState(12)
+    vals = [0.0, -0.0, 0.5, 1.5, 2.5, 0.125, 0.375, 0.00005, 0.00015, 0.99995, 0.999949999, -1e-9, 1e-320, 5e-324,
+            4503599627370495.5, 4503599627370496.0, 9007199254740993.0, 1e17, 1e22, 1.7976931348623157e308,
+            np.nan, -np.nan, np.inf, -np.inf, 12345.678951, 1e-5, 0.30000000000000004, 2.675, 1.005, 8.5e-5]
+    vals += list(rs.randn(3000) * 10.0 ** rs.randint(-12, 21, 3000))
+    vals += list(np.round(rs.rand(2000) * 100, 4) + rs.choice([0.0, 5e-5, -5e-5], 2000))  # near the 4-decimal ties
+    vals += list((rs.randint(0, 2 ** 20, 1000) + 0.5) / 2.0 ** rs.randint(0, 12, 1000))   # exact binary ties
+    vals = np.array(vals, dtype=np.float64)
+    vals = np.concatenate([vals, -vals])
+    k = 5
+    m = np.resize(vals, (vals.size // k + 1, k))
+
+    class IV(object):
+        chrom, start = "chrUn_gl000220", 16000000
+
+    for prec in (0, 1, 2, 4, 6, 9):
+        fmt = "0.%df" % prec
+        buf = io.StringIO()
+        detect.write_stats_to_output(IV, m, file=buf, fmt_string=fmt)
+        want = "".join("\t".join([IV.chrom, str(IV.start + i), str(IV.start + i + 1)]
+                                 + [("{0:" + fmt + "}").format(v) for v in m[i]]) + "\n" for i in range(m.shape[0]))
+        got = buf.getvalue()
+        if got != want:
+            for a, b in zip(got.splitlines(), want.splitlines()):
+                assert a == b, (prec, a, b)
+        assert got == want
+    # row selection, another delimiter, an empty selection
+    buf = io.StringIO()
+    detect.write_stats_to_output(IV, m, file=buf, delim=",", filter_fn=lambda x: x[:, 0] > 1.0)
+    rows = np.nonzero(m[:, 0] > 1.0)[0]
+    assert buf.getvalue() == "".join(",".join([IV.chrom, str(IV.start + i), str(IV.start + i + 1)]
+                                              + ["{0:0.4f}".format(v) for v in m[i]]) + "\n" for i in rows)
+    buf = io.StringIO()
+    detect.write_stats_to_output(IV, m, file=buf, filter_fn=lambda x: x[:, 0] > np.inf)
+    assert buf.getvalue() == ""
+
+
 # ---------------------------------------------------------------- learn_dm: NB fit, piecewise fit, model
 def test_nbinom_fit_golden():
     """nbinom.mle / nbinom.fit against the reference's (stats/distributions/nbinom.pyx:25-80)."""
