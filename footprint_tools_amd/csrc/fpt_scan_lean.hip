@@ -322,82 +322,49 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
     return bad;
 }
 
-// One tile per workgroup.  Per-workgroup timelines (tools/lean_trace.py, config 3): 12.1 us of life,
-// of which 2.6 us from the first instruction to the inputs being staged, and 2.8 us between the
-// last store being issued and the successor's first instruction -- the slot (half of the compute
-// unit's wavefronts) is not released until every store is acknowledged.  Workgroups that stay and
-// walk the tiles were built four ways to hide both; the last one ordered an iteration so that no
-// wait on the vector-memory counter (in order across loads AND stores on gfx9) meets a young
-// operation: stage(k) | issue loads(k+1) | issue table gather(k) | stores + windows of tile k-1 |
-// scans(k) | smoothing, memo gather(k), z(k) -> LDS.  It is correct (whole GPU suite) and hides
-// more of the memory time (4.6 ms exposed instead of 6.3), but its arithmetic alone is slower the
-// longer a workgroup lives -- 21.1 ms with the loads and stores ablated at 4 or 244 tiles per
-// workgroup, 23.2 ms at 1,953 (one-shot: 19.3) -- and the whole kernel never beat this form:
-// 26.0 / 25.2 / 25.5 / 25.8 / 27.0 / 27.8 ms at 1 / 4 / 30 / 244 / 977 / 1,953 tiles per workgroup
-// against 25.0.  Start offsets between the workgroups of a CU (by hardware slot) changed nothing.
+// LDS arrays of one workgroup (see lean_lds)
 template <int NT>
-__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
-    typedef lean_lds<NT> LY;
-    extern __shared__ double smem[];
-    double *PP = smem + LY::oPP, *PM = smem + LY::oPM, *Z = smem + LY::oZB, *rowtot = smem + LY::oRT;
-    double *C = rowtot + 64;
-    u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
-    u32 *bits0 = words + LY::oB0, *bits1 = words + LY::oB1, *pk = words + LY::oPK, *Wp = words + LY::oWP;
-    u32 *psP = words + LY::oSP, *psM = words + LY::oSM;
-    u32 *xP = words + LY::oXP, *xPs = words + LY::oXPs, *xM = words + LY::oXM, *xMs = words + LY::oXMs;
-    constexpr int NROW = NT / 16;
-    // Z[16 + i] = prefix sum of z up to base i (row-of-16 prefix + C[1 + row], the sum of the rows
-    // before); Z[15] = 0 stands for "before the first base", and the slot kEdge holds a
-    // prefix of -1e4, which makes the window p-value of a base near the interval's edge come out
-    // as exactly 1.0 (windowing.pyx:51) without a select: ndtr(+1e4 / sqrt(K)) = 1.
-    constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
-
-    typedef const __attribute__((address_space(4))) lean_args kargs;
-    kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const int64_t tile = a.tile_first + blockIdx.x;
-    LEAN_TRACE(1);
-    const lean_tile g = lean_geometry(a, tile);
-    const int t0 = g.t0, tl = g.tl, L = g.L, ta = g.ta, nt = g.nt, ncs = g.ncs;
-    const int64_t out_off = g.out_off;
-    const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
-
-    // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
-    lean_inputs in;
-    lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
-    bool bad = lean_stage<NT>(in, ncs, tid, pk, bits0, bits1);  // outside the case this kernel handles?
-    LEAN_TRACE(2);
-    if (tid == 0) {
-        Z[15] = 0.0;
-        Z[kEdge] = -1e4;
+struct lean_mem {
+    double *PP, *PM, *Z, *rowtot, *C;
+    u32 *bits0, *bits1, *pk, *Wp, *psP, *psM, *xP, *xPs, *xM, *xMs;
+    __device__ __forceinline__ explicit lean_mem(double *smem) {
+        typedef lean_lds<NT> LY;
+        PP = smem + LY::oPP, PM = smem + LY::oPM, Z = smem + LY::oZB, rowtot = smem + LY::oRT, C = rowtot + 64;
+        u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
+        bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK, Wp = words + LY::oWP;
+        psP = words + LY::oSP, psM = words + LY::oSM;
+        xP = words + LY::oXP, xPs = words + LY::oXPs, xM = words + LY::oXM, xMs = words + LY::oXMs;
     }
-    __syncthreads();
-    LEAN_TRACE(3);
-    if (LEAN_STOP(1)) return;
+};
 
-    // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums
+// ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums.
+// Returns true where an aligned row of 16 equal non-zero window sums shows up (see the header).
+template <int NT>
+__device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double2 *table2, int ncs, int tid) {
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i * NT + wave * kWave >= ncs) break;
         const int v = i * NT + tid;
         const int w32 = v >> 5, sh = v & 31;
-        const u32 f0 = __builtin_amdgcn_alignbit(bits0[w32 + 1], bits0[w32], sh) & 63u;
-        const u32 f1 = __builtin_amdgcn_alignbit(bits1[w32 + 1], bits1[w32], sh) & 63u;
-        const double2 tt = a.table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
-        const u32 *pw = pk + 8 + v - kHW;
+        const u32 f0 = __builtin_amdgcn_alignbit(m.bits0[w32 + 1], m.bits0[w32], sh) & 63u;
+        const u32 f1 = __builtin_amdgcn_alignbit(m.bits1[w32 + 1], m.bits1[w32], sh) & 63u;
+        const double2 tt = table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+        const u32 *pw = m.pk + 8 + v - kHW;
         u32 W = pw[0];
 #pragma unroll
         for (int j = 1; j < 2 * kHW; ++j) W += pw[j];
-        Wp[v] = W;
+        m.Wp[v] = W;
         const int vr = v + (kWave - 1) - 2 * lane;  // the tile mirrored: suffix scans are prefix scans of it
-        const u32 Wr = Wp[vr];
+        const u32 Wr = m.Wp[vr];
         const u32 wp = W & 0xffffu, wm = W >> 16, rp = Wr & 0xffffu, rm = Wr >> 16;
-        psP[v] = (u32)wave_scan_i32((int)wp);
-        psM[v] = (u32)wave_scan_i32((int)wm);
-        xP[v] = wave_scan_umax(0xffffu - wp) | (wave_scan_umax(wp) << 16);
-        xM[v] = wave_scan_umax(0xffffu - wm) | (wave_scan_umax(wm) << 16);
-        xPs[vr] = wave_scan_umax(0xffffu - rp) | (wave_scan_umax(rp) << 16);
-        xMs[vr] = wave_scan_umax(0xffffu - rm) | (wave_scan_umax(rm) << 16);
+        m.psP[v] = (u32)wave_scan_i32((int)wp);
+        m.psM[v] = (u32)wave_scan_i32((int)wm);
+        m.xP[v] = wave_scan_umax(0xffffu - wp) | (wave_scan_umax(wp) << 16);
+        m.xM[v] = wave_scan_umax(0xffffu - wm) | (wave_scan_umax(wm) << 16);
+        m.xPs[vr] = wave_scan_umax(0xffffu - rp) | (wave_scan_umax(rp) << 16);
+        m.xMs[vr] = wave_scan_umax(0xffffu - rm) | (wave_scan_umax(rm) << 16);
         // a row of 16 equal non-zero window sums (lanes 0..14 equal their right neighbour)?
         const u32 d = W ^ (u32)__builtin_amdgcn_update_dpp(0, (int)W, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
         constexpr unsigned long long kLast = 0x8000800080008000ull, kFirst = 0x0001000100010001ull;
@@ -406,32 +373,42 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8;
         rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8;
         bad |= ((rP | rM) & kFirst) != 0;
-        PP[v] = tt.x;
-        PM[v] = tt.y;
+        m.PP[v] = tt.x;
+        m.PM[v] = tt.y;
     }
-    __syncthreads();
-    LEAN_TRACE(4);
-    if (LEAN_STOP(2)) return;
+    return bad;
+}
 
-    // ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands
-    //         ('+' at padded position pad+1+t, '-' at pad+t; detect.py:121-122)
-    double z = 0.0;
-    const int t = ta + tid;
-    const bool mine = tid < nt && t >= t0 && t < t0 + tl && !LEAN_STOP(6);
+// the three per-base tracks of a lane between phase D and their stores
+struct lean_tracks {
+    double ex, pv;
+    u32 k;
+};
+
+// ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands ('+' at padded
+// position pad+1+t, '-' at pad+t; detect.py:121-122); D: observed count, p-value and z from the
+// (exp, obs) table.  Lanes beyond nt return z = 0.
+template <int NT>
+__device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_args &a, kcoef *kc, const double2 *memo,
+                                              int nt, int tid, lean_tracks &tr, double &z) {
+    bool bad = false;
+    z = 0.0;
+    tr.ex = tr.pv = 0.0;
+    tr.k = 0;
     if (tid < nt) {
         double e2[2];
 #pragma unroll
         for (int strand = 0; strand < 2; ++strand) {
             const int v = kPad + tid + (strand ? 0 : 1);
             const int lo = v - kSHW, hi = v + kSHW;
-            const u32 S = window_sum(strand ? psM : psP, lo, hi);
-            const u32 *xp = strand ? xM : xP, *xs = strand ? xMs : xPs;
+            const u32 S = window_sum(strand ? m.psM : m.psP, lo, hi);
+            const u32 *xp = strand ? m.xM : m.xP, *xs = strand ? m.xMs : m.xPs;
             const int mid = (lo | 63) + 64;  // last position of the tile after lo's
             const u32 x1 = xs[lo], x2 = xp[hi], x3 = xp[(hi >> 6) == (lo >> 6) + 2 ? mid : hi];
             const u32 cmin = max(max(x1 & 0xffffu, x2 & 0xffffu), x3 & 0xffffu);  // 0xffff - min
             const u32 mx = max(max(x1 >> 16, x2 >> 16), x3 >> 16);
             const double tsum = (double)((S + cmin) - mx - 0xffffu);  // S - min - max
-            const double *P = (strand ? PM : PP) + (kPad + tid + 1 - kHW);  // P[v-hw .. v+hw-1]
+            const double *P = (strand ? m.PM : m.PP) + (kPad + tid + 1 - kHW);  // P[v-hw .. v+hw-1]
             double q = P[0];
 #pragma unroll
             for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
@@ -443,69 +420,173 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
             bad |= !(fabs(fr - 0.5) > mul_vs(x, kc->band));  // too close to a tie (or not a number)
             e2[strand] = floor(x + 0.5);
         }
-        const double ex = e2[0] + e2[1];
-        // ---- D: observed count, p-value and z from the (exp, obs) table
-        const u32 k = (pk[8 + kPad + 1 + tid] & 0xffffu) + (pk[8 + kPad + tid] >> 16);
-        const u32 ei = (u32)(int)ex;
-        const bool hit = ei < (u32)a.memo_exp && k < (u32)a.memo_obs;
-        const double2 pz = memo[hit ? ei * (u32)a.memo_obs + k : 0u];
+        tr.ex = e2[0] + e2[1];
+        tr.k = (m.pk[8 + kPad + 1 + tid] & 0xffffu) + (m.pk[8 + kPad + tid] >> 16);
+        const u32 ei = (u32)(int)tr.ex;
+        const bool hit = ei < (u32)a.memo_exp && tr.k < (u32)a.memo_obs;
+        const double2 pz = memo[hit ? ei * (u32)a.memo_obs + tr.k : 0u];
+        tr.pv = pz.x;
         z = pz.y;
         bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
-        if (!hit && a.miss_max && ei < (u32)a.miss_rows && k < (u32)a.miss_stride) {
+        if (!hit && a.miss_max && ei < (u32)a.miss_rows && tr.k < (u32)a.miss_stride) {
             atomicMax(&a.miss_max[0], (int)ei);  // sizes the second-level table of the redo pass
-            atomicMax(&a.miss_max[1], (int)k);
-        }
-        if (mine) {
-            const int64_t gi = out_off + t;
-            if (a.exp_out) a.exp_out[gi] = ex;
-            if (a.obs_out) a.obs_out[gi] = (double)k;
-            if (a.pval_out) a.pval_out[gi] = pz.x;
+            atomicMax(&a.miss_max[1], (int)tr.k);
         }
     }
+    return bad;
+}
+
+// which lanes own an output base of the tile, and which one
+struct lean_owner {
+    int t, L;
+    int64_t out_off;
+    bool mine;
+};
+__device__ __forceinline__ lean_owner lean_own(const lean_tile &g, int tid, bool no_stores) {
+    lean_owner o;
+    o.t = g.ta + tid;
+    o.L = g.L;
+    o.out_off = g.out_off;
+    o.mine = tid < g.nt && o.t >= g.t0 && o.t < g.t0 + g.tl && !no_stores;
+    return o;
+}
+
+__device__ __forceinline__ void lean_store_tracks(const lean_args &a, const lean_owner &o, const lean_tracks &tr) {
+    if (o.mine) {
+        const int64_t gi = o.out_off + o.t;
+        if (a.exp_out) a.exp_out[gi] = tr.ex;
+        if (a.obs_out) a.obs_out[gi] = (double)tr.k;
+        if (a.pval_out) a.pval_out[gi] = tr.pv;
+    }
+}
+
+// ---- E with several scales, in pieces so that two tiles can share the barriers:
+// Z[16 + i] = prefix sum of z up to base i (row-of-16 prefix + C[1 + row], the sum of the rows
+// before); Z[15] = 0 stands for "before the first base", and the slot kEdge holds a prefix of -1e4,
+// which makes the window p-value of a base near the interval's edge come out as exactly 1.0
+// (windowing.pyx:51) without a select: ndtr(+1e4 / sqrt(K)) = 1.
+template <int NT>
+__device__ __forceinline__ double lean_z_rows(double z, int tid, double *rowtot) {  // then a barrier
+    const double zr = row_scan_f64(z);  // lanes beyond nt hold 0
+    if ((tid & 15) == 15) rowtot[tid >> 4] = zr;
+    return zr;
+}
+template <int NT>
+__device__ __forceinline__ void lean_z_carries(int tid, const double *rowtot, double *C) {  // first wavefront; then a barrier
+    constexpr int NROW = NT / 16;
+    if (tid < kWave) {
+        const double tv = tid < NROW ? rowtot[tid] : 0.0;
+        const double inc = wave_scan_f64(tv, 0.0, op_add());
+        if (tid < NROW) C[1 + tid] = inc - tv;
+    }
+}
+// the carries applied once: a scale then costs two reads and one subtraction (then a barrier)
+template <int NT>
+__device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *C, double *Z) {
+    Z[16 + tid] = zr + C[1 + (tid >> 4)];
+}
+template <int NT>
+__device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
+    constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
+    bool far = false;
+    double *dst = a.winp_out + o.out_off + o.t;
+    for (int s = 0; s < a.n_scales; ++s) {
+        const int hs = a.scales[s];
+        const bool inside = o.mine && o.t >= hs && o.t < o.L - hs;
+        const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
+        const double sv = Z[hi] - Z[lo];
+        const double arg = -(sv * a.scale_rsqrt[s]);
+        far |= inside && !(fabs(arg) < kc->limit);
+        const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+        if (o.mine) dst[(int64_t)s * a.total_bases] = pw;
+    }
+    return far;
+}
+// one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right
+template <int NT>
+__device__ __forceinline__ bool lean_window_narrow(const lean_args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
+    const int hs = a.scales[0];
+    const bool inside = o.mine && o.t >= hs && o.t < o.L - hs;
+    double sv = 0.0;
+    if (inside)
+        for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
+    const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
+    const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+    if (o.mine) a.winp_out[o.out_off + o.t] = pw;
+    return inside && !(fabs(arg) < kc->limit);
+}
+
+// One tile per workgroup.  With its loads and stores ablated the kernel needs 3.52e8 shader cycles
+// per 10^9 bases (GRBM_GUI_ACTIVE, at 2.38 GHz: the instruction-issue bound); with them 4.63e8 at
+// 2.29 GHz.  Per-workgroup timelines (tools/lean_trace.py, config 3) show 12.1 us of life, 2.6 us
+// of it before the inputs are staged, and 2.8 us between the last store and the successor's first
+// instruction (a slot is not released until every store is acknowledged) -- but that is not where
+// the extra cycles are: six forms that hide those two latencies were built and measured.  Four
+// kinds of workgroups that stay and walk the tiles (the last with every vector-memory wait --
+// the counter is in order across loads AND stores on gfx9 -- at least a phase younger than what
+// it covers: 26.0 / 25.2 / 25.5 / 25.8 / 27.0 / 27.8 ms at 1 / 4 / 30 / 244 / 977 / 1,953 tiles
+// per workgroup against 25.0; start offsets by hardware slot changed nothing), and two tiles per
+// workgroup in straight-line code (both tiles' loads first, every store of both after the last
+// gather, a second z array: 78.5 KB of LDS; 24.5-24.8 against 24.0-24.4 ms, arithmetic alone
+// 18.6 against 18.9): all correct on the whole GPU suite, none faster.  The memory time that is
+// not hidden is spread over the phases -- gathers and store issue take longer while 3.4 TB/s
+// stream through the same L2 -- not concentrated at a workgroup's two ends.
+template <int NT>
+__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
+    extern __shared__ double smem[];
+    const lean_mem<NT> m(smem);
+    constexpr int kEdge = NT + 32 + 15;
+
+    typedef const __attribute__((address_space(4))) lean_args kargs;
+    kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
+    const int tid = threadIdx.x;
+    const int64_t tile = a.tile_first + blockIdx.x;
+    LEAN_TRACE(1);
+    const lean_tile g = lean_geometry(a, tile);
+    const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
+
+    // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
+    lean_inputs in;
+    lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    bool bad = lean_stage<NT>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
+    LEAN_TRACE(2);
+    if (tid == 0) {
+        m.Z[15] = 0.0;
+        m.Z[kEdge] = -1e4;
+    }
+    __syncthreads();
+    LEAN_TRACE(3);
+    if (LEAN_STOP(1)) return;
+
+    bad |= lean_phase_b<NT>(m, a.table2, g.ncs, tid);
+    __syncthreads();
+    LEAN_TRACE(4);
+    if (LEAN_STOP(2)) return;
+
+    lean_tracks tr;
+    double z;
+    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.nt, tid, tr, z);
+    const lean_owner o = lean_own(g, tid, LEAN_STOP(6));
+    lean_store_tracks(a, o, tr);
 
     LEAN_TRACE(5);
     // ---- E: Stouffer windows (windowing.h:53-84)
     if (a.n_scales == 0 || LEAN_STOP(3)) {
     } else if (a.n_scales == 1 && a.max_scale <= 8) {
-        // one narrow scale (the reference's only one is 3): summed directly, left to right
-        Z[16 + tid] = z;
+        m.Z[16 + tid] = z;
         __syncthreads();
-        const int hs = a.scales[0];
-        const bool inside = mine && t >= hs && t < L - hs;
-        double sv = 0.0;
-        if (inside)
-            for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
-        const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
-        bad |= inside && !(fabs(arg) < kc->limit);
-        const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
-        if (mine) a.winp_out[out_off + t] = pw;
+        bad |= lean_window_narrow<NT>(a, kc, o, tid, m.Z);
     } else {
         // one workgroup-wide prefix sum of z in two levels: rows of 16 lanes on the DPP path, the
-        // NT/16 row totals scanned by the first wavefront
-        const double zr = row_scan_f64(z);  // lanes beyond nt hold 0
-        if ((lane & 15) == 15) rowtot[tid >> 4] = zr;
+        // NT/16 row totals scanned by the first wavefront, the carries added once behind a third
+        // barrier (measured 24.7 -> 24.5 ms against adding them in every scale)
+        const double zr = lean_z_rows<NT>(z, tid, m.rowtot);
         __syncthreads();
-        if (tid < kWave) {
-            const double tv = tid < NROW ? rowtot[tid] : 0.0;
-            const double inc = wave_scan_f64(tv, 0.0, op_add());
-            if (tid < NROW) C[1 + tid] = inc - tv;
-        }
+        lean_z_carries<NT>(tid, m.rowtot, m.C);
         __syncthreads();
-        // the carries applied once (a third barrier): a scale then costs two reads and one
-        // subtraction instead of four reads and three additions (measured 24.7 -> 24.5 ms)
-        Z[16 + tid] = zr + C[1 + (tid >> 4)];
+        lean_z_finish<NT>(zr, tid, m.C, m.Z);
         __syncthreads();
-        double *dst = a.winp_out + out_off + t;
-        for (int s = 0; s < a.n_scales; ++s) {
-            const int hs = a.scales[s];
-            const bool inside = mine && t >= hs && t < L - hs;
-            const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
-            const double sv = Z[hi] - Z[lo];
-            const double arg = -(sv * a.scale_rsqrt[s]);
-            bad |= inside && !(fabs(arg) < kc->limit);
-            const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
-            if (mine) dst[(int64_t)s * a.total_bases] = pw;
-        }
+        bad |= lean_windows<NT>(a, kc, o, tid, m.Z);
     }
     if (bad) a.redo[tile] = 1;
     LEAN_TRACE(6);
@@ -523,6 +604,7 @@ lean_kernel_t lean_kernel(int nt) {
         default: return k_scan_lean<1024>;
     }
 }
+
 
 }  // namespace
 
