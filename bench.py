@@ -331,6 +331,12 @@ def main():
             gp = src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
         rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
         parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
+        if S:  # the window p-values of every scale (contract: 1e-6 relative)
+            wrel = 0.0
+            for s_ in range(S):
+                gw = d_out.download(np.float64, Li, ((2 + s_) * total + o0) * 8)
+                wrel = max(wrel, float(np.nanmax(np.abs(gw - wp[s_]) / np.maximum(np.abs(wp[s_]), 1e-300))))
+            parity["winp_max_rel_err"] = wrel
         if fdr_times:  # the empirical FDR of that interval against the oracle's restatement of the sampler
             ef_src = d_gather if do_gather else d_efdr
             ef = ef_src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
