@@ -155,6 +155,10 @@ __device__ __forceinline__ double horner_e_s(double x, kdouble *c) {
 // pointer through an empty asm that depends on the argument keeps the loads (three
 // s_load_dwordx16) inside the evaluation; both sets fit at degrees 14 / 8, so one wait covers them
 // (measured against a second hand-over between the chains: 25.1 vs 25.6 ms on config 3).
+// Valid for a > -limit (26).  Beyond +26 the result is exactly 1.0, as in the reference: y underflows to
+// zero through ldexp whatever the polynomials extrapolate to (they stay bounded: 1/(t+5) only moves
+// from 0.032 to 0 -- which is also how the sentinel edge slot yields 1.0), so only arguments below
+// -26, where the reference's own value runs into the subnormal range, have to leave this kernel.
 __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     asm volatile("" : "+s"(c) : "v"(a));
     const double t = fabs(a);
@@ -496,7 +500,7 @@ __device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, cons
         const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
         const double sv = Z[hi] - Z[lo];
         const double arg = -(sv * a.scale_rsqrt[s]);
-        far |= inside && !(fabs(arg) < kc->limit);
+        far |= inside && !(arg > -kc->limit);  // one-sided: see ndtr_fast_s
         const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
         if (o.mine) dst[(int64_t)s * a.total_bases] = pw;
     }
@@ -513,7 +517,7 @@ __device__ __forceinline__ bool lean_window_narrow(const lean_args &a, kcoef *kc
     const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
     const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
     if (o.mine) a.winp_out[o.out_off + o.t] = pw;
-    return inside && !(fabs(arg) < kc->limit);
+    return inside && !(arg > -kc->limit);
 }
 
 // One tile per workgroup.  With its loads and stores ablated the kernel needs 3.52e8 shader cycles
