@@ -270,7 +270,6 @@ struct scan_args {
     int32_t memo_exp, memo_obs;
     int32_t ablate;              // timing-only diagnostics, honoured only in -DFPT_ABLATE builds
     int32_t counts_only;         // FPT_NB_NONE: stop after the expected counts
-    int64_t tile_end;            // second pass: one past the last tile of the launch
     int32_t fast_trim;           // k_trim == 1 && shw >= 32 && nc_max <= 3*NT: tile-scan smoothing
     int32_t *redo;               // per tile: memo-only pass flags a miss, full pass redoes flagged tiles
     const int32_t *redo_list;    // second pass: the flagged tiles of the launch (relative to tile_first) ...
@@ -1916,7 +1915,6 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.memo2_rows = sl.memo2_rows;
     a.memo2_stride = sl.memo2_stride;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
-    a.tile_end = sl.tile_first + (int64_t)grid;
     const bool second_pass = sl.redo && !memo_only;
     a.redo_list = nullptr;
     a.redo_cursor = nullptr;
