@@ -420,9 +420,10 @@ __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_
             double r = __builtin_amdgcn_rcp(q99);  // 2^-24; one Newton step: 2e-15, far inside the band
             r = fma(fma(-q99, r, 1.0), r, r);
             const double x = (P[kHW] * tsum) * r;  // ~ P/Q * t/99
-            const double fr = x - floor(x);
-            bad |= !(fabs(fr - 0.5) > mul_vs(x, kc->band));  // too close to a tie (or not a number)
-            e2[strand] = floor(x + 0.5);
+            const double e = floor(x + 0.5);
+            // too close to a tie (or not a number)?  |x - e| = 1/2 - (distance of x to the nearest half-integer)
+            bad |= !(fabs(x - e) < fma(x, -kc->band, 0.5));
+            e2[strand] = e;
         }
         tr.ex = e2[0] + e2[1];
         tr.k = (m.pk[8 + kPad + 1 + tid] & 0xffffu) + (m.pk[8 + kPad + tid] >> 16);
@@ -492,19 +493,21 @@ __device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *
 template <int NT>
 __device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
     constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
-    bool far = false;
     double *dst = a.winp_out + o.out_off + o.t;
+    // a window of half-width hs fits iff hs <= the distance to the nearer end (-1: not this lane's base)
+    const int room = o.mine ? min(o.t, o.L - 1 - o.t) : -1;
+    double lowest = 0.0;  // the edge lanes' argument is +1e4 / sqrt(K): it never lowers the minimum
     for (int s = 0; s < a.n_scales; ++s) {
         const int hs = a.scales[s];
-        const bool inside = o.mine && o.t >= hs && o.t < o.L - hs;
+        const bool inside = hs <= room;
         const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
         const double sv = Z[hi] - Z[lo];
         const double arg = -(sv * a.scale_rsqrt[s]);
-        far |= inside && !(arg > -kc->limit);  // one-sided: see ndtr_fast_s
+        lowest = fmin(lowest, arg);
         const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
         if (o.mine) dst[(int64_t)s * a.total_bases] = pw;
     }
-    return far;
+    return !(lowest > -kc->limit);  // one-sided: see ndtr_fast_s (z is finite here, so is every argument)
 }
 // one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right
 template <int NT>
