@@ -456,12 +456,18 @@ __device__ __forceinline__ lean_owner lean_own(const lean_tile &g, int tid, bool
     return o;
 }
 
+// base[byte_off / 8] = v with a uniform base and an unsigned 32-bit BYTE offset per lane: the form the
+// store instruction takes directly (base in scalar registers), without 64-bit vector address adds
+__device__ __forceinline__ void store_at(double *base, u32 byte_off, double v) {
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 __device__ __forceinline__ void lean_store_tracks(const lean_args &a, const lean_owner &o, const lean_tracks &tr) {
     if (o.mine) {
-        const int64_t gi = o.out_off + o.t;
-        if (a.exp_out) a.exp_out[gi] = tr.ex;
-        if (a.obs_out) a.obs_out[gi] = (double)tr.k;
-        if (a.pval_out) a.pval_out[gi] = tr.pv;
+            const u32 t8 = (u32)o.t * 8u;  // a tile's interval is far shorter than 2^29 bases
+        if (a.exp_out) store_at(a.exp_out + o.out_off, t8, tr.ex);
+        if (a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)tr.k);
+        if (a.pval_out) store_at(a.pval_out + o.out_off, t8, tr.pv);
     }
 }
 
@@ -493,7 +499,8 @@ __device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *
 template <int NT>
 __device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
     constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
-    double *dst = a.winp_out + o.out_off + o.t;
+    double *row = a.winp_out + o.out_off;  // uniform: see lean_store_tracks
+    const u32 t8 = (u32)o.t * 8u;
     // a window of half-width hs fits iff hs <= the distance to the nearer end (-1: not this lane's base)
     const int room = o.mine ? min(o.t, o.L - 1 - o.t) : -1;
     double lowest = 0.0;  // the edge lanes' argument is +1e4 / sqrt(K): it never lowers the minimum
@@ -505,7 +512,9 @@ __device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, cons
         const double arg = -(sv * a.scale_rsqrt[s]);
         lowest = fmin(lowest, arg);
         const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
-        if (o.mine) dst[(int64_t)s * a.total_bases] = pw;
+        double *row_s = row + (int64_t)s * a.total_bases;
+        asm volatile("" : "+s"(row_s));  // keeps the scale's base in scalar registers (no per-lane pointer carried through the loop)
+        if (o.mine) store_at(row_s, t8, pw);
     }
     return !(lowest > -kc->limit);  // one-sided: see ndtr_fast_s (z is finite here, so is every argument)
 }
@@ -519,7 +528,7 @@ __device__ __forceinline__ bool lean_window_narrow(const lean_args &a, kcoef *kc
         for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
     const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
     const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
-    if (o.mine) a.winp_out[o.out_off + o.t] = pw;
+    if (o.mine) store_at(a.winp_out + o.out_off, (u32)o.t * 8u, pw);
     return inside && !(arg > -kc->limit);
 }
 
