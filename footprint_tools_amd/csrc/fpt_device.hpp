@@ -138,6 +138,110 @@ __device__ __forceinline__ double trimmed_mean(const double *x, int n, int k) {
     return trimmed_mean_general(x, n, k);
 }
 
+// ---- the same window in the reference's own order of operations (modeling/smoothing.h:11-99)
+//
+// The multiset forms above give the exact trimmed sum T.  The reference's value is T plus the
+// rounding noise of its evaluation: Beliakov weights such as 2/3 are inexact, and the elements
+// are added up in whatever order the two in-place selections left them in.  That noise (at most
+// ~1.2e-14 relative for non-negative data) matters in exactly one place: when P/Q * W' lies so
+// close to a half-integer that it decides round() (predict.h:62).  Windows flagged as such are
+// evaluated once more by the two functions below, operation for operation like the reference.
+
+// smoothing.h:11-53 -- Numerical-Recipes selection of the k-th smallest of v[0..n): median of
+// v[lo], v[lo+1], v[hi] as the pivot, two cursors walking towards each other.  The permutation it
+// leaves in v is part of the result.  The cursor guards (i < hi, j > lo) never fire on ordered
+// data -- v[lo] <= pivot <= v[hi] stop the cursors there at the latest -- and keep the walk inside
+// the window when a NaN breaks the ordering (the reference then reads out of bounds).
+__device__ __forceinline__ void exch(double *v, int p, int q) {
+    const double t = v[p];
+    v[p] = v[q];
+    v[q] = t;
+}
+__device__ __forceinline__ double select_in_place(double *v, int n, int k) {
+    int lo = 0, hi = n - 1;
+    while (hi > lo + 1) {
+        exch(v, (lo + hi) >> 1, lo + 1);
+        if (v[lo] > v[hi]) exch(v, lo, hi);
+        if (v[lo + 1] > v[hi]) exch(v, lo + 1, hi);
+        if (v[lo] > v[lo + 1]) exch(v, lo, lo + 1);
+        int i = lo + 1, j = hi;
+        const double pivot = v[lo + 1];
+        for (;;) {
+            do ++i; while (i < hi && v[i] < pivot);
+            do --j; while (j > lo && v[j] > pivot);
+            if (j < i) break;
+            exch(v, i, j);
+        }
+        v[lo + 1] = v[j];
+        v[j] = pivot;
+        if (j >= k) hi = j - 1;
+        if (j <= k) lo = i;
+    }
+    if (hi == lo + 1 && v[hi] < v[lo]) exch(v, lo, hi);
+    return v[k];
+}
+
+// smoothing.h:59-99 on a private, writable copy of the window: both selections, the class counts,
+// the two weights as quotients, and the weighted elements added left to right in the permuted
+// order.  Returns the trimmed SUM.
+__device__ __noinline__ double trimmed_sum_reference_order(double *v, int n, int k) {
+#pragma clang fp contract(off)
+    const double os1 = select_in_place(v, n, k);
+    const double os2 = select_in_place(v, n, n - k - 1);
+    double b = 0.0, bm = 0.0, d = 0.0, dm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double r = v[i];
+        if (r < os1) bm += 1.0; else if (r == os1) b += 1.0;
+        if (r < os2) dm += 1.0; else if (r == os2) d += 1.0;
+    }
+    const double w1 = (b + bm - (double)k) / b;
+    const double w2 = ((double)(n - k) - dm) / d;
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double x = v[i];
+        double term;  // smoothing.h:59-70, in its order of tests (it matters when os1 == os2)
+        if (x < os2 && x > os1) term = x;
+        else if (x < os1) term = 0.0;
+        else if (x > os2) term = 0.0;
+        else if (x == os1) term = w1 * x;
+        else term = w2 * x;
+        t += term;
+    }
+    return t;
+}
+
+// Could the reference's rounding noise move round(x) away from round() of the exactly computed
+// product?  x = P/Q * T/(n-2k) from the exact trimmed sum T; tol_x bounds |x_reference - x|.
+__device__ __forceinline__ bool near_rounding_tie(double x, double tol_x) {
+    const double ax = fabs(x);
+    return fabs((ax - floor(ax)) - 0.5) <= tol_x;
+}
+
+// Workgroup-cooperative re-evaluation: lanes with `need` copy their window (n values at src) into
+// one of n_slots scratch windows in LDS (handed out through an LDS counter, as many rounds as it
+// takes) and run the reference's order of operations on it.  Must be called by every lane of the
+// workgroup; scratch (n_slots * n doubles) may still be read by other lanes on entry -- the first
+// vote is a barrier.  Returns the trimmed sum for lanes with `need`, 0 otherwise.
+__device__ __forceinline__ double trimmed_sum_rounds(bool need, const double *src, int n, int k, double *scratch,
+                                                     int n_slots, int *counter, int tid) {
+    double res = 0.0;
+    bool pending = need;
+    while (__syncthreads_or(pending ? 1 : 0)) {
+        if (tid == 0) *counter = 0;
+        __syncthreads();
+        if (pending) {
+            const int slot = atomicAdd(counter, 1);
+            if (slot < n_slots) {
+                double *buf = scratch + (size_t)slot * n;
+                for (int i = 0; i < n; ++i) buf[i] = src[i];
+                res = trimmed_sum_reference_order(buf, n, k);
+                pending = false;
+            }
+        }
+    }
+    return res;
+}
+
 // Correctly rounded t / d for a divisor whose reciprocal rd = RN(1/d) is computed once
 // (Markstein: q = RN(t*rd) is within an ulp, the remainder fma is exact, the corrected quotient
 // rounds like the true division).  Replaces the ~25-instruction IEEE divide where the divisor

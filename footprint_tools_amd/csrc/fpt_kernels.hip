@@ -49,39 +49,71 @@ __global__ void __launch_bounds__(256) k_kmer_probs(const uint8_t *__restrict__ 
 // ===========================================================================
 __global__ void __launch_bounds__(256) k_predict_rows(const double *__restrict__ obs,
                                                       const double *__restrict__ probs, int l,
-                                                      int hw, int shw, int k_trim, int tile_len,
+                                                      int hw, int shw, int k_trim, int tile_len, int n_slots,
                                                       double *__restrict__ exp_out,
                                                       double *__restrict__ win_out) {
-    extern __shared__ double s_w[];  // tile_len + 2*shw window sums
+    extern __shared__ double s_w[];  // tile_len + 2*shw window sums | n_slots windows | 2 words
     const int64_t row = blockIdx.y;
     const double *o = obs + row * (int64_t)l;
     const double *p = probs + row * (int64_t)l;
     const int i0 = blockIdx.x * tile_len;
     const int nw = tile_len + 2 * shw;
+    const int w = 2 * shw + 1;
+    double *scratch = s_w + nw;
+    unsigned long long *wmax_bits = reinterpret_cast<unsigned long long *>(scratch + (size_t)n_slots * w);
+    int *counter = reinterpret_cast<int *>(wmax_bits + 1);
+    if (threadIdx.x == 0) *wmax_bits = 0ull;
+    __syncthreads();
+    double mx = 0.0;
     for (int v = threadIdx.x; v < nw; v += blockDim.x) {
         int u = i0 - shw + v;
         double acc = 0.0;
         if (u >= hw && u < l - hw)
             for (int j = -hw; j < hw; ++j) acc += o[u + j];
         s_w[v] = acc;
+        mx = acc != acc ? __longlong_as_double(0x7ff8000000000000ll) : fmax(mx, fabs(acc));
     }
+    // largest |window sum| of the tile for the tolerance below (non-negative doubles order like
+    // their bit patterns; a NaN lands on top and switches the re-evaluation off)
+    atomicMax(wmax_bits, (unsigned long long)__double_as_longlong(mx));
     __syncthreads();
-    for (int v = threadIdx.x; v < tile_len; v += blockDim.x) {
-        int u = i0 + v;
-        if (u >= l) break;
-        double ws;
-        if (shw > 0)
-            ws = (u >= shw && u < l - shw) ? trimmed_mean(&s_w[v], 2 * shw + 1, k_trim) : 0.0;
-        else
-            ws = s_w[v];
-        double e = 0.0;
-        if (u >= hw && u < l - hw) {
-            double q = 0.0;
-            for (int j = -hw; j < hw; ++j) q += p[u + j];
-            e = round((p[u] / q) * ws);
+    const double w_max = __longlong_as_double((long long)*wmax_bits);
+    const double w_div = (double)(w - 2 * k_trim);
+    for (int first = 0; first < tile_len; first += blockDim.x) {  // same trip count for every lane: votes inside
+#pragma clang fp contract(off)
+        const int v = first + threadIdx.x;
+        const int u = i0 + v;
+        const bool live = u < l;
+        const bool smoothed = live && shw > 0 && u >= shw && u < l - shw;
+        double ws = 0.0, q = 0.0, e = 0.0;
+        bool need = false;
+        if (live) {
+            if (shw > 0)
+                ws = smoothed ? trimmed_mean(&s_w[v], w, k_trim) : 0.0;
+            else
+                ws = s_w[v];
+            if (u >= hw && u < l - hw) {
+                for (int j = -hw; j < hw; ++j) q += p[u + j];
+                const double pq = p[u] / q, x = pq * ws;
+                e = round(x);
+                // Where the reference's rounding noise around the exact trimmed sum could decide
+                // round(), the window goes through its order of operations (fpt_device.hpp); the
+                // bound is the one of tie_ctx::tol_x with the summation noise always counted in.
+                const double tol_t = w_max * ((double)((w + 256) * 256) * 1.1102230246251565e-16);
+                need = smoothed && near_rounding_tie(x, fabs(pq) * tol_t / w_div + fabs(x) * 1e-13);
+            }
         }
-        exp_out[row * (int64_t)l + u] = e;
-        win_out[row * (int64_t)l + u] = ws;
+        if (shw > 0) {
+            const double t = trimmed_sum_rounds(need, &s_w[need ? v : 0], w, k_trim, scratch, n_slots, counter, threadIdx.x);
+            if (need) {
+                ws = t / w_div;
+                e = round((p[u] / q) * ws);
+            }
+        }
+        if (live) {
+            exp_out[row * (int64_t)l + u] = e;
+            win_out[row * (int64_t)l + u] = ws;
+        }
     }
 }
 
@@ -394,11 +426,32 @@ __device__ __forceinline__ int opaque_tid() {
     return t;
 }
 
+// What phase C needs to send a window through the reference's own order of operations
+// (fpt_device.hpp: trimmed_sum_rounds).  w_max = the largest |2*hw window sum| staged by the
+// workgroup, or 0 when the window sums are small non-negative integers: every fast form then holds
+// the exact trimmed sum T and the reference's value is T(1 + 1.2e-14) at worst.  Otherwise the
+// scans and the reference both carry summation noise, bounded through w_max: at most
+// (w + 256) additions of magnitude <= 256 * w_max each side.
+struct tie_ctx {
+    double *scratch;      // LDS free in phase C once the scans have been read (xA, xB)
+    int scratch_doubles;
+    int *counter;         // LDS word: slot hand-out
+    double w_max;
+    bool flag_only;       // the memo-only instance: flag the tile for the full instance instead
+    __device__ __forceinline__ int slots(int w) const { return scratch_doubles / w; }
+    // bound on |x_reference - x| for x = pq * T / div
+    __device__ __forceinline__ double tol_x(double pq, double x, int w, double div) const {
+        const double tol_t = w_max * ((double)((w + 256) * 256) * 1.1102230246251565e-16);
+        return fabs(pq) * tol_t / div + fabs(x) * 1e-13;
+    }
+};
+
 template <int NT, typename T>
 __device__ __forceinline__ void smooth_expected_fast(const double *wP, const double *wM, const double *pP,
                                                      const double *pM, double *cP, double *cM, double *xA,
                                                      double *xB, int nc, int ncr, int nc_max, int pad,
-                                                     int hw, int shw, bool skip_trim, int tid_in) {
+                                                     int hw, int shw, bool skip_trim, int tid_in,
+                                                     const tie_ctx &tc) {
     constexpr int MAXI = 3;
     const int tid = tid_in;
     const int lane = tid & (kWave - 1);
@@ -450,6 +503,7 @@ __device__ __forceinline__ void smooth_expected_fast(const double *wP, const dou
     __syncthreads();
     // C2: per strand, tile prefix / suffix extrema, then the expected counts
     double eOut[2][MAXI];
+    unsigned near = 0;  // bit strand * MAXI + i: that window goes through the reference's order
 #pragma unroll
     for (int strand = 0; strand < 2; ++strand) {
         const double *ws = strand ? wM : wP;
@@ -492,10 +546,31 @@ __device__ __forceinline__ void smooth_expected_fast(const double *wP, const dou
                 const double wsm = skip_trim ? ws[v] : div_invariant(t, w_div, w_rdiv);
                 double q = 0.0;
                 for (int j = -hw; j < hw; ++j) q += ps[v + j];
-                eOut[strand][i] = round((ps[v] / q) * wsm);
+                const double pq = ps[v] / q, x = pq * wsm;
+                eOut[strand][i] = round(x);
+                if (!skip_trim && near_rounding_tie(x, tc.tol_x(pq, x, w, w_div))) near |= 1u << (strand * MAXI + i);
             }
         }
         __syncthreads();  // extrema buffers are reused by the other strand / overwritten by E
+    }
+    // windows whose rounding the reference's order of operations decides: once more, in that order
+    // (xA / xB are free now; the first vote inside is a barrier)
+#pragma unroll
+    for (int strand = 0; strand < 2; ++strand) {
+        const double *ws = strand ? wM : wP;
+        const double *ps = strand ? pM : pP;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+#pragma clang fp contract(off)
+            const int v = i * NT + tid;
+            const bool need = !tc.flag_only && ((near >> (strand * MAXI + i)) & 1u);
+            const double t = tc.flag_only ? 0.0 : trimmed_sum_rounds(need, ws + (need ? v - shw : 0), w, 1, tc.scratch, tc.slots(w), tc.counter, tid);
+            if (need) {
+                double q = 0.0;
+                for (int j = -hw; j < hw; ++j) q += ps[v + j];
+                eOut[strand][i] = round((ps[v] / q) * (t / w_div));
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
@@ -519,7 +594,8 @@ __device__ __forceinline__ void smooth_expected_fused(const double *wP, const do
                                                       const double *pM, double *cP, double *cM, double *xA,
                                                       double *xB, int nc, int ncr, int nc_max, int nt, int pad,
                                                       int hw, int shw, bool skip_trim, double &e_plus,
-                                                      double &e_minus, int tid_in) {
+                                                      double &e_minus, int tid_in, const tie_ctx &tc,
+                                                      bool &flag_tile) {
     typedef unsigned short u16;
     const int tid = tid_in;
     const int lane = tid & (kWave - 1);
@@ -560,7 +636,7 @@ __device__ __forceinline__ void smooth_expected_fused(const double *wP, const do
     }
     __syncthreads();
     e_plus = e_minus = 0.0;
-    if (tid >= nt) return;
+    flag_tile = false;
     const bool le3 = shw <= 64;
     auto range_min = [&](const u16 *p, const u16 *s, int lo, int hi) {  // spans >= 2 tiles (w > 64)
         int m = min((int)s[lo], (int)p[hi]);
@@ -572,30 +648,56 @@ __device__ __forceinline__ void smooth_expected_fused(const double *wP, const do
         for (int q = (lo >> 6) + 1; q < (hi >> 6); ++q) m = max(m, (int)p[(q << 6) + 63]);
         return m;
     };
+    bool near[2] = {false, false};
+    if (tid < nt) {
+#pragma unroll
+        for (int strand = 0; strand < 2; ++strand) {
+#pragma clang fp contract(off)
+            const int v = pad + tid + (strand ? 0 : 1);
+            const double *ws = strand ? wM : wP, *pr = strand ? pM : pP;
+            const int lo = v - shw, hi = v + shw;
+            const int S = le3 ? tile_range_sum3(strand ? psM : psP, lo, hi) : tile_range_sum(strand ? psM : psP, lo, hi);
+            const int wc = le3 ? tile_range_sum3(chB, lo, hi - 1) : tile_range_sum(chB, lo, hi - 1);
+            const int nchg = strand ? (wc >> 16) : (wc & 0xffff);
+            double t;
+            if (nchg > 4) {
+                const int mn = range_min(strand ? mnM : mnP, strand ? mnMs : mnPs, lo, hi);
+                const int mx = range_max(strand ? mxM : mxP, strand ? mxMs : mxPs, lo, hi);
+                t = ((double)S - (double)mn) - (double)mx;
+            } else if (nchg == 0) {
+                t = (double)(w - 1) * ws[lo];
+            } else {
+                t = trimmed_sum_k1(ws + lo, w);
+            }
+            const double wsm = skip_trim ? ws[v] : div_invariant(t, w_div, w_rdiv);
+            double q = 0.0;
+            for (int j = -hw; j < hw; ++j) q += pr[v + j];
+            const double pq = pr[v] / q, x = pq * wsm;
+            const double e = round(x);
+            near[strand] = !skip_trim && near_rounding_tie(x, tc.tol_x(pq, x, w, w_div));
+            if (strand) e_minus = e; else e_plus = e;
+        }
+    }
+    if (tc.flag_only) {  // the full instance, launched behind this one, settles it
+        flag_tile = near[0] | near[1];
+        return;
+    }
+    // t is the exact integer; a window whose rounding the reference's noise around it could decide
+    // is evaluated once more the reference's way (the scan buffers in xA / xB are free after the
+    // first vote inside)
 #pragma unroll
     for (int strand = 0; strand < 2; ++strand) {
 #pragma clang fp contract(off)
         const int v = pad + tid + (strand ? 0 : 1);
         const double *ws = strand ? wM : wP, *pr = strand ? pM : pP;
-        const int lo = v - shw, hi = v + shw;
-        const int S = le3 ? tile_range_sum3(strand ? psM : psP, lo, hi) : tile_range_sum(strand ? psM : psP, lo, hi);
-        const int wc = le3 ? tile_range_sum3(chB, lo, hi - 1) : tile_range_sum(chB, lo, hi - 1);
-        const int nchg = strand ? (wc >> 16) : (wc & 0xffff);
-        double t;
-        if (nchg > 4) {
-            const int mn = range_min(strand ? mnM : mnP, strand ? mnMs : mnPs, lo, hi);
-            const int mx = range_max(strand ? mxM : mxP, strand ? mxMs : mxPs, lo, hi);
-            t = ((double)S - (double)mn) - (double)mx;
-        } else if (nchg == 0) {
-            t = (double)(w - 1) * ws[lo];
-        } else {
-            t = trimmed_sum_k1(ws + lo, w);
+        const bool need = near[strand];
+        const double t = trimmed_sum_rounds(need, ws + (need ? v - shw : 0), w, 1, tc.scratch, tc.slots(w), tc.counter, tid);
+        if (need) {
+            double q = 0.0;
+            for (int j = -hw; j < hw; ++j) q += pr[v + j];
+            const double e = round((pr[v] / q) * (t / w_div));
+            if (strand) e_minus = e; else e_plus = e;
         }
-        const double wsm = skip_trim ? ws[v] : div_invariant(t, w_div, w_rdiv);
-        double q = 0.0;
-        for (int j = -hw; j < hw; ++j) q += pr[v + j];
-        const double e = round((pr[v] / q) * wsm);
-        if (strand) e_minus = e; else e_plus = e;
     }
 }
 
@@ -613,8 +715,9 @@ template <int NT, int HWC, int SHWC, bool TBLG, bool MO, bool LOOPED, typename A
 __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     extern __shared__ double smem[];
     const double *tbl = TBLG ? a.table : smem;  // kTable + 1 (+1 pad to keep 16-B alignment)
-    double *par_lds = smem + (TBLG ? 0 : (kTable + 2));  // 24 (unused when MO)
-    double *cP = par_lds + (MO ? 0 : 24);     // counts '+', scratch in C, expected '+' for D
+    double *par_lds = smem + (TBLG ? 0 : (kTable + 2));  // 24 + 2 (unused when MO)
+    double *aux = par_lds + 24;               // [0] largest |window sum| of the tile, [1] slot counter (tie_ctx)
+    double *cP = par_lds + (MO ? 0 : 26);     // counts '+', scratch in C, expected '+' for D
     double *cM = cP + a.nc_max;
     double *pP = cM + a.nc_max;               // propensities
     double *pM = pP + a.nc_max;
@@ -781,6 +884,31 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     }
     const bool all_small_int = __syncthreads_and(small_int) != 0;
     if (ABL(64)) return;
+    // what a window needs to go through the reference's own order of operations where that order
+    // decides round() (tie_ctx).  The memo-only instance hands such tiles to the full one.
+    tie_ctx tc;
+    tc.scratch = xA;
+    tc.scratch_doubles = 2 * a.nc_max;
+    tc.counter = reinterpret_cast<int *>(aux + 1);
+    tc.w_max = 0.0;
+    tc.flag_only = MO;
+    if (MO) {
+        if (!all_small_int && tid == 0) a.redo[tile] = 1;
+    } else if (!all_small_int) {
+        // fractional, negative or very large counts: the tolerance needs the largest |window sum|
+        // (non-negative doubles order like their bit patterns; a NaN ends up on top and switches
+        // the re-evaluation off -- the reference's selection is undefined on NaN)
+        unsigned long long *wmax_bits = reinterpret_cast<unsigned long long *>(aux);
+        if (tid == 0) *wmax_bits = 0ull;
+        __syncthreads();
+        double mx = 0.0;
+        for (int v = tid; v < nc; v += NT) mx = fmax(mx, fmax(fabs(wP[v]), fabs(wM[v])));
+        for (int v = tid; v < nc; v += NT)
+            if (wP[v] != wP[v] || wM[v] != wM[v]) mx = __longlong_as_double(0x7ff8000000000000ll);
+        atomicMax(wmax_bits, (unsigned long long)__double_as_longlong(mx));
+        __syncthreads();
+        tc.w_max = __longlong_as_double((long long)*wmax_bits);
+    }
 
     // ---- C: smoothing (smoothing.h:107-133) + expected counts (predict.h:60-63);
     //         E overwrites the counts, which nobody reads any more
@@ -788,23 +916,44 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     if (a.fast_trim) {
         // T = int when the whole tile's window sums are small integers (decided block-wide at the
         // barrier that ends phase B), else double
-        if (all_small_int)
+        if (all_small_int) {
+            bool flag_tile = false;
             smooth_expected_fused<NT>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, nt, pad, hw, shw, ABL(1),
-                                      ex_plus, ex_minus, tid);
-        else
-            smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1), tid);
+                                      ex_plus, ex_minus, tid, tc, flag_tile);
+            if (MO && flag_tile) a.redo[tile] = 1;
+        } else {
+            smooth_expected_fast<NT, double>(wP, wM, pP, pM, cP, cM, xA, xB, nc, ncr, a.nc_max, pad, hw, shw, ABL(1), tid, tc);
+        }
     } else {
         const int ne = nt + 1;  // padded positions [pad, nc-pad) per strand
-        for (int idx = tid; idx < 2 * ne; idx += NT) {
+        const int w = 2 * shw + 1;
+        const bool smooth = shw > 0 && !ABL(1);
+        const double w_div = (double)(w - 2 * a.k_trim);
+        for (int first = 0; first < 2 * ne; first += NT) {  // the same trip count for every lane: votes inside
+#pragma clang fp contract(off)
+            const int idx = first + tid;
+            const bool live = idx < 2 * ne;
             const bool minus = idx >= ne;
-            const int v = pad + (minus ? idx - ne : idx);
+            const int v = live ? pad + (minus ? idx - ne : idx) : pad;
             const double *ws = minus ? wM : wP;
             const double *ps = minus ? pM : pP;
-            double wsm = (shw > 0 && !ABL(1)) ? trimmed_mean(ws + v - shw, 2 * shw + 1, a.k_trim) : ws[v];
-            double q = 0.0;
-            for (int j = -hw; j < hw; ++j) q += ps[v + j];
-            double e = round((ps[v] / q) * wsm);
-            (minus ? cM : cP)[v] = e;
+            double q = 0.0, pq = 0.0, e = 0.0;
+            bool need = false;
+            if (live) {
+                const double wsm = smooth ? trimmed_mean(ws + v - shw, w, a.k_trim) : ws[v];
+                for (int j = -hw; j < hw; ++j) q += ps[v + j];
+                pq = ps[v] / q;
+                const double x = pq * wsm;
+                e = round(x);
+                need = smooth && near_rounding_tie(x, tc.tol_x(pq, x, w, w_div));
+            }
+            if (MO) {
+                if (need) a.redo[tile] = 1;
+            } else if (smooth) {
+                const double t = trimmed_sum_rounds(need, ws + v - shw, w, a.k_trim, tc.scratch, tc.slots(w), tc.counter, tid);
+                if (need) e = round(pq * (t / w_div));
+            }
+            if (live) (minus ? cM : cP)[v] = e;
         }
     }
     __syncthreads();
@@ -1793,12 +1942,18 @@ void launch_predict_rows(hipStream_t st, const double *obs, const double *probs,
     if (n_rows <= 0 || l <= 0) return;
     const int tile_len = 1024;
     int tiles = (l + tile_len - 1) / tile_len;
-    size_t lds = (size_t)(tile_len + 2 * shw) * sizeof(double);
+    // scratch windows for the re-evaluation in the reference's order (k_predict_rows): 16, fewer for
+    // very wide smoothing windows
+    const int w = 2 * shw + 1;
+    int n_slots = 16;
+    while (n_slots > 1 && (size_t)(tile_len + 2 * shw + (size_t)n_slots * w + 2) * sizeof(double) > 96 * 1024) n_slots >>= 1;
+    size_t lds = (size_t)(tile_len + 2 * shw + (size_t)n_slots * w + 2) * sizeof(double);
+    (void)hipFuncSetAttribute((const void *)k_predict_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // grid.y is limited to 65535: loop over row chunks
     for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
         int64_t nr = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
         hipLaunchKernelGGL(k_predict_rows, dim3(tiles, (unsigned)nr), dim3(256), lds, st,
-                           obs + r0 * l, probs + r0 * l, l, hw, shw, k_trim, tile_len,
+                           obs + r0 * l, probs + r0 * l, l, hw, shw, k_trim, tile_len, n_slots,
                            exp_out + r0 * l, win_out + r0 * l);
     }
 }
@@ -1839,7 +1994,7 @@ void launch_window_rows(hipStream_t st, int op, const double *x, const double *w
 
 size_t scan_lds_bytes(int nc_max, bool tblg, bool memo_only) {
     if (memo_only) return (size_t)(8 * (size_t)nc_max) * sizeof(double);
-    return (size_t)((tblg ? 0 : kTable + 2) + 24 + 8 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
+    return (size_t)((tblg ? 0 : kTable + 2) + 26 + 8 * (size_t)nc_max) * sizeof(double) + (size_t)nc_max + 16;
 }
 
 typedef void (*scan_kernel_t)(const scan_args);

@@ -855,8 +855,70 @@ def g12():
     save("post_driver.npz", **out)
 
 
+# ---------------------------------------------------------------- G13: rounding ties of fast_predict
+def g13():
+    """Rows on which round() in predict.h:62 is decided by the rounding noise of the reference's own
+    trimmed sum (smoothing.h:72-99: inexact Beliakov weights such as 2/3, elements added in the
+    order the two selections left them in): equal propensities (a homopolymer: P/Q = 1/10),
+    alternating 1/0 counts (window sums of 5, so T/99 * 1/10 sits on 0.5) with a few bumps that tie
+    the window extrema three and more times.  An evaluation from the exact trimmed sum gives a
+    different integer on dozens of positions per row (counted in `n_flip`)."""
+    rs = np.random.RandomState(1313)
+    bm_p = 0.00437  # any value: every propensity of the row is the same
+    out, meta = {}, []
+    c = 0
+
+    def exact_exp(obs, probs, hw, shw, k):
+        l = obs.size
+        w = 2 * shw + 1
+        W, Q = np.zeros(l), np.zeros(l)
+        for i in range(hw, l - hw):
+            for j in range(-hw, hw):
+                W[i] += obs[i + j]
+                Q[i] += probs[i + j]
+        sm = np.zeros(l)
+        for i in range(shw, l - shw):
+            x = np.sort(W[i - shw:i + shw + 1])
+            sm[i] = x[k:w - k].sum() / (w - 2 * k)
+        e = np.zeros(l)
+        for i in range(hw, l - hw):
+            v = probs[i] / Q[i] * sm[i]
+            e[i] = np.floor(v + 0.5)
+        return e
+
+    for (hw, shw, clip, l, kind) in [(5, 50, .01, 1111, "alt"), (5, 50, .01, 1111, "alt"), (5, 50, .01, 611, "alt"),
+                                     (5, 50, .01, 611, "alt3"), (5, 50, .01, 611, "five"), (5, 50, .05, 611, "alt"),
+                                     (3, 20, .05, 400, "alt"), (5, 50, .01, 1111, "alt_rand_p")]:
+        base = np.tile([1.0, 0.0], l)[:l]
+        obs = base.copy()
+        if kind == "five":
+            obs = np.full(l, 5.0)
+            obs[rs.randint(0, l, 6)] += 1.0
+        else:
+            idx = rs.randint(0, l, 30 if l > 700 else 16)
+            obs[idx] += rs.choice([-1.0, 1.0, 1.0, 2.0], idx.size) * (base[idx] > 0)
+            obs = np.maximum(obs, 0.0)
+            if kind == "alt3":
+                obs *= 3.0
+        probs = np.full(l, bm_p)
+        if kind == "alt_rand_p":  # ordinary propensities around a homopolymer stretch
+            probs = rs.uniform(3e-4, 0.22, l)
+            probs[200:700] = bm_p
+        e, w = ref_predict_c(obs, probs, hw, shw, clip)
+        k = int((2 * shw + 1) * clip)
+        n_flip = int((exact_exp(obs, probs, hw, shw, k) != e).sum())
+        out["obs%d" % c], out["probs%d" % c] = obs, probs
+        out["exp%d" % c], out["win%d" % c] = e, w
+        meta.append((hw, shw, clip, l, n_flip))
+        c += 1
+    out["meta"] = np.array(meta, dtype=np.float64)
+    assert sum(m[4] for m in meta) > 50, meta
+    print("ties: positions where the exact trimmed sum rounds differently:", [m[4] for m in meta])
+    save("predict_ties.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -880,3 +942,5 @@ if __name__ == "__main__":
         g11()
     if "12" in which:
         g12()
+    if "13" in which:
+        g13()

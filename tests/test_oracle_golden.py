@@ -40,6 +40,19 @@ def test_fast_predict_golden(orc):
         assert same(w, g["win%d" % c]), "win case %d %s" % (c, meta[c])
 
 
+def test_fast_predict_rounding_ties_golden(orc):
+    """predict_ties.npz: rows where the rounding noise of the reference's own trimmed sum decides
+    round() on dozens of positions (meta[:, 4] counts them) -- the oracle follows the reference's
+    order of operations, so it is bit-identical there too."""
+    g = golden("predict_ties.npz")
+    meta = g["meta"]
+    assert meta[:, 4].sum() > 50
+    for c, (hw, shw, clip, l, n_flip) in enumerate(meta):
+        e, w = orc.fast_predict(g["obs%d" % c], g["probs%d" % c], int(hw), int(shw), float(clip))
+        assert same(e, g["exp%d" % c]), "exp case %d %s" % (c, meta[c])
+        assert same(w, g["win%d" % c]), "win case %d %s" % (c, meta[c])
+
+
 def test_trimmed_mean_quirks(orc):
     """OS1 == OS2 windows."""
     p = np.full(301, 0.1)
