@@ -24,7 +24,7 @@ EXPORTS = [
     "fpt_dev_zero", "fpt_format_stats", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_cut_counts_dev",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
-    "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
+    "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
 
@@ -73,6 +73,33 @@ class FdrDesc(C.Structure):
         ("efdr_out", C.c_void_p),
         ("null_uniform", C.c_void_p),
         ("null_winp_out", C.c_void_p),
+    ]
+
+
+class PosteriorDesc(C.Structure):
+    """struct fpt_posterior_desc of include/fpt.h"""
+    _fields_ = [
+        ("n_intervals", C.c_int64),
+        ("interval_len", C.c_int32),
+        ("interval_off", C.c_void_p),
+        ("total_bases", C.c_int64),
+        ("max_interval_len", C.c_int32),
+        ("n_datasets", C.c_int32),
+        ("dm_id", C.c_int32),
+        ("half_win_width", C.c_int32),
+        ("fdr_cutoff", C.c_double),
+        ("pseudocount", C.c_double),
+        ("betas", C.c_void_p),
+        ("obs", C.c_void_p),
+        ("exp", C.c_void_p),
+        ("fdr", C.c_void_p),
+        ("w", C.c_void_p),
+        ("post_out", C.c_void_p),
+        ("prior_out", C.c_void_p),
+        ("delta_out", C.c_void_p),
+        ("ll_on_out", C.c_void_p),
+        ("ll_off_out", C.c_void_p),
+        ("status_out", C.c_void_p),
     ]
 
 
@@ -126,6 +153,7 @@ def load():
         L.fpt_special.argtypes = [vp, i32, vp, vp, vp, i64, vp]
         L.fpt_scan_dev.argtypes = [vp, C.POINTER(ScanDesc)]
         L.fpt_fdr_dev.argtypes = [vp, C.POINTER(FdrDesc)]
+        L.fpt_posterior_dev.argtypes = [vp, C.POINTER(PosteriorDesc)]
         L.fpt_hist2d_dev.argtypes = [vp, vp, vp, i64, i32, i32, vp]
         L.fpt_segment_count_dev.argtypes = [vp, C.POINTER(SegmentDesc), C.POINTER(C.c_int64)]
         L.fpt_segment_fill_dev.argtypes = [vp, C.POINTER(SegmentDesc), i64, vp, vp, vp, vp]

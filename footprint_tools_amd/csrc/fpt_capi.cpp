@@ -76,6 +76,8 @@ struct fpt_ctx {
     std::vector<int64_t> plan_off;
     int plan_H = -1;
     int64_t plan_tiles = 0;
+    int plan_max_len = 0;  // longest interval of the cached ragged plan
+    std::vector<double> beta_host;  // fpt_posterior_dev: source of its asynchronous upload
     int64_t plan_cls_count[fptk::kLeanClasses] = {};  // tiles per workgroup-size class, in table order
     int64_t last_tiles = 0;      // tiles of the most recent memo-mode scan (fpt_scan_stats)
     bool last_has_redo = false;
@@ -523,10 +525,12 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         if (!cached) {
             constexpr int NC = fptk::kLeanClasses;
             std::vector<int32_t> tiv[NC], tt0[NC], ttl[NC];
+            int max_len = 0;
             for (int64_t i = 0; i < d->n_intervals; ++i) {
                 int64_t L64 = off[i + 1] - off[i];
                 if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
                 int L = (int)L64;
+                max_len = std::max(max_len, L);
                 if (L == 0) continue;
                 if (L <= 1024) {
                     int cls = lean_class(L);
@@ -560,6 +564,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
             c->plan_off.assign(off, off + n_off);
             c->plan_tiles = n_tiles;
+            c->plan_max_len = max_len;
             for (int cls = 0; cls < NC; ++cls) c->plan_cls_count[cls] = (int64_t)tiv[cls].size();
             c->plan_H = H;
         }
@@ -644,7 +649,9 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         if (memo_only && c->use_lean) {
             fptk::scan_launch s2 = sl;
             s2.redo = (int32_t *)d_redo;
-            lean_pass = fptk::scan_lean_applies(s2);
+            // the lean kernel addresses its outputs with 32-bit byte offsets inside an interval
+            const int longest = d->interval_off ? c->plan_max_len : d->interval_len;
+            lean_pass = fptk::scan_lean_applies(s2) && longest < (1 << 29);
         }
         for (const launch_t &ln : lean_pass ? lean_launches : launches) {
             fptk::scan_launch s2 = sl;
@@ -888,6 +895,57 @@ int fpt_last_scan_ms(fpt_ctx *c, float *ms_out) {
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
     return FPT_OK;
+}
+
+int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
+    if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
+    if (d->n_datasets < 1 || d->dm_id < 0 || d->dm_id + d->n_datasets > FPT_MAX_DISPERSION_MODELS)
+        return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range", d->dm_id, d->dm_id + d->n_datasets);
+    for (int i = 0; i < d->n_datasets; ++i)
+        if (!c->have_model[d->dm_id + i]) return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
+    if (d->half_win_width < 0 || d->half_win_width > 32)
+        return fail(FPT_ERR_INVALID, "half window %d out of range", d->half_win_width);
+    if (d->n_intervals == 0 || d->total_bases == 0) return FPT_OK;
+    if (d->total_bases < 0) return fail(FPT_ERR_INVALID, "negative track length");
+    if (!d->betas || !d->obs || !d->exp || !d->fdr || !d->w || !d->post_out) return fail(FPT_ERR_INVALID, "null buffer");
+    if (!d->interval_off) {
+        if (d->interval_len <= 0) return fail(FPT_ERR_INVALID, "interval_len must be positive");
+        if (d->n_intervals * (int64_t)d->interval_len != d->total_bases)
+            return fail(FPT_ERR_INVALID, "total_bases does not match n_intervals x interval_len");
+    }
+    // the Beta priors travel through a small device buffer (slot 6: shared with the FDR pass's
+    // lists, both are consumed by the launch that follows on the same stream)
+    void *d_beta;
+    const size_t nb = (size_t)d->n_datasets * 2 * sizeof(double);
+    if (int rc = ws_get(c, 6, nb, &d_beta)) return rc;
+    c->beta_host.assign(d->betas, d->betas + (size_t)d->n_datasets * 2);  // stays alive for the async copy
+    HIP_TRY(hipMemcpyAsync(d_beta, c->beta_host.data(), nb, hipMemcpyHostToDevice, c->stream));
+    fptk::posterior_launch pl{};
+    pl.n_intervals = d->n_intervals;
+    pl.interval_len = d->interval_off ? 0 : d->interval_len;
+    pl.interval_off = d->interval_off;
+    pl.total_bases = d->total_bases;
+    pl.max_len = d->interval_off ? (d->max_interval_len > 0 ? d->max_interval_len : 2048) : d->interval_len;
+    pl.n_datasets = d->n_datasets;
+    pl.hw = d->half_win_width;
+    pl.cutoff = d->fdr_cutoff;
+    pl.pseudocount = d->pseudocount;
+    pl.obs = d->obs;
+    pl.exp = d->exp;
+    pl.fdr = d->fdr;
+    pl.w = d->w;
+    pl.models = c->d_models + (size_t)d->dm_id * kModelDoubles;
+    pl.betas = (const double *)d_beta;
+    pl.post_out = d->post_out;
+    pl.prior_out = d->prior_out;
+    pl.delta_out = d->delta_out;
+    pl.ll_on_out = d->ll_on_out;
+    pl.ll_off_out = d->ll_off_out;
+    pl.status_out = d->status_out;
+    HIP_TRY(fptk::launch_posterior(c->stream, pl));
+    return launch_ok("k_posterior");
 }
 
 int fpt_hist2d_dev(fpt_ctx *c, const double *exp_dev, const double *obs_dev, int64_t n, int rows, int cols,

@@ -85,6 +85,25 @@ struct fdr_launch {
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl);
 
+// fpt_posterior.hip: the multi-dataset posterior caller (cli/post.py:98-124) as one kernel
+struct posterior_launch {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    int64_t total_bases;
+    int32_t max_len;                    // longest interval (sizes workgroups and the grid; any length is handled)
+    int32_t n_datasets, hw;
+    double cutoff, pseudocount;
+    const double *obs, *exp, *fdr, *w;  // (n_datasets, total_bases)
+    const double *models;               // n_datasets x 24
+    const double *betas;                // n_datasets x 2
+    double *post_out;                   // (total_bases, n_datasets)
+    double *prior_out, *delta_out, *ll_on_out, *ll_off_out;
+    int32_t *status_out;
+};
+size_t posterior_lds_bytes(int n_datasets, int nt);
+hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl);
+
 struct segment_launch {
     int64_t n_intervals;
     int32_t interval_len;

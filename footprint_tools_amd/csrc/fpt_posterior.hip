@@ -1,0 +1,238 @@
+// fpt_posterior.hip -- the multi-dataset posterior caller as ONE kernel (gfx950 / CDNA4, wave64).
+//
+// The reference computes, per interval and with numpy loops over the datasets (cli/post.py:98-124):
+//   prior  = compute_prior_weighted(fdr, w)                         stats/posterior.py:12-42
+//   delta  = compute_delta_prior(obs, exp, fdr, betas)              stats/posterior.py:45-90
+//   ll_on  = log_likelihood(obs, exp, dm, delta=delta, w=3)         stats/posterior.py:93-121
+//   ll_off = log_likelihood(obs, exp, dm, w=3)
+//   post   = -posterior(prior, ll_on, ll_off); post[post <= 0] = 0  stats/posterior.py:124-149, post.py:121-122
+// Here a workgroup owns a tile of one interval, a lane one base of it (plus `hw` halo bases either
+// side for the likelihood windows), and loops over the datasets twice:
+//   1. the two priors of its base -- counts over datasets, the Beta posterior mean and variance in
+//      closed form (scipy.stats.beta.stats is a/(a+b) and ab/((a+b)^2 (a+b+1)));
+//   2. per dataset: both NB log-pmfs of the base (dispersion.pyx:170-226 -> nbinom.pyx:82-100:
+//      lgam(k+r) - lgam(k+1) - lgam(r) + r log p + k log1p(-p); lgam(k+1) is shared by the two) into
+//      LDS, one barrier, the 2*hw+1 window sums left to right like windowing.h:11-23 (edges 1.0,
+//      windowing.pyx:51), log-sum-exp like numpy's logaddexp, clamp, store.
+// Tracks are dataset-major (D rows of sum(L) bases: lanes read consecutive doubles); the result
+// is base-major (sum(L) rows of D values), which is what the reference's record holds
+// (`post.T`) and what its writer prints per base.
+//
+// Cost: per dataset and base 5 lgam, 2 log, 2 log1p, 4 piecewise fits, exp + log1p -- vector fp64
+// work, not HBM traffic (40 bytes per dataset-base): see DESIGN.md for the measured rate.
+#include "fpt_kernels.hpp"
+
+#include "fpt_device.hpp"
+
+using namespace fptd;
+
+namespace {
+
+struct post_args {
+    int64_t n_intervals;
+    int32_t interval_len;
+    const int64_t *interval_off;
+    int64_t total_bases;
+    int32_t n_datasets, hw;
+    double cutoff, pseudocount;
+    const double *obs, *exp, *fdr, *w;  // (D, total_bases)
+    const double *models;               // D x 24 (mu 9, r 15)
+    const double *betas;                // D x 2
+    double *post_out;                   // (total_bases, D)
+    double *prior_out, *delta_out, *ll_on_out, *ll_off_out;  // optional: (D, total) / (total) / (D, total) x 2
+    int32_t *status_out;                // optional, per interval: 1 = a dispersion fit divided by zero
+};
+
+// np.max(np.vstack([a, b]), axis=0) of two values: NaN wins (posterior.py:72)
+__device__ __forceinline__ double np_max2(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+
+// numpy's logaddexp (npy_logaddexp): the branch on the sign of x - y keeps exp's argument <= 0
+__device__ __forceinline__ double np_logaddexp(double x, double y) {
+    if (x == y) return x + 0.6931471805599453094;  // also +-inf == +-inf
+    const double t = x - y;
+    if (t > 0) return x + log1p(exp(-t));
+    if (t <= 0) return y + log1p(exp(t));
+    return t;  // NaN
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
+    extern __shared__ double smem[];
+    const int D = a.n_datasets, hw = a.hw;
+    double *par = smem;                  // D x 24
+    double *beta = par + (size_t)D * 24; // D x 2
+    double *lp = beta + (size_t)D * 2;   // [2 buffers][on, off][NT]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < D * 24; i += NT) par[i] = a.models[i];
+    for (int i = tid; i < D * 2; i += NT) beta[i] = a.betas[i];
+    __syncthreads();
+
+    const int64_t iv = blockIdx.x;
+    int64_t off;
+    int L;
+    if (a.interval_off) {
+        off = a.interval_off[iv];
+        L = (int)(a.interval_off[iv + 1] - off);
+    } else {
+        L = a.interval_len;
+        off = iv * (int64_t)L;
+    }
+    const int64_t T = a.total_bases;
+    const int TL = NT - 2 * hw;  // output bases per tile
+    bool zero_div = false;
+    int round = 0;               // parity of the LDS buffer across tiles and datasets
+    for (int t0 = blockIdx.y * TL; t0 < L; t0 += gridDim.y * TL) {
+        const int u = t0 - hw + tid;  // this lane's base (halo lanes included)
+        const bool valid = u >= 0 && u < L;
+        const int64_t g = off + (valid ? u : 0);
+        // ---- 1: the priors of this base (both are reductions over the datasets)
+        double pr = 1.0, delta = 1.0;
+        unsigned long long uncovered = 0;  // bit d: w[d] == 0 (the prior of that dataset is 1)
+        if (valid) {
+            double k_called = 0.0, n_cov = 0.0, sw = 0.0, swm = 0.0;
+            for (int d = 0; d < D; ++d) {
+#pragma clang fp contract(off)
+                const int64_t j = (int64_t)d * T + g;
+                const double f = a.fdr[j], ww = a.w[j], o = a.obs[j], e = a.exp[j];
+                if (f <= a.cutoff) k_called += 1.0;
+                n_cov += ww;
+                if (ww == 0.0) uncovered |= 1ull << d;
+                // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean and variance
+                const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
+                double mu = NAN, var = NAN;  // scipy returns NaN for arguments outside the domain
+                if (al > 0.0 && be > 0.0) {
+                    const double s = al + be;
+                    mu = al / s;
+                    var = al * be / ((s * s) * (s + 1.0));
+                }
+                double wt = 1.0 / sqrt(var);
+                if (f > a.cutoff) wt = 0.0;
+                swm += wt * mu;
+                sw += wt;
+            }
+            const double unocc = n_cov - k_called + a.pseudocount, occ = k_called + a.pseudocount;
+            pr = unocc / (unocc + occ);
+            delta = swm / sw;
+            if (delta != delta) delta = 1.0;
+            if (a.delta_out && tid >= hw && tid < NT - hw) a.delta_out[g] = delta;
+        }
+        const bool mine = valid && tid >= hw && tid < NT - hw;  // an output base of this tile
+        const bool inside = mine && u >= hw && u < L - hw;       // its window fits the interval
+        const double log_pr = log(pr), log_1mpr = log(1.0 - pr);
+        // ---- 2: per dataset, both log-pmfs -> LDS -> window sums -> posterior
+        for (int d = 0; d < D; ++d, ++round) {
+            double *lp_on = lp + (size_t)(round & 1) * 2 * NT, *lp_off = lp_on + NT;
+            double v_on = 0.0, v_off = 0.0;
+            if (valid) {
+                const int64_t j = (int64_t)d * T + g;
+                const double o = a.obs[j], e = a.exp[j];
+                const double *mu9 = par + d * 24, *r15 = mu9 + 9;
+                const int32_t k = fptm::c_int(o);
+                const double lg_k1 = fptm::lgam((double)fptm::wrap_inc(k));
+                double lg[2][2];
+                double rr[2], pp[2];
+                FPT_NOUNROLL
+                for (int s = 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
+                    const double x = s == 0 ? e * delta : e;
+                    rr[s] = fptm::fit_r(r15, x, &zero_div);
+                    const double mu = fptm::fit_mu(mu9, x);
+                    pp[s] = rr[s] / (rr[s] + mu);
+                    lg[s][0] = fptm::lgam((double)k + rr[s]);
+                    lg[s][1] = fptm::lgam(rr[s]);
+                }
+                {
+#pragma clang fp contract(off)
+                    v_on = ((lg[0][0] - lg_k1) - lg[0][1]) + rr[0] * log(pp[0]) + (double)k * fptm::log1p_fn(-pp[0]);
+                    v_off = ((lg[1][0] - lg_k1) - lg[1][1]) + rr[1] * log(pp[1]) + (double)k * fptm::log1p_fn(-pp[1]);
+                }
+            }
+            lp_on[tid] = v_on;
+            lp_off[tid] = v_off;
+            __syncthreads();  // the other buffer is free again once every lane is past the NEXT barrier
+            if (mine) {
+                double ll_on = 1.0, ll_off = 1.0;  // windowing.pyx:51: edges keep the 1.0 of np.ones
+                if (inside) {
+                    ll_on = ll_off = 0.0;
+                    for (int j = tid - hw; j <= tid + hw; ++j) {
+                        ll_on += lp_on[j];
+                        ll_off += lp_off[j];
+                    }
+                }
+                const bool unc = (uncovered >> d) & 1ull;
+                // posterior.py:140-149 with prior = 1 where the dataset has no hotspot (log 0 = -inf)
+                const double p_off = (unc ? 0.0 : log_pr) + ll_off;
+                const double p_on = (unc ? -fptm::kInf : log_1mpr) + ll_on;
+                double post = -(p_off - np_logaddexp(p_on, p_off));
+                if (post <= 0.0) post = 0.0;  // post.py:122 (a NaN stays)
+                a.post_out[g * D + d] = post;
+                const int64_t j = (int64_t)d * T + g;
+                if (a.prior_out) a.prior_out[j] = unc ? 1.0 : pr;
+                if (a.ll_on_out) a.ll_on_out[j] = ll_on;
+                if (a.ll_off_out) a.ll_off_out[j] = ll_off;
+            }
+        }
+    }
+    if (zero_div && a.status_out) atomicOr(&a.status_out[iv], 1);
+}
+
+}  // namespace
+
+namespace fptk {
+
+size_t posterior_lds_bytes(int n_datasets, int nt) { return (size_t)(n_datasets * 26 + 4 * nt) * sizeof(double); }
+
+hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
+    post_args a;
+    a.n_intervals = pl.n_intervals;
+    a.interval_len = pl.interval_len;
+    a.interval_off = pl.interval_off;
+    a.total_bases = pl.total_bases;
+    a.n_datasets = pl.n_datasets;
+    a.hw = pl.hw;
+    a.cutoff = pl.cutoff;
+    a.pseudocount = pl.pseudocount;
+    a.obs = pl.obs;
+    a.exp = pl.exp;
+    a.fdr = pl.fdr;
+    a.w = pl.w;
+    a.models = pl.models;
+    a.betas = pl.betas;
+    a.post_out = pl.post_out;
+    a.prior_out = pl.prior_out;
+    a.delta_out = pl.delta_out;
+    a.ll_on_out = pl.ll_on_out;
+    a.ll_off_out = pl.ll_off_out;
+    a.status_out = pl.status_out;
+    // short intervals (the whole-genome hotspot set averages 162 bases) in 128-lane workgroups,
+    // anything longer in 256-lane ones; an interval longer than 8 tiles is spread over gridDim.y
+    const int nt = pl.max_len + 2 * pl.hw <= 128 ? 128 : 256;
+    const int tl = nt - 2 * pl.hw;
+    int64_t tiles = ((int64_t)pl.max_len + tl - 1) / tl;
+    int gy = tiles <= 8 ? 1 : (int)((tiles + 7) / 8);
+    if (gy > 65535) gy = 65535;
+    const size_t lds = posterior_lds_bytes(pl.n_datasets, nt);
+    void (*kern)(const post_args) = nt == 128 ? k_posterior<128> : k_posterior<256>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    for (int64_t done = 0; done < pl.n_intervals; done += 0x7fffff00) {
+        post_args b = a;
+        const int64_t n = pl.n_intervals - done < 0x7fffff00 ? pl.n_intervals - done : 0x7fffff00;
+        if (done) {  // a later chunk of a very large batch: shift the interval view
+            if (b.interval_off) b.interval_off += done;
+            else {
+                const int64_t shift = done * (int64_t)b.interval_len;
+                b.obs += shift, b.exp += shift, b.fdr += shift, b.w += shift;
+                b.post_out += shift * b.n_datasets;
+                if (b.prior_out) b.prior_out += shift;
+                if (b.delta_out) b.delta_out += shift;
+                if (b.ll_on_out) b.ll_on_out += shift;
+                if (b.ll_off_out) b.ll_off_out += shift;
+            }
+            if (b.status_out) b.status_out += done;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)n, gy), dim3(nt), lds, st, b);
+    }
+    return hipSuccess;
+}
+
+}  // namespace fptk

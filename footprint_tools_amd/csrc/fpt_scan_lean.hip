@@ -464,7 +464,7 @@ __device__ __forceinline__ void store_at(double *base, u32 byte_off, double v) {
 
 __device__ __forceinline__ void lean_store_tracks(const lean_args &a, const lean_owner &o, const lean_tracks &tr) {
     if (o.mine) {
-            const u32 t8 = (u32)o.t * 8u;  // a tile's interval is far shorter than 2^29 bases
+        const u32 t8 = (u32)o.t * 8u;  // intervals of 2^29 bases and more never reach this kernel (fpt_scan_dev)
         if (a.exp_out) store_at(a.exp_out + o.out_off, t8, tr.ex);
         if (a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)tr.k);
         if (a.pval_out) store_at(a.pval_out + o.out_off, t8, tr.pv);

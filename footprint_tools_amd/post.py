@@ -1,11 +1,13 @@
-"""Posterior footprint probabilities over many datasets: the per-interval driver of
-cli/post.py:40-124 (`posterior_stats`) on this package's modules.
+"""Posterior footprint probabilities over many datasets: the driver of cli/post.py:40-124
+(`posterior_stats`) in batched form.
 
-For one interval, every dataset's per-nucleotide track (`ftd detect` output) gives obs, exp and
-fdr rows (`_load_data`, post.py:57-87: column 3 = exp, 4 = obs, 7 = fdr, w = 1 where the dataset
-has a row); the priors are numpy reductions over datasets (stats/posterior.py:12-90) and the
-windowed NB log-likelihoods run on the GPU (stats.posterior.log_likelihood).  The record is
-`{"interval", "stats"}` with stats = -log P(unoccupied) clipped at 0, bases x datasets."""
+Every dataset's per-nucleotide track (`ftd detect` output) gives obs, exp and fdr rows over an
+interval (cli/post.py:57-87: file column 3 = exp, 4 = obs, 7 = fdr, w = 1 where the dataset has a
+row; 0 / 0 / 1 / 0 elsewhere).  `load_batch` builds those rows for any number of intervals back to
+back, and ONE kernel launch (stats.posterior.posterior_batch -> fpt_posterior_dev) turns them into
+the records: priors over datasets, windowed NB log-likelihoods with and without the expected
+depletion, log-sum-exp, -log P(unoccupied) clipped at 0.  `ps[i]` is the reference's per-interval
+record `{"interval", "stats"}` (a batch of one); `ps.batch(indices)` is how the drivers call it."""
 import numpy as np
 
 from .modeling import dispersion
@@ -25,7 +27,7 @@ class _interval(object):
 
 
 class posterior_stats(object):
-    def __init__(self, intervals, samples_data, fdr_cutoff):
+    def __init__(self, intervals, samples_data, fdr_cutoff, ctx=None):
         """intervals: sequence of (chrom, start, end) or objects with those attributes (the
         reference reads a BED file); samples_data: one record per dataset with `tabix_file`,
         `dm_file`, `beta_a`, `beta_b` (a pandas DataFrame with those columns, as in the reference,
@@ -34,29 +36,38 @@ class posterior_stats(object):
         rows = samples_data.to_dict("records") if hasattr(samples_data, "to_dict") else list(samples_data)
         self.samples_data = rows
         self.fdr_cutoff = fdr_cutoff
-        self.tabix_files = []  # opened on the first __getitem__, as in the reference
+        self.ctx = ctx
+        self.tabix_files = []  # opened on first use, as in the reference
         self.disp_models = [dispersion.load_dispersion_model(r["dm_file"]) for r in rows]
         self.betas = np.array([[r["beta_a"], r["beta_b"]] for r in rows], dtype=np.float64)
 
     def _open_tabix_files(self):
         self.tabix_files = [TabixFile(r["tabix_file"]) for r in self.samples_data]
 
-    def _load_data(self, interval):
-        """post.py:57-87"""
-        n, m = len(self.tabix_files), len(interval)
-        obs, exp = np.zeros((n, m)), np.zeros((n, m))
-        fdr, w = np.ones((n, m)), np.zeros((n, m))
+    def load_batch(self, intervals):
+        """The (datasets, bases) arrays obs, exp, fdr, w of cli/post.py:57-87 for `intervals` back
+        to back, and the offsets of the intervals in them."""
+        if len(self.tabix_files) == 0:
+            self._open_tabix_files()
+        off = np.concatenate([[0], np.cumsum([len(iv) for iv in intervals])]).astype(np.int64)
+        n, total = len(self.tabix_files), int(off[-1])
+        obs, exp = np.zeros((n, total)), np.zeros((n, total))
+        fdr, w = np.ones((n, total)), np.zeros((n, total))
         for i, tbf in enumerate(self.tabix_files):
-            try:
-                pos, vals = tbf.fetch_columns(interval.chrom, interval.start, interval.end)
-                j = pos - interval.start
-                exp[i, j] = vals[:, 2]   # file column 3
-                obs[i, j] = vals[:, 3]   # 4
-                fdr[i, j] = vals[:, 6]   # 7
-                w[i, j] = 1.0
-            except Exception:  # the reference logs and carries on with what it has (post.py:84-85)
-                pass
-        return obs, exp, fdr, w
+            for iv, a in zip(intervals, off[:-1]):
+                try:
+                    pos, vals = tbf.fetch_columns(iv.chrom, iv.start, iv.end)
+                except Exception:  # the reference logs and carries on with what it has (post.py:84-85)
+                    continue
+                if pos.size == 0:
+                    continue
+                j = a + (pos - iv.start)
+                exp[i, j], obs[i, j], fdr[i, j], w[i, j] = vals[:, 2], vals[:, 3], vals[:, 6], 1.0
+        return obs, exp, fdr, w, off
+
+    def _load_data(self, interval):
+        """post.py:57-87 for one interval"""
+        return self.load_batch([interval])[:4]
 
     def cleanup(self):
         for tbf in self.tabix_files:
@@ -66,16 +77,13 @@ class posterior_stats(object):
     def __len__(self):
         return len(self.intervals)
 
+    def batch(self, indices):
+        """Records of many intervals from one launch (the order of `indices`)."""
+        ivs = [self.intervals[i] for i in indices]
+        obs, exp, fdr, w, off = self.load_batch(ivs)
+        stats = posterior.posterior_batch(obs, exp, fdr, w, self.betas, self.disp_models, fdr_cutoff=self.fdr_cutoff,
+                                          half_win_width=3, interval_off=off, ctx=self.ctx)
+        return [{"interval": iv, "stats": stats[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])]
+
     def __getitem__(self, index):
-        """post.py:98-124"""
-        if len(self.tabix_files) == 0:
-            self._open_tabix_files()
-        interval = self.intervals[index]
-        obs, exp, fdr, w = self._load_data(interval)
-        prior = posterior.compute_prior_weighted(fdr, w, cutoff=self.fdr_cutoff)
-        delta = posterior.compute_delta_prior(obs, exp, fdr, self.betas, cutoff=self.fdr_cutoff)
-        ll_on = posterior.log_likelihood(obs, exp, self.disp_models, delta=delta, w=3)
-        ll_off = posterior.log_likelihood(obs, exp, self.disp_models, w=3)
-        post = -posterior.posterior(prior, ll_on, ll_off)
-        post[post <= 0] = 0.0
-        return {"interval": interval, "stats": post.T}
+        return self.batch([index])[0]

@@ -1,9 +1,14 @@
 """Posterior footprint probabilities: the call surface of footprint_tools/stats/posterior.py
-(v1.3.7).  The windowed negative-binomial log-likelihoods run on the GPU (log-pmf kernel +
-window-sum kernel); the two prior builders are small numpy reductions over datasets, as in the
-reference."""
+(v1.3.7) -- the four functions, one reference call each (the windowed negative-binomial
+log-likelihoods on the GPU, the two prior builders as numpy reductions over datasets) -- and the
+batched form the drivers use: `posterior_batch` / `posterior_dev` run the whole sequence of
+cli/post.py:98-124 for every interval and dataset of a batch in ONE kernel (fpt_posterior_dev of
+include/fpt.h)."""
+import ctypes as C
+
 import numpy as np
 
+from .. import _lib
 from . import windowing
 
 
@@ -60,3 +65,87 @@ def posterior(prior, ll_on, ll_off):
         occupied = np.log(1 - prior) + ll_on
         unoccupied = np.log(prior) + ll_off
         return unoccupied - np.logaddexp(occupied, unoccupied)
+
+
+# ---- the batched form: cli/post.py:98-124 for a whole batch in one launch ----------------------
+def posterior_dev(ctx, n_intervals, total_bases, n_datasets, dm_slot, betas, obs, exp, fdr, w, post_out,
+                  interval_len=None, interval_off_dev=None, max_interval_len=0, fdr_cutoff=0.05,
+                  half_win_width=3, pseudocount=0.5, prior_out=None, delta_out=None, ll_on_out=None,
+                  ll_off_out=None, status_out=None):
+    """Enqueue fpt_posterior_dev on device pointers (ints); does not synchronise.  Tracks are
+    (n_datasets, total_bases) row-major, post_out (total_bases, n_datasets); dataset d uses
+    dispersion slot dm_slot + d and betas[d]."""
+    d = _lib.PosteriorDesc()
+    d.n_intervals, d.interval_len, d.interval_off = int(n_intervals), int(interval_len or 0), interval_off_dev
+    d.total_bases, d.max_interval_len = int(total_bases), int(max_interval_len)
+    d.n_datasets, d.dm_id, d.half_win_width = int(n_datasets), int(dm_slot), int(half_win_width)
+    d.fdr_cutoff, d.pseudocount = float(fdr_cutoff), float(pseudocount)
+    keep = _lib.f64(betas).reshape(int(n_datasets), 2)
+    d.betas = keep.ctypes.data
+    d.obs, d.exp, d.fdr, d.w, d.post_out = obs, exp, fdr, w, post_out
+    d.prior_out, d.delta_out, d.ll_on_out, d.ll_off_out, d.status_out = prior_out, delta_out, ll_on_out, ll_off_out, status_out
+    _lib.check(ctx.L.fpt_posterior_dev(ctx.h, C.byref(d)))
+
+
+def posterior_batch(obs, exp, fdr, w, betas, dm, fdr_cutoff=0.05, half_win_width=3, interval_off=None,
+                    pieces=False, ctx=None):
+    """-log P(unoccupied | data), clipped at 0, for every base and dataset of a batch.
+
+    obs, exp, fdr, w : (datasets, bases) host arrays -- what cli/post.py's `_load_data` builds for
+    one interval, for many intervals back to back (`interval_off`: their offsets; None = the
+    arrays are one interval).  betas: (datasets, 2); dm: one dispersion model per dataset.
+    Returns the (bases, datasets) array whose slice per interval is the reference's `stats`
+    record; with pieces=True also a dict of prior, delta, ll_on, ll_off as the reference's
+    functions return them.  Raises ZeroDivisionError where dm.log_pmf_values would."""
+    from ..scan import DeviceArray
+    ctx = ctx or _lib.get_ctx()
+    obs, exp, fdr, w = (_lib.f64(a) for a in (obs, exp, fdr, w))
+    if obs.ndim != 2 or exp.shape != obs.shape or fdr.shape != obs.shape or w.shape != obs.shape:
+        raise ValueError("obs, exp, fdr and w must be (datasets, bases) arrays of one shape")
+    D, total = obs.shape
+    models = list(dm)[:D]
+    if len(models) != D:
+        raise ValueError("one dispersion model per dataset")
+    if interval_off is None:
+        off = np.array([0, total], dtype=np.int64)
+    else:
+        off = np.ascontiguousarray(interval_off, dtype=np.int64)
+        if off[0] != 0 or off[-1] != total or np.any(np.diff(off) < 0):
+            raise ValueError("interval_off does not partition the tracks")
+    n_iv = off.size - 1
+    if total == 0:
+        empty = np.zeros((0, D))
+        return (empty, dict(prior=np.zeros((D, 0)), delta=np.zeros(0), ll_on=np.zeros((D, 0)), ll_off=np.zeros((D, 0)))) if pieces else empty
+    slot = (ctx.dispersion_slot(models[0].mu_params, models[0].r_params) if D == 1
+            else ctx.dispersion_slots([(m.mu_params, m.r_params) for m in models]))
+    bufs = []
+    try:
+        def dev(a):
+            b = DeviceArray(ctx, max(a.nbytes, 16)).upload(a)
+            bufs.append(b)
+            return b
+        d_in = dev(np.concatenate([obs.ravel(), exp.ravel(), fdr.ravel(), w.ravel()]))
+        d_off = dev(off)
+        d_st = dev(np.zeros(max(n_iv, 1), np.int32))
+        n = D * total
+        d_out = DeviceArray(ctx, (n * (4 if pieces else 1) + (total if pieces else 0)) * 8)
+        bufs.append(d_out)
+        base = d_out.ptr
+        posterior_dev(ctx, n_iv, total, D, slot, betas, d_in.ptr, d_in.ptr + n * 8, d_in.ptr + 2 * n * 8,
+                      d_in.ptr + 3 * n * 8, base, interval_off_dev=d_off.ptr,
+                      max_interval_len=int(np.diff(off).max()), fdr_cutoff=fdr_cutoff,
+                      half_win_width=half_win_width, status_out=d_st.ptr,
+                      prior_out=base + n * 8 if pieces else None, ll_on_out=base + 2 * n * 8 if pieces else None,
+                      ll_off_out=base + 3 * n * 8 if pieces else None, delta_out=base + 4 * n * 8 if pieces else None)
+        ctx.synchronize()
+        if d_st.download(np.int32, n_iv).any():
+            raise ZeroDivisionError("float division")  # dispersion.pyx:160-161 through log_pmf_values
+        post = d_out.download(np.float64, n).reshape(total, D)
+        if not pieces:
+            return post
+        rest = d_out.download(np.float64, 3 * n + total, n * 8)
+        return post, dict(prior=rest[:n].reshape(D, total), ll_on=rest[n:2 * n].reshape(D, total),
+                          ll_off=rest[2 * n:3 * n].reshape(D, total), delta=rest[3 * n:])
+    finally:
+        for b in bufs:
+            b.free()

@@ -232,6 +232,45 @@ typedef struct fpt_fdr_desc {
  * same kernel over buffers in global memory, which is slower per base. */
 int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
 
+/* ---- the multi-dataset posterior caller (BASELINE config 5; SURVEY.md 8a row A11 + 8f row 4).
+ * One call = cli/post.py:98-124 (`posterior_stats.__getitem__`) for a whole batch of intervals
+ * and all datasets:
+ *     prior  = posterior.compute_prior_weighted(fdr, w, cutoff)           stats/posterior.py:12-42
+ *     delta  = posterior.compute_delta_prior(obs, exp, fdr, betas, cutoff) stats/posterior.py:45-90
+ *     ll_on  = posterior.log_likelihood(obs, exp, dms, delta=delta, w=hw)  stats/posterior.py:93-121
+ *     ll_off = posterior.log_likelihood(obs, exp, dms, w=hw)               (dm.log_pmf_values ->
+ *              nbinom.logpmf, dispersion.pyx:170-226, nbinom.pyx:82-100; windowing.sum, edges 1.0)
+ *     post   = -posterior.posterior(prior, ll_on, ll_off); post[post <= 0] = 0
+ *                                                  stats/posterior.py:124-149, cli/post.py:121-122
+ * Tracks are DEVICE arrays of shape (n_datasets, sum(L)), row-major: row d is dataset d's track
+ * over the batch's intervals back to back -- the reference's (n, m) arrays of `_load_data`
+ * (cli/post.py:57-87: exp = file column 3, obs = 4, fdr = 7, w = 1 where the dataset has a row;
+ * defaults 0 / 0 / 1 / 0) concatenated over intervals.  Dataset d uses dispersion slot dm_id + d
+ * and the Beta prior betas[d] (sample file columns beta_a, beta_b).  post_out is
+ * (sum(L), n_datasets) row-major: the slice of an interval is the reference's `stats` (= post.T).
+ * status_out[i] = 1 where a dispersion fit of interval i divides by zero (dm.log_pmf_values raises
+ * ZeroDivisionError there).  Enqueued on the context's stream; no synchronisation. */
+typedef struct fpt_posterior_desc {
+    int64_t n_intervals;
+    int32_t interval_len;             /* uniform batches (interval_off == NULL) */
+    const int64_t *interval_off;      /* ragged: DEVICE offsets into the tracks (n_intervals+1) */
+    int64_t total_bases;              /* sum(L): the row length of the tracks */
+    int32_t max_interval_len;         /* ragged: the longest interval (a sizing hint; 0 = unknown) */
+    int32_t n_datasets;               /* 1 .. FPT_MAX_DISPERSION_MODELS */
+    int32_t dm_id;                    /* model slot of dataset 0; dataset d uses dm_id + d */
+    int32_t half_win_width;           /* likelihood window (cli/post.py: 3), <= 32 */
+    double fdr_cutoff;                /* cli/post.py --fdr_cutoff (0.05) */
+    double pseudocount;               /* compute_prior_weighted's default 0.5 */
+    const double *betas;              /* HOST: n_datasets x 2 (beta_a, beta_b) */
+    const double *obs, *exp, *fdr, *w;/* DEVICE tracks */
+    double *post_out;                 /* DEVICE (sum(L), n_datasets) */
+    double *prior_out;                /* optional DEVICE (n_datasets, sum(L)) */
+    double *delta_out;                /* optional DEVICE (sum(L)) */
+    double *ll_on_out, *ll_off_out;   /* optional DEVICE (n_datasets, sum(L)) */
+    int32_t *status_out;              /* optional DEVICE int32[n_intervals], zeroed by the caller */
+} fpt_posterior_desc;
+int fpt_posterior_dev(fpt_ctx *ctx, const fpt_posterior_desc *desc);
+
 /* (exp, obs) histogram of `ftd learn_dm` (cli/learn_dm.py:276-287): hist[int(exp), int(obs)] += 1
  * for the n pairs of two DEVICE tracks, pairs outside the rows x cols histogram (the reference
  * uses 200 x 1000) ignored like its IndexError branch; negative or non-finite values are

@@ -225,6 +225,53 @@ def log_likelihood_row(mu_par, r_par, obs, exp, delta, w):
     return out
 
 
+def posterior_stats(obs, exp, fdr, w, betas, models, cutoff=0.05, hw=3, pseudocount=0.5):
+    """cli/post.py:109-122 for one interval: the reference's own sequence of numpy operations
+    (stats/posterior.py:12-149) with its scipy call written out -- scipy.stats.beta.stats(a, b,
+    moments="mv") is a/(a+b), ab/((a+b)^2 (a+b+1)), NaN outside a, b > 0 -- and its
+    dm.log_pmf_values / windowing.sum through the C restatement.  models: (mu_par, r_par) per
+    dataset.  Returns stats (bases x datasets) and the pieces (prior, delta, ll_on, ll_off)."""
+    obs, exp, fdr, w = (np.asarray(a, dtype=np.float64) for a in (obs, exp, fdr, w))
+    betas = np.asarray(betas, dtype=np.float64)
+    n, m = obs.shape
+    with np.errstate(all="ignore"):
+        # posterior.py:31-42
+        k = np.sum(fdr <= cutoff, axis=0)
+        nn = np.sum(w, axis=0)
+        a = nn - k + pseudocount
+        b = k + pseudocount
+        pr = a / (a + b)
+        prior = np.ones(fdr.shape)
+        prior *= pr[np.newaxis, :]
+        prior[w == 0] = 1
+        # posterior.py:66-90
+        mus, ws = np.ones((n, m)), np.ones((n, m))
+        for i in range(n):
+            kk = obs[i, :]
+            trials = np.max(np.vstack([exp[i, :], obs[i, :]]), axis=0)
+            al, be = kk + betas[i][0], trials - kk + betas[i][1]
+            s = al + be
+            ok = (al > 0) & (be > 0)
+            mu = np.where(ok, al / s, np.nan)
+            v = np.where(ok, al * be / (s ** 2 * (s + 1)), np.nan)
+            mus[i, :] = mu
+            ws[i, :] = 1 / np.sqrt(v)
+        ws[fdr > cutoff] = 0
+        delta = np.sum(ws * mus, axis=0) / np.sum(ws, axis=0)
+        delta[np.isnan(delta)] = 1
+        # posterior.py:114-121
+        ll_on, ll_off = np.ones((n, m)), np.ones((n, m))
+        for i in range(n):
+            ll_on[i, :] = log_likelihood_row(models[i][0], models[i][1], obs[i], exp[i], delta, hw)
+            ll_off[i, :] = log_likelihood_row(models[i][0], models[i][1], obs[i], exp[i], 1.0, hw)
+        # posterior.py:140-149, post.py:121-122
+        p_off = np.log(prior) + ll_off
+        p_on = np.log(1 - prior) + ll_on
+        post = -(p_off - np.logaddexp(p_on, p_off))
+        post[post <= 0] = 0.0
+    return post.T, dict(prior=prior, delta=delta, ll_on=ll_on, ll_off=ll_off)
+
+
 def fdr_null(mu_par, r_par, exp, winp, hw, times, seed, base0=0, uniforms=None, table=(256, 256),
              return_null=False):
     """One interval of the reproducible empirical-FDR pass (see fpt_fdr_dev in include/fpt.h)."""

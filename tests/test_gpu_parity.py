@@ -795,6 +795,101 @@ def test_posterior_log_likelihood(fpt):
     assert np.allclose(post, g["post"], rtol=1e-6, atol=1e-9, equal_nan=True)
 
 
+def test_posterior_batch_golden(fpt):
+    """fpt_posterior_dev (one launch: priors, both likelihoods, log-sum-exp, clamp) against what the
+    reference's four functions returned for the same arrays (posterior.npz)."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    g = golden("posterior.npz")
+    lat = golden("nb_lattice.npz")
+    dms = []
+    for key in g["dm_keys"]:
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + str(key)], lat["r_" + str(key)]
+        dms.append(dm)
+    stats, pc = posterior.posterior_batch(g["obs"], g["exp"], g["fdr"], g["w"], g["betas"], dms, fdr_cutoff=0.05,
+                                          pieces=True)
+    assert np.array_equal(pc["prior"], g["prior"])
+    assert rel_err(pc["delta"], g["delta"]) < 1e-12
+    assert rel_err(pc["ll_on"], g["ll_on"]) < P_TOL and rel_err(pc["ll_off"], g["ll_off"]) < P_TOL
+    want = -g["post"]
+    want[want <= 0] = 0.0
+    assert np.allclose(stats, want.T, rtol=1e-6, atol=1e-9, equal_nan=True)
+    assert (stats > 1).any()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "10"))))
+def test_posterior_batch_fuzz(fpt, orc, seed):
+    """random numbers of datasets, ragged intervals (shorter than the window, one base, several
+    tiles, longer than eight tiles), window widths, Beta priors (also outside scipy's domain), gaps
+    in the tracks (w = 0), NaN fdr, counts beyond exp -- against the checker's restatement of
+    cli/post.py:109-122, interval by interval."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    rs = np.random.RandomState(4200 + seed)
+    lat = golden("nb_lattice.npz")
+    D = int(rs.choice([1, 2, 3, 8, 8, 11]))
+    hw = int(rs.choice([0, 1, 3, 3, 3, 7]))
+    n_iv = int(rs.randint(1, 9))
+    lens = rs.choice([1, 2, 6, 7, 8, 100, 122, 123, 250, 251, 500, 1000, 2300], n_iv)
+    if seed % 4 == 0:
+        lens[0] = 2600  # more than eight 250-base tiles: spread over gridDim.y
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(off[-1])
+    keys = [str(rs.choice(["A", "B", "C"])) for _ in range(D)]
+    dms = []
+    for key in keys:
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + key], lat["r_" + key]
+        dms.append(dm)
+    exp = np.round(rs.gamma(2.0, float(rs.choice([1.0, 6.0, 40.0])), (D, total)))
+    obs = np.floor(exp * rs.uniform(0.0, 1.6, (D, total)))
+    fdr = rs.uniform(0, 1, (D, total)) ** float(rs.choice([1, 4, 9]))
+    w = (rs.uniform(0, 1, (D, total)) < 0.85).astype(float)
+    obs[w == 0], exp[w == 0], fdr[w == 0] = 0.0, 0.0, 1.0   # what _load_data leaves where a track has no row
+    if seed % 3 == 0:
+        fdr[rs.randint(0, D), rs.randint(0, total, 3)] = np.nan
+    betas = rs.uniform(0.5, 30.0, (D, 2))
+    if seed % 5 == 1:
+        betas[0, 0] = -1.0  # outside the Beta domain for k = 0: scipy's stats are NaN there
+    stats, pc = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
+                                          interval_off=off, pieces=True)
+    assert stats.shape == (total, D)
+    models = [(lat["mu_" + k], lat["r_" + k]) for k in keys]
+    tag = (seed, D, hw, lens.tolist())
+    for a, b in zip(off[:-1], off[1:]):
+        want, wp = orc.posterior_stats(obs[:, a:b], exp[:, a:b], fdr[:, a:b], w[:, a:b], betas, models, cutoff=0.05, hw=hw)
+        assert np.array_equal(pc["prior"][:, a:b], wp["prior"]), tag
+        assert rel_err(pc["delta"][a:b], wp["delta"]) < 1e-12, tag
+        assert rel_err(pc["ll_on"][:, a:b], wp["ll_on"]) < P_TOL and rel_err(pc["ll_off"][:, a:b], wp["ll_off"]) < P_TOL, tag
+        assert np.allclose(stats[a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True), tag
+    # without the optional outputs the records are the same bits
+    assert np.array_equal(posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
+                                                    interval_off=off), stats, equal_nan=True)
+
+
+def test_posterior_batch_zero_division(fpt):
+    """dm.log_pmf_values raises ZeroDivisionError where the 1/r fit is exactly 0 (dispersion.pyx:160-161);
+    so does the batched call, whichever dataset and likelihood hits it."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    lat = golden("nb_lattice.npz")
+    ok = dispersion.dispersion_model()
+    ok.mu_params, ok.r_params = lat["mu_A"], lat["r_A"]
+    zd = dispersion.dispersion_model()
+    zd.mu_params = lat["mu_A"]
+    r = np.array(lat["r_A"], dtype=np.float64)
+    r[5], r[10] = -0.5, 0.25  # first segment: -0.5 + 0.25 x = 0 at x = 2
+    zd.r_params = r
+    obs, exp = np.full((2, 40), 3.0), np.full((2, 40), 5.0)
+    fdr, w = np.full((2, 40), 0.5), np.ones((2, 40))
+    betas = np.array([[2.0, 5.0], [2.0, 5.0]])
+    posterior.posterior_batch(obs, exp, fdr, w, betas, [ok, zd])  # x = 5: no division by zero
+    exp[1, 17] = 2.0
+    with pytest.raises(ZeroDivisionError):
+        posterior.posterior_batch(obs, exp, fdr, w, betas, [ok, zd])
+
+
 # ---------------------------------------------------------------- A10: empirical FDR on the device
 def _scan_small(orc, n_iv, L, seed, dm="A", bump=None):
     from footprint_tools_amd.scan import FootprintScanner
@@ -1321,8 +1416,15 @@ def test_posterior_driver_from_tracks(fpt, tmp_path):
     want = -posterior.posterior(prior, posterior.log_likelihood(obs, exp, ps.disp_models, delta=delta, w=3),
                                 posterior.log_likelihood(obs, exp, ps.disp_models, w=3))
     want[want <= 0] = 0.0
-    assert np.array_equal(rec["stats"], want.T, equal_nan=True)
+    assert np.allclose(rec["stats"], want.T, rtol=1e-9, atol=1e-12, equal_nan=True)
     assert (rec["stats"][10:310] > 0).any()
+    # many intervals from one launch = the same records one by one
+    ps2 = posterior_stats([("chr7", 1990, 2310), ("chr7", 2100, 2101), ("chr7", 2250, 2400), ("chrQ", 5, 50)], rows, fdr_cutoff=0.05)
+    recs = ps2.batch([0, 1, 2, 3])
+    assert np.array_equal(recs[0]["stats"], rec["stats"], equal_nan=True)
+    for i in (1, 2, 3):
+        assert np.array_equal(recs[i]["stats"], ps2[i]["stats"], equal_nan=True)
+    assert recs[3]["stats"].shape == (45, 2) and not recs[3]["stats"].any()
 
 
 def test_posterior_driver_against_the_reference_driver(fpt, tmp_path):

@@ -180,6 +180,22 @@ def test_log_likelihood_golden(orc):
         assert same(on, g["ll_on"][i]) and same(off, g["ll_off"][i])
 
 
+def test_posterior_sequence_golden(orc):
+    """the checker's restatement of cli/post.py:109-122 (priors, likelihoods, log-sum-exp, clamp)
+    against what the reference's functions returned (posterior.npz) and what its driver class
+    returned for whole track files (post_driver.npz)."""
+    g = golden("posterior.npz")
+    lat = golden("nb_lattice.npz")
+    models = [(lat["mu_" + str(k)], lat["r_" + str(k)]) for k in g["dm_keys"]]
+    stats, pc = orc.posterior_stats(g["obs"], g["exp"], g["fdr"], g["w"], g["betas"], models, cutoff=0.05)
+    assert same(pc["prior"], g["prior"])
+    assert np.allclose(pc["delta"], g["delta"], rtol=1e-13, atol=0)
+    assert np.allclose(pc["ll_on"], g["ll_on"], rtol=1e-12, atol=0) and same(pc["ll_off"], g["ll_off"])
+    want = -g["post"]
+    want[want <= 0] = 0.0
+    assert np.allclose(stats, want.T, rtol=1e-9, atol=1e-12, equal_nan=True)
+
+
 # ---------------------------------------------------------------- whole path, BASELINE config 1
 def test_e2e_config1_golden(orc):
     g = golden("e2e_cfg1.npz")
