@@ -41,7 +41,9 @@ CONFIGS = {
     "4": dict(name="437500xragged171bp_1scale", n_iv=437500, L=0, scales=(3,)),
     # BASELINE.json configs[4]: the same set through the full `detect` statistics -- per-interval NB
     # dispersion models (4 models, chosen per interval) + empirical FDR with 100 null draws per base
-    "5": dict(name="437500xragged171bp_4models_fdr100", n_iv=437500, L=0, scales=(3,), fdr_times=100, n_models=4),
+    # -- and, beside the headline, the posterior caller over 8 datasets of that shape (one launch)
+    "5": dict(name="437500xragged171bp_4models_fdr100", n_iv=437500, L=0, scales=(3,), fdr_times=100, n_models=4,
+              posterior_datasets=8),
     # small shapes for quick checks
     "1": dict(name="1000x500bp_5scales", n_iv=1000, L=500, scales=(3, 5, 10, 20, 40)),
 }
@@ -134,6 +136,7 @@ def main():
     ap.add_argument("--no-heavy", action="store_true",
                     help="N=1: skip the extra heavy-tailed measurement (20 per mille hotspots) reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-posterior", action="store_true", help="config 5: skip the posterior-caller leg")
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
     ap.add_argument("--allgather", action="store_true",
@@ -383,6 +386,67 @@ def main():
                      note="observed counts up to ~1000 in the hotspots; the redo pass reads a second-level "
                           "(exp, obs) table sized on the device by the largest pair the first pass missed")
 
+    # ---- config 5, second half: the posterior footprint caller (cli/post.py:98-124) over D datasets
+    #      of this rank's interval set, as ONE launch of fpt_posterior_dev.  Each dataset's tracks
+    #      (exp, obs, empirical FDR) come from a scan + FDR pass over its own synthetic cut counts
+    #      (seed 1 + d), made once outside the timed region; the launch is then timed K times.
+    post = None
+    D = cfg.get("posterior_datasets", 0)
+    if D and fdr_times and not args.no_posterior:
+        from footprint_tools_amd.stats import posterior as post_mod
+        d_tracks = DeviceArray(ctx, 4 * D * total * 8)   # obs, exp, fdr, w: (D, total) each
+        d_post = DeviceArray(ctx, D * total * 8)
+        d_st = DeviceArray(ctx, max(n_iv, 1) * 4).zero()
+        row = total * 8
+        p_obs, p_exp, p_fdr, p_w = (d_tracks.ptr + k * D * row for k in range(4))
+        ones = np.ones(total)
+        for d_ in range(D):
+            _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1 + d_, pos0_counts, n_counts, p_cp, p_cm, pos0_seq, n_seq, p_sq))
+            sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_exp + d_ * row, obs_out=p_obs + d_ * row, pval_out=p_p,
+                        winp_out=p_out + 2 * t8, interval_off_dev=d_off.ptr, interval_off_host=off,
+                        dm_ids_dev=d_dm.ptr if d_dm else None)
+            sc.fdr_dev(n_iv, p_exp + d_ * row, p_out + 2 * t8, p_fdr + d_ * row, times=fdr_times, seed=1 + d_,
+                       half_win_width=scales[0], interval_off_dev=d_off.ptr, base_index0=bases_before,
+                       dm_ids_dev=d_dm.ptr if d_dm else None)
+            _lib.check(ctx.L.fpt_memcpy_h2d(ctx.h, p_w + d_ * row, ones.ctypes.data, ones.nbytes))
+        ctx.synchronize()
+        # dataset d is scored with model d % n_models (the reference has one model per dataset)
+        ds_models = [models[d_ % n_models] for d_ in range(D)] if n_models > 1 else [DM] * D
+        slot = ctx.dispersion_slots([(m.mu_params, m.r_params) for m in ds_models])
+        betas = np.array([[2.0 + 0.5 * d_, 8.0 - 0.5 * d_] for d_ in range(D)])
+
+        def post_step():
+            post_mod.posterior_dev(ctx, n_iv, total, D, slot, betas, p_obs, p_exp, p_fdr, p_w, d_post.ptr,
+                                   interval_off_dev=d_off.ptr, max_interval_len=int(lens.max()), fdr_cutoff=0.05,
+                                   half_win_width=3, status_out=d_st.ptr)
+        post_step()
+        ctx.synchronize()
+        kp = max(3, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(kp):
+            post_step()
+        ctx.synchronize()
+        dtp = (time.perf_counter() - t0) / kp
+        if comm is not None:
+            dtp = comm.max_over_ranks(dtp)
+        post = dict(n_datasets=D, launches=kp, ms_per_launch=dtp * 1e3, value=total_all / dtp, unit="bases/s",
+                    dataset_bases_per_s=total_all * D / dtp,
+                    bound="fp64 vector ALU: 5 lgam + 2 log + 2 log1p + exp + log1p per dataset-base, 40 B of HBM "
+                          "traffic per dataset-base (DESIGN.md, posterior kernel)",
+                    hbm_GBps=total * D * 40.0 / dtp / 1e9)
+        if rank == 0:  # one interval against the checker's restatement of cli/post.py:109-122
+            from oracle import oracle
+            iv = n_iv - 1
+            a, b = int(off[iv]), int(off[iv + 1])
+            host = [np.stack([d_tracks.download(np.float64, b - a, (k * D + d_) * row + a * 8) for d_ in range(D)])
+                    for k in range(4)]
+            want = oracle.posterior_stats(host[0], host[1], host[2], host[3], betas,
+                                          [(m.mu_params, m.r_params) for m in ds_models], cutoff=0.05, hw=3)[0]
+            got = d_post.download(np.float64, (b - a) * D, a * D * 8).reshape(b - a, D)
+            post["parity_max_abs_err"] = float(np.nanmax(np.abs(got - want)))
+            post["parity_ok"] = bool(np.allclose(got, want, rtol=1e-6, atol=1e-9, equal_nan=True))
+            post["zero_division_flags"] = int(d_st.download(np.int32, n_iv).any())
+
     if rank == 0:
         rd, wr = algorithmic_bytes_per_base(L if not ragged else total / n_iv, S)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None
@@ -450,6 +514,7 @@ def main():
             "other_nb_mode": other,
             "memo_robustness": robust,
             "heavy_tailed": heavy,
+            "posterior": post,
             "parity": parity,
         }
         print(json.dumps(out), flush=True)
