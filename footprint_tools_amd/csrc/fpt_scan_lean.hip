@@ -180,24 +180,27 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
 template <int NT>
 struct lean_lds {
     static constexpr int NCR = NT + 128;
+    static constexpr int NROW = NT / 16;
     // doubles
     static constexpr int oPP = 0;                  // P+[v]
     static constexpr int oPM = oPP + NCR;          // P-[v-1] (slot 0 is a dummy)
-    static constexpr int oZB = oPM + NCR + 2;      // row prefix sums of z (see Z / C in the kernel)
-    static constexpr int oRT = oZB + NT + 48;      // row totals (64), then row carries (64 + 4)
-    static constexpr int nDoubles = oRT + 64 + 68;
+    static constexpr int oRT = oPM + NCR + 2;      // row totals (NROW), then row carries (NROW + 4)
+    static constexpr int nDoubles = oRT + 2 * NROW + 4;
     // 32-bit words, after the doubles
     static constexpr int oB0 = 0;                  // sequence bit planes
     static constexpr int oB1 = oB0 + NCR / 32 + 4;
     static constexpr int oPK = oB1 + NCR / 32 + 4; // packed counts with 8 zero words either side
-    static constexpr int oWP = oPK + NCR + 16;     // packed 2*hw window sums
-    static constexpr int oSP = oWP + NCR;          // tile prefix sums of W+, W-
+    static constexpr int oSP = oPK + NCR + 16;     // tile prefix sums of W+, W-
     static constexpr int oSM = oSP + NCR;
     static constexpr int oXP = oSM + NCR;          // W+: (0xffff - prefix min) | prefix max << 16
     static constexpr int oXPs = oXP + NCR;         //     same for the suffixes
     static constexpr int oXM = oXPs + NCR;
     static constexpr int oXMs = oXM + NCR;
     static constexpr int nWords = oXMs + NCR;
+    // the prefix sums of z (phase E, NT + 48 doubles) take the place of the six scan arrays, which
+    // nobody reads after phase D: 6 * NCR words >= 2 * (NT + 48)
+    static constexpr int oZB = oSP;                // in words; 8-byte aligned: see the static_assert
+    static_assert((oSP % 2) == 0 && 6 * NCR >= 2 * (NT + 48), "z prefix must fit the scan arrays, aligned");
     static constexpr size_t bytes = (size_t)nDoubles * 8 + (size_t)nWords * 4;
 };
 
@@ -330,12 +333,13 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
 template <int NT>
 struct lean_mem {
     double *PP, *PM, *Z, *rowtot, *C;
-    u32 *bits0, *bits1, *pk, *Wp, *psP, *psM, *xP, *xPs, *xM, *xMs;
+    u32 *bits0, *bits1, *pk, *psP, *psM, *xP, *xPs, *xM, *xMs;
     __device__ __forceinline__ explicit lean_mem(double *smem) {
         typedef lean_lds<NT> LY;
-        PP = smem + LY::oPP, PM = smem + LY::oPM, Z = smem + LY::oZB, rowtot = smem + LY::oRT, C = rowtot + 64;
+        PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW;
         u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
-        bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK, Wp = words + LY::oWP;
+        Z = reinterpret_cast<double *>(words + LY::oZB);
+        bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK;
         psP = words + LY::oSP, psM = words + LY::oSM;
         xP = words + LY::oXP, xPs = words + LY::oXPs, xM = words + LY::oXM, xMs = words + LY::oXMs;
     }
@@ -359,9 +363,8 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         u32 W = pw[0];
 #pragma unroll
         for (int j = 1; j < 2 * kHW; ++j) W += pw[j];
-        m.Wp[v] = W;
         const int vr = v + (kWave - 1) - 2 * lane;  // the tile mirrored: suffix scans are prefix scans of it
-        const u32 Wr = m.Wp[vr];
+        const u32 Wr = (u32)__builtin_amdgcn_ds_bpermute((kWave - 1 - lane) << 2, (int)W);  // W of the mirrored lane
         const u32 wp = W & 0xffffu, wm = W >> 16, rp = Wr & 0xffffu, rm = Wr >> 16;
         m.psP[v] = (u32)wave_scan_i32((int)wp);
         m.psM[v] = (u32)wave_scan_i32((int)wm);
@@ -566,10 +569,6 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
     bool bad = lean_stage<NT>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
     LEAN_TRACE(2);
-    if (tid == 0) {
-        m.Z[15] = 0.0;
-        m.Z[kEdge] = -1e4;
-    }
     __syncthreads();
     LEAN_TRACE(3);
     if (LEAN_STOP(1)) return;
@@ -589,6 +588,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     // ---- E: Stouffer windows (windowing.h:53-84)
     if (a.n_scales == 0 || LEAN_STOP(3)) {
     } else if (a.n_scales == 1 && a.max_scale <= 8) {
+        __syncthreads();  // Z takes the place of the scan arrays: every lane is through phase C
         m.Z[16 + tid] = z;
         __syncthreads();
         bad |= lean_window_narrow<NT>(a, kc, o, tid, m.Z);
@@ -600,7 +600,11 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
         __syncthreads();
         lean_z_carries<NT>(tid, m.rowtot, m.C);
         __syncthreads();
-        lean_z_finish<NT>(zr, tid, m.C, m.Z);
+        lean_z_finish<NT>(zr, tid, m.C, m.Z);  // two barriers behind phase C: the scan arrays are free
+        if (tid == 0) {
+            m.Z[15] = 0.0;
+            m.Z[kEdge] = -1e4;
+        }
         __syncthreads();
         bad |= lean_windows<NT>(a, kc, o, tid, m.Z);
     }
