@@ -10,12 +10,16 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fpt.h"
@@ -95,6 +99,7 @@ int rccl_ready() {
 struct fpt_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
+    bool force_ragged = false;  // FPT_COMM_RAGGED=1, read once when the communicator is made
 };
 
 extern "C" {
@@ -121,11 +126,40 @@ int fpt_comm_init(fpt_ctx *c, const uint8_t id[FPT_COMM_ID_BYTES], int world_siz
     fpt_comm *k = new fpt_comm();
     k->world = world_size;
     k->rank = rank;
-    int r = api().CommInitRank(&k->comm, world_size, uid, rank);
+    // FPT_COMM_RAGGED=1 sends equal shards down the ragged path too (a one-GPU box can then run it)
+    const char *force = getenv("FPT_COMM_RAGGED");
+    k->force_ragged = force && force[0] == '1';
+    // ncclCommInitRank blocks until every rank has called it with the same id and has no timeout
+    // of its own: a missing peer, or one holding another id, would hang the job.  It runs on a
+    // helper thread; if it has not returned after FPT_COMM_TIMEOUT_S seconds (default 300) this
+    // call fails with a message, and the helper is left behind (the process is expected to end).
+    int device = 0;
+    (void)hipGetDevice(&device);
+    double timeout_s = 300.0;
+    if (const char *e = getenv("FPT_COMM_TIMEOUT_S")) timeout_s = atof(e) > 0 ? atof(e) : timeout_s;
+    struct init_state {
+        std::promise<int> done;
+        ncclComm_t comm = nullptr;
+    };
+    auto st = std::make_shared<init_state>();
+    std::future<int> fut = st->done.get_future();
+    std::thread([st, device, world_size, uid, rank]() {
+        (void)hipSetDevice(device);
+        const int r = api().CommInitRank(&st->comm, world_size, uid, rank);
+        st->done.set_value(r);
+    }).detach();
+    if (fut.wait_for(std::chrono::duration<double>(timeout_s)) != std::future_status::ready) {
+        delete k;
+        return fpt_internal_fail(FPT_ERR_HIP,
+                                 "ncclCommInitRank did not return within %.0f s (rank %d of %d): a rank is missing or "
+                                 "holds a different communicator id", timeout_s, rank, world_size);
+    }
+    const int r = fut.get();
     if (r != 0) {
         delete k;
         return fpt_internal_fail(FPT_ERR_HIP, "ncclCommInitRank failed: %s", api().GetErrorString(r));
     }
+    k->comm = st->comm;
     *out = k;
     return FPT_OK;
 }
@@ -148,9 +182,7 @@ int fpt_allgather_track(fpt_ctx *c, fpt_comm *k, const double *send, const int64
     }
     if (!send && counts[k->rank] > 0) return fpt_internal_fail(FPT_ERR_INVALID, "null send buffer");
     hipStream_t st = fpt_internal_stream(c);
-    // FPT_COMM_RAGGED=1 sends equal shards down the ragged path too (a one-GPU box can then run it)
-    const char *force = getenv("FPT_COMM_RAGGED");
-    if (equal && !(force && force[0] == '1')) {
+    if (equal && !k->force_ragged) {
         if (counts[0] == 0) return FPT_OK;
         NCCL_TRY(api().AllGather(send, recv, (size_t)counts[0], kNcclFloat64, k->comm, st));
         return FPT_OK;

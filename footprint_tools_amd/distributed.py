@@ -8,9 +8,11 @@ re-assembled on every rank with ONE collective at the end: an all-gather over RC
 RCCL is bound directly by the library (`fpt_comm_*`, `fpt_allgather_track` in include/fpt.h;
 librccl.so through dlopen) -- no PyTorch, no MPI.  The only thing the host program has to carry
 between the processes is the 128-byte communicator id that rank 0 makes; `TrackComm` does that
-through a file (the ranks of one node share /tmp), keyed by the launcher's MASTER_PORT and the
-parent process id, or by FPT_COMM_FILE.  Barriers and the max-over-ranks of a timing are tiny
-all-gathers on the same communicator.
+through a file (the ranks of one node share /tmp) whose name is unique per job and per
+communicator (launcher port, launcher pid, run id, a per-process counter -- or FPT_COMM_FILE) and
+which only counts while rank 0 keeps touching it, so a leftover of an aborted run is never read
+as the new id.  `ncclCommInitRank` runs under a timeout (FPT_COMM_TIMEOUT_S).  Barriers and the
+max-over-ranks of a timing are tiny all-gathers on the same communicator.
 
 Reference counterpart: cli/detect.py:380-411 -- worker processes (`batch_iter(num_workers=...)`)
 compute per-interval statistics and one writer thread formats them.  `sharded_deviation_stats`
@@ -42,12 +44,94 @@ def rank_info():
     return rank, world, local
 
 
+_comm_counter = [0]  # communicators made by this process so far: part of the rendezvous name
+
+
 def _id_path():
+    """Where rank 0 leaves the communicator id for the other ranks of THIS job and THIS
+    communicator: FPT_COMM_FILE if given (a launcher-supplied unique path), else a name made of
+    the launcher's rendezvous port, the launcher's pid (the parent all ranks share) and the number
+    of communicators this process has made before (every rank makes them in the same order)."""
+    n = _comm_counter[0]
     p = os.environ.get("FPT_COMM_FILE")
     if p:
-        return p
+        return p if n == 0 else "%s.%d" % (p, n)
+    token = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    token = "".join(ch for ch in token if ch.isalnum())[:32]
     return os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                        "fpt_comm_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+                        "fpt_comm_%s_%d_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), token, n))
+
+
+_ID_BYTES = 128
+_FRESH_S = 5.0      # an id file counts only while rank 0 keeps touching it (every _BEAT_S seconds)
+_BEAT_S = 0.25
+
+
+def _read_fresh_id(path):
+    """The id in `path` if the file is a live offer: 128 bytes, owned by this user, and touched
+    within the last _FRESH_S seconds -- rank 0 keeps touching its file until every rank has joined,
+    so the leftover of an aborted run (same shell, same port) is never taken for the new id."""
+    try:
+        st = os.stat(path)
+    except OSError:
+        return None
+    if st.st_size != _ID_BYTES or st.st_uid != os.getuid() or time.time() - st.st_mtime > _FRESH_S:
+        return None
+    try:
+        with open(path, "rb") as f:
+            raw = f.read()
+    except OSError:
+        return None
+    return raw if len(raw) == _ID_BYTES else None
+
+
+class _id_offer(object):
+    """Rank 0's side of the rendezvous: the id file under `path`, kept fresh until withdrawn."""
+
+    def __init__(self, path, ident_bytes):
+        import threading
+        self.path = path
+        # a leftover of another run goes first; the new file is created exclusively (a file
+        # somebody else planted under the temporary name is an error) and appears complete (rename)
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(bytes(ident_bytes))
+        os.replace(tmp, path)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._keep_fresh, daemon=True)
+        self._thread.start()
+
+    def _keep_fresh(self):
+        while not self._stop.wait(_BEAT_S):
+            try:
+                os.utime(self.path)
+            except OSError:
+                return
+
+    def withdraw(self):
+        self._stop.set()
+        self._thread.join()
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+
+
+def _await_id(path, timeout_s):
+    """The other ranks' side: wait for a live offer under `path`."""
+    t0 = time.time()
+    while True:
+        raw = _read_fresh_id(path)
+        if raw is not None:
+            return raw
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("no live communicator id at %s after %.0f s (is rank 0 running?)" % (path, timeout_s))
+        time.sleep(0.01)
 
 
 class TrackComm(object):
@@ -56,6 +140,8 @@ class TrackComm(object):
     ctx   : this rank's _lib.Context (its GPU)
     rank, world : default from the environment (rank_info)
     path  : file through which rank 0 hands the communicator id to the others
+    timeout_s : how long a rank waits for the id, and (through FPT_COMM_TIMEOUT_S, read by the
+                library) how long ncclCommInitRank may take before the call fails instead of hanging
     """
 
     def __init__(self, ctx, rank=None, world=None, path=None, timeout_s=300.0):
@@ -64,26 +150,17 @@ class TrackComm(object):
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
         path = path or _id_path()
-        ident = (C.c_uint8 * 128)()
+        _comm_counter[0] += 1
+        ident = (C.c_uint8 * _ID_BYTES)()
+        offer = None
         if self.rank == 0:
             _lib.check(self.L.fpt_comm_unique_id(ident))
             if self.world > 1:
-                tmp = "%s.%d.tmp" % (path, os.getpid())
-                with open(tmp, "wb") as f:
-                    f.write(bytes(ident))
-                os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
+                offer = _id_offer(path, bytes(ident))
         else:
-            t0 = time.time()
-            while not os.path.exists(path):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError("no communicator id at %s after %.0f s" % (path, timeout_s))
-                time.sleep(0.01)
-            with open(path, "rb") as f:
-                raw = f.read()
-            if len(raw) != 128:
-                raise IOError("communicator id file %s is damaged" % path)
-            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+            ident = (C.c_uint8 * _ID_BYTES).from_buffer_copy(_await_id(path, timeout_s))
         h = C.c_void_p()
+        os.environ.setdefault("FPT_COMM_TIMEOUT_S", "%d" % max(1, int(timeout_s)))
         # RCCL prints a version banner on stdout while rank 0 initialises; programs that print
         # a result on stdout (bench.py: ONE JSON line) get it on stderr instead
         import sys
@@ -96,16 +173,13 @@ class TrackComm(object):
         finally:
             os.dup2(saved, 1)
             os.close(saved)
+            if offer is not None:  # every rank is through init (or it failed): withdraw the offer
+                offer.withdraw()
         _lib.check(rc)
         self.h = h
         self._scratch = DeviceArray(ctx, 8 * (self.world + 1))
         self._path = path
         self.barrier()
-        if self.rank == 0 and self.world > 1:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
 
     def close(self):
         if getattr(self, "h", None):

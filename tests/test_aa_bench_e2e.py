@@ -1,0 +1,51 @@
+"""bench.py end to end as child processes, on the GPU box: the sharded job's path -- shard the
+global interval list, scan, ONE RCCL all-gather of the track (here on a one-rank communicator, with
+the ragged grouped-broadcast form forced) -- for BASELINE configs 4 and 5, and the posterior-caller
+leg of config 5.  The file sorts first on purpose: the children are started before this process
+has touched the GPU (a process that has initialised the GPU must not fork/exec on the GPU pool)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]   # ONE JSON line on stdout (the RCCL banner goes to stderr)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged_form", ["0", "1"])
+def test_bench_config4_allgather_one_rank(ragged_form):
+    d = _bench(["--gpus", "1", "--config", "4", "--intervals", "30000", "--steps", "3", "--warmup", "1", "--allgather",
+                "--no-cpu-baseline", "--no-other-mode"], {"FPT_COMM_RAGGED": ragged_form})
+    assert d["n_gpus"] == 1 and d["config"]["allgather_p_track"] is True
+    mg = d["multi_gpu"]
+    assert mg["allgather_bytes_per_rank"] == 8 * sum(mg["bases_per_rank"]) and mg["allgather_s"] > 0
+    # the spot check reads the GATHERED track: it holds this rank's p-values, equal to the oracle's
+    p = d["parity"]
+    assert p["exp_bit_exact"] is True and p["p_max_rel_err"] < 1e-6 and p["winp_max_rel_err"] < 1e-6
+    assert d["roofline"]["kernel_ms"] > 0 and d["value"] > 1e9
+
+
+@pytest.mark.gpu
+def test_bench_config5_allgather_and_posterior_one_rank():
+    d = _bench(["--gpus", "1", "--config", "5", "--intervals", "8000", "--steps", "2", "--warmup", "1", "--allgather",
+                "--no-cpu-baseline", "--no-other-mode"], {"FPT_COMM_RAGGED": "1"})
+    p = d["parity"]
+    assert p["exp_bit_exact"] is True and p["p_max_rel_err"] < 1e-6
+    assert p["efdr_max_abs_err"] <= 2.5 / (50 * 100)   # the gathered FDR track against the oracle's sampler
+    assert d["config"]["empirical_fdr_null_draws_per_base"] == 100
+    post = d["posterior"]
+    assert post["n_datasets"] == 8 and post["parity_ok"] is True and post["zero_division_flags"] == 0
+    assert post["value"] > 1e7

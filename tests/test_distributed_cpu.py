@@ -111,3 +111,42 @@ def test_shard_and_allgather_two_ranks_gloo(tmp_path, mode):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "OK " + mode in out.stdout
+
+
+def test_id_rendezvous_ignores_leftovers(tmp_path):
+    """The file rendezvous of TrackComm (rank 0 offers the 128-byte communicator id, the others wait
+    for it): a leftover of an aborted run under the same name is never taken for the id -- an
+    offer only counts while rank 0 keeps touching it -- wrong sizes are ignored, a withdrawn offer
+    is gone, and successive communicators of one process use different names."""
+    import threading
+    import time
+    from footprint_tools_amd import distributed as D
+    path = str(tmp_path / "fpt_comm.id")
+    old, new = bytes(range(128)), bytes(reversed(range(128)))
+    with open(path, "wb") as f:           # what an aborted run left behind
+        f.write(old)
+    os.utime(path, (time.time() - 60, time.time() - 60))
+    assert D._read_fresh_id(path) is None
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("id", D._await_id(path, 20.0)))
+    t.start()
+    time.sleep(0.3)
+    assert "id" not in got                 # still waiting: the stale file does not count
+    offer = D._id_offer(path, new)
+    t.join(10)
+    assert got.get("id") == new
+    time.sleep(3 * D._BEAT_S)              # the offer stays fresh while it stands
+    assert D._read_fresh_id(path) == new
+    offer.withdraw()
+    assert not os.path.exists(path) and D._read_fresh_id(path) is None
+    with open(path, "wb") as f:            # a damaged file
+        f.write(new[:100])
+    assert D._read_fresh_id(path) is None
+    with pytest.raises(TimeoutError):
+        D._await_id(path, 0.2)
+    a = D._id_path()
+    D._comm_counter[0] += 1
+    try:
+        assert D._id_path() != a
+    finally:
+        D._comm_counter[0] -= 1

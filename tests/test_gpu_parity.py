@@ -1196,18 +1196,20 @@ def test_rccl_track_allgather_one_rank(fpt, orc, tmp_path):
     assert np.array_equal(d_s.download(np.float64, x.size), x)
     m = x[:99999].reshape(33333, 3)
     assert np.array_equal(comm.allgather_rows(m, [33333]), m)
-    os.environ["FPT_COMM_RAGGED"] = "1"  # the grouped-broadcast form that ragged shards take
-    try:
-        d_r2 = DeviceArray(ctx, x.nbytes)
-        comm.allgather_dev(d_s.ptr, [x.size], d_r2.ptr)
-        ctx.synchronize()
-        assert np.array_equal(d_r2.download(np.float64, x.size), x)
-        assert np.array_equal(comm.allgather_rows(m, [33333]), m)  # in place
-    finally:
-        del os.environ["FPT_COMM_RAGGED"]
     with pytest.raises(ValueError):
         comm.allgather_dev(d_s.ptr, [1, 2], d_r.ptr)
     comm.close()
+    os.environ["FPT_COMM_RAGGED"] = "1"  # the grouped-broadcast form that ragged shards take (read when the communicator is made)
+    try:
+        comm2 = TrackComm(ctx, rank=0, world=1)
+        d_r2 = DeviceArray(ctx, x.nbytes)
+        comm2.allgather_dev(d_s.ptr, [x.size], d_r2.ptr)
+        ctx.synchronize()
+        assert np.array_equal(d_r2.download(np.float64, x.size), x)
+        assert np.array_equal(comm2.allgather_rows(m, [33333]), m)  # in place
+        comm2.close()
+    finally:
+        del os.environ["FPT_COMM_RAGGED"]
     # the sharded detect driver (one rank = the whole list) equals the plain one
     lat = golden("nb_lattice.npz")
     table = golden("kmer_probs.npz")["table"]
