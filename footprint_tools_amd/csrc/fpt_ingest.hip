@@ -39,6 +39,9 @@ __global__ void __launch_bounds__(256) k_cut_counts(fpt_cutcount_desc d) {
     if ((int)d.mapq[i] < d.min_qual) return;
     if ((fl & kPaired) && (!(fl & kProper) || (fl & (kSecondary | kSupplementary)))) return;
     const bool rev = (fl & kReverse) != 0;
+    // a reverse read without a reference-consuming CIGAR operation has no reference_end (the reader
+    // hands it over as -1; pysam gives None and the reference's lookup fails on it): left out
+    if (rev && d.ref_end[i] < 0) return;
     const int64_t pos = rev ? (int64_t)d.ref_end[i] + d.offset_minus : (int64_t)d.ref_start[i] + d.offset_plus;
     if (pos < 0) return;
     const int64_t x = ((int64_t)d.ref_id[i] << 32) | pos;
@@ -48,10 +51,16 @@ __global__ void __launch_bounds__(256) k_cut_counts(fpt_cutcount_desc d) {
         const int64_t mid = (lo + hi) >> 1;
         if (d.start_key[mid] <= x) lo = mid + 1; else hi = mid;
     }
-    double *dst = rev ? d.counts_minus : d.counts_plus;
     for (int64_t j = lo - 1; j >= 0 && d.maxend_key[j] > x; --j) {
-        const int64_t rel = x - d.start_key[j];
-        if (rel < d.padded_len[j]) atomicAdd(dst + d.counts_off[j] + rel, 1.0);
+        int64_t rel = x - d.start_key[j];
+        const int64_t plen = d.padded_len[j];
+        if (rel < plen) {
+            // an interval on strand '-' gets its arrays mirrored and swapped (cutcounts.py:307-311)
+            const bool flip = d.flip && d.flip[j];
+            if (flip) rel = plen - 1 - rel;
+            double *dst = (rev != flip) ? d.counts_minus : d.counts_plus;
+            atomicAdd(dst + d.counts_off[j] + rel, 1.0);
+        }
     }
 }
 

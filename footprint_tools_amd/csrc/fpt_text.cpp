@@ -11,7 +11,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/fpt.h"
 
@@ -88,19 +92,18 @@ inline char *put_fixed(char *p, char *end, double v, int prec) {
 extern "C" {
 #pragma GCC visibility push(default)
 
-int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int64_t n_rows, int32_t n_cols,
-                     const int64_t *rows, int64_t n_sel, char delim, int32_t precision, char *buf, int64_t cap,
-                     int64_t *len_out) {
-    if (!chrom || !len_out || n_rows < 0 || n_cols < 0 || precision < 0 || precision > 30 || cap < 0 || (!buf && cap > 0))
-        return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
-    if ((!stats && n_rows > 0 && n_cols > 0) || (rows && n_sel < 0)) return fpt_internal_fail(FPT_ERR_INVALID, "null matrix");
-    const size_t lc = strlen(chrom);
-    const int64_t count = rows ? n_sel : n_rows;
-    char *p = buf, *end = buf + cap;
-    for (int64_t r = 0; r < count; ++r) {
+// rows [r0, r1) of the selection into [p, end): the new end, or nullptr when the buffer is too
+// small / a row index is outside the matrix (*bad_row set)
+static char *format_rows(const char *chrom, size_t lc, int64_t start, const double *stats, int64_t n_rows, int32_t n_cols,
+                         const int64_t *rows, int64_t r0, int64_t r1, char delim, int32_t precision, char *p, char *end,
+                         int64_t *bad_row) {
+    for (int64_t r = r0; r < r1; ++r) {
         const int64_t i = rows ? rows[r] : r;
-        if (i < 0 || i >= n_rows) return fpt_internal_fail(FPT_ERR_INVALID, "row %lld outside the matrix", (long long)i);
-        if ((size_t)(end - p) < lc + 48) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+        if (i < 0 || i >= n_rows) {
+            *bad_row = i;
+            return nullptr;
+        }
+        if ((size_t)(end - p) < lc + 48) return nullptr;
         memcpy(p, chrom, lc);
         p += lc;
         *p++ = delim;
@@ -110,14 +113,79 @@ int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int6
         *p++ = delim;
         const double *row = stats + i * (int64_t)n_cols;
         for (int32_t c = 0; c < n_cols; ++c) {
-            if (end - p < 48) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+            if (end - p < 48) return nullptr;
             if (c) *p++ = delim;
             p = put_fixed(p, end - 2, row[c], precision);
-            if (!p) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+            if (!p) return nullptr;
         }
         *p++ = '\n';
     }
-    *len_out = p - buf;
+    return p;
+}
+
+int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int64_t n_rows, int32_t n_cols,
+                     const int64_t *rows, int64_t n_sel, char delim, int32_t precision, char *buf, int64_t cap,
+                     int64_t *len_out) {
+    if (!chrom || !len_out || n_rows < 0 || n_cols < 0 || precision < 0 || precision > 30 || cap < 0 || (!buf && cap > 0))
+        return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
+    if ((!stats && n_rows > 0 && n_cols > 0) || (rows && n_sel < 0)) return fpt_internal_fail(FPT_ERR_INVALID, "null matrix");
+    const size_t lc = strlen(chrom);
+    const int64_t count = rows ? n_sel : n_rows;
+    int64_t bad_row = -1;
+    // large selections: row blocks on a team of threads, each into its own buffer, joined in order
+    // (a line is 30-70 bytes; the text of a million rows is what a `detect` run waits for)
+    unsigned hc = std::thread::hardware_concurrency();
+    int nt = (int)(hc == 0 ? 1 : (hc > 32 ? 32 : hc));
+    if (const char *e = getenv("FPT_TEXT_THREADS")) nt = atoi(e) > 0 ? atoi(e) : 1;
+    if (count < 8192 || nt < 2) {
+        char *p = format_rows(chrom, lc, start, stats, n_rows, n_cols, rows, 0, count, delim, precision, buf, buf + cap, &bad_row);
+        if (!p) {
+            if (bad_row != -1) return fpt_internal_fail(FPT_ERR_INVALID, "row %lld outside the matrix", (long long)bad_row);
+            return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+        }
+        *len_out = p - buf;
+        return FPT_OK;
+    }
+    if ((int64_t)nt > count / 4096) nt = (int)(count / 4096);
+    // worst case of one line on the fast path; values beyond 1e17 take the snprintf path, whose
+    // lines can be longer: a block that overflows its private buffer is redone with more room
+    const size_t per_line = lc + 44 + (size_t)n_cols * (size_t)(22 + precision);
+    std::vector<std::string> parts((size_t)nt);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<int> fail((size_t)nt, 0);
+    std::vector<std::thread> team;
+    for (int t = 0; t < nt; ++t)
+        team.emplace_back([&, t]() {
+            const int64_t r0 = count * t / nt, r1 = count * (t + 1) / nt;
+            size_t room = (size_t)(r1 - r0) * per_line + 64;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                parts[(size_t)t].resize(room);
+                char *b0 = &parts[(size_t)t][0];
+                char *p = format_rows(chrom, lc, start, stats, n_rows, n_cols, rows, r0, r1, delim, precision, b0, b0 + room,
+                                      &bad[(size_t)t]);
+                if (p) {
+                    parts[(size_t)t].resize((size_t)(p - b0));
+                    return;
+                }
+                if (bad[(size_t)t] != -1) break;
+                room = (size_t)(r1 - r0) * (lc + 44 + (size_t)n_cols * (size_t)(330 + precision)) + 64;
+            }
+            fail[(size_t)t] = 1;
+        });
+    for (std::thread &t : team) t.join();
+    size_t total = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (bad[(size_t)t] != -1) return fpt_internal_fail(FPT_ERR_INVALID, "row %lld outside the matrix", (long long)bad[(size_t)t]);
+        if (fail[(size_t)t]) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+        total += parts[(size_t)t].size();
+    }
+    if ((int64_t)total > cap) return fpt_internal_fail(FPT_ERR_INVALID, "output buffer too small");
+    char *p = buf;
+    for (int t = 0; t < nt; ++t) {
+        memcpy(p, parts[(size_t)t].data(), parts[(size_t)t].size());
+        p += parts[(size_t)t].size();
+    }
+    *len_out = (int64_t)total;
     return FPT_OK;
 }
 

@@ -13,10 +13,15 @@ a read counts if it is not QC-fail (remove_qcfail) / duplicate (remove_dups), ha
 and -- when paired -- is a proper pair and neither secondary nor supplementary; forward reads cut
 at reference_start + offset[0] on '+', reverse reads at reference_end + offset[1] on '-'.
 
-Differences, on purpose: the file is read sequentially by the library's own BGZF/BAM reader
-(htslib / pysam are not available here; no index, no CRAM), all alignments are kept on the device
-after the first pass, and 'fragments' (the fragment intervals the reference also returns; unused
-on this path) is always empty.  Unmapped reads carrying a position are skipped.  Parity of the
+Differences, on purpose: the file is read once by the library's own BGZF/BAM reader (htslib /
+pysam are not available here; no .bai, no CRAM; blocks inflated on a team of threads), all
+alignments are kept ON THE DEVICE (13 bytes per alignment; the host keeps one start key per 256
+alignments as a coarse index), and 'fragments' (the fragment intervals the reference also returns;
+unused on this path) is always empty.  A query launches the counting kernel over the alignments
+that can reach it only -- those whose start lies between the query's first base minus the longest
+alignment span and its last base -- found in the coarse index, so a single-interval lookup costs
+what its neighbourhood holds, not the file (files that are not coordinate-sorted are sorted once
+at load).  Unmapped reads carrying a position are skipped.  Parity of the
 file reader is unpinned (no pysam to compare with); the counting rule is pinned: tests compare
 `lookup` with what the reference's own `bamfile.lookup` returned for 6,000 alignments under five
 filter / offset settings (tests/golden/cutcounts.npz), and with hand-derived vectors.  One case of
@@ -52,7 +57,7 @@ class CutCountDesc(C.Structure):
         ("min_qual", C.c_int32), ("remove_dups", C.c_int32), ("remove_qcfail", C.c_int32),
         ("n_intervals", C.c_int64), ("start_key", C.c_void_p), ("maxend_key", C.c_void_p),
         ("padded_len", C.c_void_p), ("counts_off", C.c_void_p),
-        ("counts_plus", C.c_void_p), ("counts_minus", C.c_void_p),
+        ("counts_plus", C.c_void_p), ("counts_minus", C.c_void_p), ("flip", C.c_void_p),
     ]
 
 
@@ -117,7 +122,18 @@ class bamfile(object):
         self._ctx = ctx
         self.references, rid, st, en, fl, mq = read_alignments(filepath)
         self._ref_index = {name: i for i, (name, _) in enumerate(self.references)}
-        self._host = (rid, st, en, fl, mq)
+        key = (rid.astype(np.int64) << 32) | np.clip(st, 0, None).astype(np.int64)
+        if key.size and np.any(key[1:] < key[:-1]):  # not coordinate-sorted: sort once
+            order = np.argsort(key, kind="stable")
+            rid, st, en, fl, mq, key = rid[order], st[order], en[order], fl[order], mq[order], key[order]
+        self._n_reads = int(rid.size)
+        # coarse index: the start key of every 256th alignment, and how far an alignment's cut
+        # can lie from its start (the longest reference span, plus the offsets)
+        self._index_step = 256
+        self._index = key[::self._index_step].copy()
+        span = int((en.astype(np.int64) - st).max()) if rid.size else 0
+        self._reach = max(span, 0) + abs(int(offset[0])) + abs(int(offset[1])) + 1
+        self._host = (rid, st, en, fl, mq)  # dropped once the arrays are on the device
         self._dev = None
 
     def close(self):
@@ -130,26 +146,35 @@ class bamfile(object):
 
     @property
     def n_reads(self):
-        return int(self._host[0].size)
+        return self._n_reads
 
     def _reads_dev(self):
         if self._dev is None:
             ctx = self._ctx or _lib.get_ctx()
             self._ctx = ctx
+            if self._host is None:
+                raise RuntimeError("the alignments of this bamfile have been released (close())")
             self._dev = [DeviceArray(ctx, max(a.nbytes, 16)).upload(a) if a.size else DeviceArray(ctx, 16)
                          for a in self._host]
+            self._host = None  # the device holds them now
         return self._dev
 
-    def cut_counts_ranges_dev(self, chroms, starts, lengths, counts_plus=None, counts_minus=None):
+    def _read_range(self, lo_key, hi_key):
+        """[a, b): the alignments whose start key lies in [lo_key - reach, hi_key], from the coarse index"""
+        a = int(np.searchsorted(self._index, lo_key - self._reach, side="left")) - 1
+        b = int(np.searchsorted(self._index, hi_key, side="right"))
+        return max(a, 0) * self._index_step, min(b * self._index_step, self._n_reads)
+
+    def cut_counts_ranges_dev(self, chroms, starts, lengths, counts_plus=None, counts_minus=None, flip=None):
         """Counts of the ranges [starts[i], starts[i] + lengths[i]) on chroms[i], written back to
         back (CSR) into two device arrays of sum(lengths) doubles: returns (plus, minus, offsets).
-        Existing arrays are accumulated into (several files of one dataset)."""
+        Existing arrays are accumulated into (several files of one dataset).  flip[i] = True gives
+        range i the reference's strand '-' form ({'+': rev[::-1], '-': fw[::-1]}, cutcounts.py:307-311)."""
         ctx = self._ctx or _lib.get_ctx()
         self._ctx = ctx
         L = _bind(ctx.L)
         starts = np.asarray(starts, dtype=np.int64)
         lengths = np.asarray(lengths, dtype=np.int64)
-        n = starts.size
         off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
         total = int(off[-1])
         if counts_plus is None:
@@ -166,40 +191,54 @@ class bamfile(object):
             plen = (lengths[idx] - clip[idx]).astype(np.int32)
             ekey = np.maximum.accumulate(skey + plen)
             coff = (off[:-1][idx] + clip[idx]).astype(np.int64)
-            dev = self._reads_dev()
-            tmp = [DeviceArray(ctx, a.nbytes).upload(a) for a in (skey, ekey, plen, coff)]
-            d = CutCountDesc()
-            d.n_reads = self.n_reads
-            d.ref_id, d.ref_start, d.ref_end, d.flag, d.mapq = (x.ptr for x in dev)
-            d.offset_plus, d.offset_minus = int(self.offset[0]), int(self.offset[1])
-            d.min_qual, d.remove_dups, d.remove_qcfail = int(self.min_qual), int(bool(self.remove_dups)), int(bool(self.remove_qcfail))
-            d.n_intervals = idx.size
-            d.start_key, d.maxend_key, d.padded_len, d.counts_off = (x.ptr for x in tmp)
-            d.counts_plus, d.counts_minus = counts_plus.ptr, counts_minus.ptr
-            _lib.check(L.fpt_cut_counts_dev(ctx.h, C.byref(d)))
-            ctx.synchronize()
-            for x in tmp:
-                x.free()
+            # only the alignments that can reach the ranges (sorted by start key)
+            r0, r1 = self._read_range(int(skey[0]), int(ekey[-1]))
+            if r1 > r0:
+                dev = self._reads_dev()
+                arrs = [skey, ekey, plen, coff]
+                if flip is not None:
+                    fl = np.ascontiguousarray(np.asarray(flip, dtype=bool)[idx], dtype=np.uint8)
+                    if np.any(clip[idx][fl.astype(bool)] > 0):
+                        raise ValueError("a strand '-' range may not start before position 0")
+                    arrs.append(fl)
+                tmp = [DeviceArray(ctx, max(a.nbytes, 16)).upload(a) for a in arrs]
+                d = CutCountDesc()
+                d.n_reads = r1 - r0
+                d.ref_id, d.ref_start, d.ref_end = (dev[k].ptr + 4 * r0 for k in range(3))
+                d.flag, d.mapq = dev[3].ptr + 2 * r0, dev[4].ptr + r0
+                d.offset_plus, d.offset_minus = int(self.offset[0]), int(self.offset[1])
+                d.min_qual, d.remove_dups, d.remove_qcfail = int(self.min_qual), int(bool(self.remove_dups)), int(bool(self.remove_qcfail))
+                d.n_intervals = idx.size
+                d.start_key, d.maxend_key, d.padded_len, d.counts_off = (x.ptr for x in tmp[:4])
+                d.flip = tmp[4].ptr if flip is not None else None
+                d.counts_plus, d.counts_minus = counts_plus.ptr, counts_minus.ptr
+                _lib.check(L.fpt_cut_counts_dev(ctx.h, C.byref(d)))
+                ctx.synchronize()
+                for x in tmp:
+                    x.free()
         return counts_plus, counts_minus, off
 
     def cut_counts_dev(self, intervals, pad):
         """The padded count arrays of an interval list exactly as the fused scan reads them
         (`prediction.compute` fetches [start - pad - 1, end + pad), modeling/predict.pyx:132-134):
-        (counts_plus, counts_minus) DeviceArrays in FootprintScanner.scan_dev's CSR layout."""
+        (counts_plus, counts_minus) DeviceArrays in FootprintScanner.scan_dev's CSR layout.
+        Intervals on strand '-' get the reference's mirrored and swapped arrays."""
         ivs = list(intervals)
+        flip = [getattr(iv, "strand", None) == "-" for iv in ivs]
         cp, cm, _ = self.cut_counts_ranges_dev([iv.chrom for iv in ivs], [iv.start - pad - 1 for iv in ivs],
-                                               [iv.end - iv.start + 2 * pad + 1 for iv in ivs])
+                                               [iv.end - iv.start + 2 * pad + 1 for iv in ivs],
+                                               flip=flip if any(flip) else None)
         return cp, cm
 
     def lookup(self, interval):
         """Lookup reads in a defined genomic region (cutcounts.py:274-313)."""
         n = interval.end - interval.start
-        cp, cm, _ = self.cut_counts_ranges_dev([interval.chrom], [interval.start], [n])
-        fw, rev = cp.download(np.float64, n), cm.download(np.float64, n)
+        flip = getattr(interval, "strand", None) == "-"
+        cp, cm, _ = self.cut_counts_ranges_dev([interval.chrom], [interval.start], [n], flip=[True] if flip else None)
+        plus, minus = cp.download(np.float64, n), cm.download(np.float64, n)
         cp.free()
         cm.free()
-        flip = getattr(interval, "strand", None) == "-"
-        return {"+": rev[::-1] if flip else fw, "-": fw[::-1] if flip else rev, "fragments": []}
+        return {"+": plus, "-": minus, "fragments": []}
 
     def __getitem__(self, x):
         return self.lookup(x)

@@ -147,7 +147,7 @@ class deviation_stats(object):
         lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         sc = self._scanner()
-        if self._device_inputs() and not any(getattr(iv, "strand", None) == "-" for iv in ivs):
+        if self._device_inputs():  # (strand '-' intervals included: cut_counts_dev mirrors and swaps their counts)
             res, efdr = self._compute_on_device(indices, ivs, lens, off)
         else:
             cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
@@ -230,7 +230,9 @@ def write_stats_to_output(interval, stats, file=sys.stdout, delim="\t", filter_f
     rows = np.nonzero(filter_fn(stats))[0] if filter_fn else None
     chrom, start = interval.chrom, interval.start
     fixed = _FIXED.match(fmt_string)
-    text = _native_stats_text(chrom, start, stats, rows, delim, int(fixed.group(1))) if fixed else None
+    # the library's formatter takes up to 30 decimals; anything else goes value by value below
+    text = (_native_stats_text(chrom, start, stats, rows, delim, int(fixed.group(1)))
+            if fixed and int(fixed.group(1)) <= 30 else None)
     if text is None:  # any other format string: value by value, as the reference does
         fmt = "{0:" + fmt_string + "}"
         text = "".join(

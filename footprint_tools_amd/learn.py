@@ -47,8 +47,7 @@ class expected_counts(object):
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         ctx = self._sc.ctx
         if (hasattr(self.read_func, "cut_counts_dev") and hasattr(self.fasta_func, "fetch_batch")
-                and self.bm.offset() == 3 and getattr(self.read_func, "_ctx", None) in (None, ctx)
-                and not any(getattr(iv, "strand", None) == "-" for iv in ivs)):
+                and self.bm.offset() == 3 and getattr(self.read_func, "_ctx", None) in (None, ctx)):
             # a cutcounts.bamfile and a fasta.FastaFile: the count arrays are filled on the device
             # from the alignments held there, no round trip per interval (see detect.deviation_stats)
             if getattr(self.read_func, "_ctx", None) is None:

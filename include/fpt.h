@@ -350,6 +350,8 @@ typedef struct fpt_cutcount_desc {
     const int32_t *padded_len;
     const int64_t *counts_off;                       /* element offset of each interval in the count arrays */
     double *counts_plus, *counts_minus;
+    const uint8_t *flip;                             /* optional, per interval: 1 = strand '-' interval: the reference
+                                                      * returns {'+': rev[::-1], '-': fw[::-1]} (cutcounts.py:307-311) */
 } fpt_cutcount_desc;
 int fpt_cut_counts_dev(fpt_ctx *ctx, const fpt_cutcount_desc *d);
 

@@ -1,0 +1,163 @@
+"""Runs under LD_PRELOAD=libasan.so (tests/test_ingest_cpu.py::test_sanitizer_build starts it): the
+host-only sanitizer builds of the BGZF / BAM reader and the text formatter
+(footprint_tools_amd/libfpt_host_asan.so, `make -C footprint_tools_amd/csrc asan`) and of the CPU
+checker (oracle/libfpt_oracle_asan.so) on good input, and the reader on a corpus of damaged files:
+every damaged file must end in an error code, never in a sanitizer report.  Prints "ASAN-DRIVER OK"."""
+import ctypes as C
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.bamwriter import _bgzf_block, write_bam  # noqa: E402
+
+L = C.CDLL(os.path.join(ROOT, "footprint_tools_amd", "libfpt_host_asan.so"))
+vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+L.fpt_last_error.restype = C.c_char_p
+L.fpt_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+L.fpt_bam_close.argtypes = [vp]
+L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+L.fpt_format_stats.argtypes = [C.c_char_p, i64, vp, i64, i32, vp, i64, C.c_char, i32, vp, i64, C.POINTER(i64)]
+
+
+def read_all(path, batch=500):
+    """(rc_open, rc_read, n_reads): reads until the end or the first error"""
+    h = vp()
+    rc = L.fpt_bam_open(path.encode(), C.byref(h))
+    if rc:
+        return rc, 0, 0
+    total, rc2 = 0, 0
+    while True:
+        a = [np.empty(batch, np.int32) for _ in range(3)]
+        fl, mq = np.empty(batch, np.uint16), np.empty(batch, np.uint8)
+        got = i64()
+        rc2 = L.fpt_bam_read(h, batch, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, fl.ctypes.data,
+                             mq.ctypes.data, C.byref(got))
+        total += got.value
+        if rc2 or got.value == 0:
+            break
+    L.fpt_bam_close(h)
+    return 0, rc2, total
+
+
+def main(tmp):
+    rs = np.random.RandomState(5)
+    refs = [("chr1", 100000), ("chr2", 50000)]
+    reads = [dict(ref=int(rs.randint(0, 2)), pos=int(rs.randint(0, 40000)), cigar=str(rs.choice(["36M", "20M2D16M", "5S31M"])),
+                  flag=int(rs.choice([0, 16, 99, 147])), mapq=int(rs.choice([0, 30, 60]))) for _ in range(4000)]
+    good = os.path.join(tmp, "good.bam")
+    write_bam(good, refs, reads, block_bytes=2500)
+    for threads in ("1", "4"):
+        os.environ["FPT_BAM_THREADS"] = threads
+        assert read_all(good) == (0, 0, len(reads)), read_all(good)
+    raw = open(good, "rb").read()
+
+    def case(name, data, expect_reads=None):
+        p = os.path.join(tmp, name)
+        with open(p, "wb") as f:
+            f.write(data)
+        rc_open, rc_read, n = read_all(p)
+        failed = rc_open != 0 or rc_read != 0
+        if expect_reads is None:
+            assert failed, (name, rc_open, rc_read, n)
+        else:
+            assert not failed and n == expect_reads, (name, rc_open, rc_read, n)
+        return L.fpt_last_error().decode()
+
+    # ---- container damage
+    case("empty.bam", b"")
+    case("garbage.bam", b"not a bam file at all" * 10)
+    for cut in (5, 17, 40, len(raw) // 3, len(raw) // 2, len(raw) - 30, len(raw) - 5):
+        case("cut%d.bam" % cut, raw[:cut])
+    for k in range(60):  # single bit flips all over the file: header fields, deflate payload, CRC, ISIZE
+        pos = int(rs.randint(0, len(raw) - 28))  # (the empty EOF block at the end may be damaged harmlessly)
+        b = bytearray(raw)
+        b[pos] ^= 1 << int(rs.randint(0, 8))
+        p = os.path.join(tmp, "flip.bam")
+        with open(p, "wb") as f:
+            f.write(bytes(b))
+        read_all(p)  # error or not (a flip inside a read name changes nothing we look at): no sanitizer report
+    b = bytearray(raw)
+    b[16:18] = struct.pack("<H", 10)        # BSIZE smaller than the header it sits in
+    case("bsize_small.bam", bytes(b))
+    b = bytearray(raw)
+    b[10:12] = struct.pack("<H", 60000)     # XLEN far beyond the member
+    case("xlen_big.bam", bytes(b))
+    case("no_bc.bam", zlib.compress(b"BAM\1" + b"\0" * 100))  # a gzip-less zlib stream / no BC subfield
+
+    # ---- record damage inside well-formed BGZF blocks
+    def bam_bytes(records, l_text=None, n_ref=None, l_name_ref=None):
+        text = b"@HD\tVN:1.6\n"
+        out = bytearray(b"BAM\1") + struct.pack("<i", len(text) if l_text is None else l_text) + text
+        out += struct.pack("<i", 1 if n_ref is None else n_ref)
+        out += struct.pack("<i", 5 if l_name_ref is None else l_name_ref) + b"chr1\0" + struct.pack("<i", 1000)
+        for r in records:
+            out += r
+        return _bgzf_block(bytes(out)) + _bgzf_block(b"")
+
+    def record(block_size=None, l_name=3, n_cig=1, cig=((36 << 4) | 0,), tail=b""):
+        body = struct.pack("<iiBBHHHiiii", 0, 100, l_name, 30, 0, n_cig, 0, 36, -1, -1, 0) + b"r1\0"
+        body += b"".join(struct.pack("<I", v) for v in cig) + tail
+        return struct.pack("<i", len(body) if block_size is None else block_size) + body
+
+    case("ok_one.bam", bam_bytes([record()]), expect_reads=1)
+    case("neg_l_text.bam", bam_bytes([record()], l_text=-5))
+    case("huge_l_text.bam", bam_bytes([record()], l_text=1 << 30))
+    case("neg_n_ref.bam", bam_bytes([record()], n_ref=-1))
+    case("many_refs.bam", bam_bytes([record()], n_ref=1000))
+    case("bad_l_name_ref.bam", bam_bytes([record()], l_name_ref=1 << 28))
+    case("zero_l_name_ref.bam", bam_bytes([record()], l_name_ref=0))
+    case("small_block.bam", bam_bytes([record(block_size=12)]))
+    case("neg_block.bam", bam_bytes([record(block_size=-1)]))
+    case("huge_block.bam", bam_bytes([record(block_size=1 << 29)]))
+    case("block_past_end.bam", bam_bytes([record(block_size=500)]))
+    # a CIGAR count / name length that reaches past the record: the record is still walked, its end unknown
+    case("n_cig_past.bam", bam_bytes([record(n_cig=60000)]), expect_reads=1)
+    case("l_name_past.bam", bam_bytes([record(l_name=255)]), expect_reads=1)
+    case("no_cigar.bam", bam_bytes([record(n_cig=0, cig=())]), expect_reads=1)
+
+    # ---- text formatter: against Python's own formatting, serial and threaded, tight buffers
+    for threads, n in (("1", 300), ("5", 40000)):
+        os.environ["FPT_TEXT_THREADS"] = threads
+        m = rs.standard_normal((n, 5)) * 10.0 ** rs.randint(-6, 7, (n, 5))
+        m[rs.randint(0, n, 20), rs.randint(0, 5, 20)] = rs.choice([np.nan, np.inf, -np.inf, 0.0, -0.0, 0.5, 2.5e-5, 1e300], 20)
+        for prec in (4, 0, 9, 12):
+            want = "".join("chrX\t%d\t%d\t%s\n" % (1000 + i, 1001 + i, "\t".join(("{:0.%df}" % prec).format(v) for v in m[i]))
+                           for i in range(n)).encode()
+            for cap in (len(want) + 64 + (n // 4096 + 1) * 64, len(want) // 2):
+                buf = C.create_string_buffer(max(cap, 1))
+                out = i64()
+                rc = L.fpt_format_stats(b"chrX", 1000, m.ctypes.data, n, 5, None, 0, b"\t", prec, buf, cap, C.byref(out))
+                if cap >= len(want):
+                    assert rc == 0 and buf.raw[:out.value] == want, (threads, prec, rc, L.fpt_last_error())
+                else:
+                    assert rc != 0
+        rows = np.array([0, n - 1, 5], dtype=np.int64)
+        buf, out = C.create_string_buffer(4096), i64()
+        assert L.fpt_format_stats(b"c", 0, m.ctypes.data, n, 5, rows.ctypes.data, 3, b" ", 4, buf, 4096, C.byref(out)) == 0
+        rows[1] = n  # outside the matrix
+        assert L.fpt_format_stats(b"c", 0, m.ctypes.data, n, 5, rows.ctypes.data, 3, b" ", 4, buf, 4096, C.byref(out)) != 0
+
+    # ---- the CPU checker under the sanitizers: the expected-cleavage path with rounding ties, the
+    # NB / window functions and one small whole-path batch
+    O = C.CDLL(os.path.join(ROOT, "oracle", "libfpt_oracle_asan.so"))
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    O.orc_fast_predict.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "predict_ties.npz"))
+    for c, (hw, shw, clip, l, _) in enumerate(g["meta"]):
+        e, w = np.empty(int(l)), np.empty(int(l))
+        O.orc_fast_predict(np.ascontiguousarray(g["obs%d" % c]), np.ascontiguousarray(g["probs%d" % c]), int(l), int(hw),
+                           int(shw), float(clip), e, w)
+        assert np.array_equal(e, g["exp%d" % c])
+    for l in (0, 1, 7, 11, 101, 102):  # degenerate lengths
+        e, w = np.empty(max(l, 1)), np.empty(max(l, 1))
+        O.orc_fast_predict(np.ones(max(l, 1)), np.full(max(l, 1), 0.1), l, 5, 50, 0.01, e, w)
+    print("ASAN-DRIVER OK")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

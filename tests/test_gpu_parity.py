@@ -1352,6 +1352,27 @@ def test_cut_count_ingestion(fpt, orc, tmp_path):
             assert np.array_equal(arr[pos:pos + b - a], want), (iv.chrom, iv.start, strand)
         pos += b - a
     assert hp.sum() > 1000
+    # strand '-' intervals in the batched form: the reference's mirrored and swapped arrays
+    # (cutcounts.py:307-311), the same as asking for them one by one
+    sivs = [Iv("chr1", 300, 800, "-"), Iv("chr1", 350, 420, "+"), Iv("chr2", 1000, 1500, "-"), Iv("chr1", 4800, 4990, "-")]
+    cps, cms = bf.cut_counts_dev(sivs, pad)
+    tot_s = sum(iv.end - iv.start + 2 * pad + 1 for iv in sivs)
+    sp, sm = cps.download(np.float64, tot_s), cms.download(np.float64, tot_s)
+    pos = 0
+    for iv in sivs:
+        c = [n for n, _ in refs].index(iv.chrom)
+        a, b = iv.start - pad - 1, iv.end + pad
+        fw = np.array([genome[(c, "+")][x] if 0 <= x < 6000 else 0.0 for x in range(a, b)])
+        rv = np.array([genome[(c, "-")][x] if 0 <= x < 6000 else 0.0 for x in range(a, b)])
+        want_p, want_m = (rv[::-1], fw[::-1]) if iv.strand == "-" else (fw, rv)
+        assert np.array_equal(sp[pos:pos + b - a], want_p) and np.array_equal(sm[pos:pos + b - a], want_m), (iv.start, iv.strand)
+        one = bf[Iv(iv.chrom, a, b, iv.strand)]
+        assert np.array_equal(one["+"], want_p) and np.array_equal(one["-"], want_m)
+        pos += b - a
+    cps.free(); cms.free()
+    # a lookup touches the alignments near it only (coarse index over the start keys)
+    r0, r1 = bf._read_range((0 << 32) | 300, (0 << 32) | 800)
+    assert 0 < r1 - r0 < bf.n_reads // 3
     # end to end: BAM + FASTA -> the scan, equal to the oracle on the same arrays
     gseq = {name: "".join(rs.choice(list("ACGT"), n)) for name, n in refs}
     fa_path = tmp_path / "g.fa"

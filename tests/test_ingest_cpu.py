@@ -150,3 +150,52 @@ def test_tabix_track_reader_and_load_data(tmp_path):
                 assert abs(exp[d, j] - e) < 1e-9 and abs(obs[d, j] - o) < 1e-9 and abs(fdr[d, j] - round(f, 4)) < 1e-9
                 assert w[d, j] == float((iv.chrom, iv.start + j) in truth[d])
     ps.cleanup()
+
+
+def test_bam_reader_threads_and_missing_cigar(tmp_path, monkeypatch):
+    """the block-parallel inflate gives the same alignments whatever the team size, and a read
+    without a reference-consuming CIGAR operation has no reference_end (-1, pysam: None)."""
+    from footprint_tools_amd.cutcounts import read_alignments
+    rs = np.random.RandomState(3)
+    refs = [("chr1", 100000)]
+    reads = _reads(rs, 20000, n_ref=1)
+    reads[10]["cigar"] = "36S"      # soft clip only
+    reads[11]["cigar"] = "10I26S"
+    path = str(tmp_path / "t.bam")
+    write_bam(path, refs, reads, block_bytes=1500)
+    got = {}
+    for nt in ("1", "3", "16"):
+        monkeypatch.setenv("FPT_BAM_THREADS", nt)
+        got[nt] = read_alignments(path, batch=4096)
+    for nt in ("3", "16"):
+        for a, b in zip(got["1"][1:], got[nt][1:]):
+            assert np.array_equal(a, b)
+    en = got["1"][3]
+    assert en[10] == -1 and en[11] == -1
+    assert np.array_equal(np.delete(en, [10, 11]), [r["pos"] + _ref_span(r["cigar"]) for i, r in enumerate(reads) if i not in (10, 11)])
+
+
+def test_sanitizer_build(tmp_path):
+    """`make asan`: the BGZF / BAM reader, the text formatter (footprint_tools_amd/csrc) and the CPU
+    checker built with -fsanitize=address,undefined, driven by tests/asan_driver.py under
+    LD_PRELOAD=libasan.so over good files and a corpus of truncated / bit-flipped / inconsistent
+    ones (bad l_name, n_cigar past the record, negative l_text, BSIZE / XLEN / ISIZE lies...)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE).stdout.decode().strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan is not installed")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "footprint_tools_amd", "csrc"), "asan"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py"), str(tmp_path)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "ASAN-DRIVER OK" in text, text[-3000:]
+    assert "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
