@@ -753,7 +753,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     if (!d->exp || !d->winp || !d->efdr_out) return fail(FPT_ERR_INVALID, "null track");
     // Intervals of up to kLdsMax bases keep their buffers in LDS; longer ones (up to kLongMax)
     // run the same kernel over buffers in global memory.
-    constexpr int kLdsMax = 4096, kLongMax = 1 << 22;
+    constexpr int kLdsMax = 2048, kLongMax = 1 << 22;  // five n2-sized double buffers + three int ones must fit 160 KB
     int lmax = d->interval_len;
     // Ragged batches are binned by the power of two that holds the interval: the kernel's LDS
     // buffers are sized by the largest interval of a launch, so one 2,000-base interval in a

@@ -473,24 +473,25 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Two uniforms in [0, 1) with 53 random bits each from ONE Philox block keyed by
-// (seed, base, pair): words (0,1) are the draw of sample 2*pair, words (2,3) of sample 2*pair+1.
-__host__ __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t base, uint32_t pair,
-                                                         double &u0, double &u1) {
+// Four uniforms in (0, 1) from ONE Philox block keyed by (seed, base, quad): word w of the block is
+// the draw of sample 4 * quad + w, u = (word + 1/2) * 2^-32.  A null draw is an inverse-CDF bracket
+// in a tabulated cdf row (the smallest k with cdf(k) >= u), so 32 bits of resolution only merge
+// brackets narrower than 2.3e-10 -- far below what 100 draws per base can tell apart -- and the
+// half-step keeps u off 0 and 1.  One block per four draws instead of two halves the generator's
+// share of the kernel (measured: DESIGN.md, empirical-FDR kernel).
+__host__ __device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t base, uint32_t quad, double u[4]) {
     uint32_t o[4];
-    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), pair, 0x66707464u /* "fptd" */,
+    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), quad, 0x66707464u /* "fptd" */,
                   (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    const uint64_t x = ((uint64_t)o[1] << 32) | o[0];
-    const uint64_t y = ((uint64_t)o[3] << 32) | o[2];
-    u0 = (double)(x >> 11) * (1.0 / 9007199254740992.0);
-    u1 = (double)(y >> 11) * (1.0 / 9007199254740992.0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) u[w] = ((double)o[w] + 0.5) * (1.0 / 4294967296.0);
 }
 
 // the uniform of one (seed, base, sample)
 __host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
-    double u0, u1;
-    philox_uniform2(seed, base, sample >> 1, u0, u1);
-    return (sample & 1u) ? u1 : u0;
+    double u[4];
+    philox_uniform4(seed, base, sample >> 2, u);
+    return u[sample & 3u];
 }
 
 }  // namespace fptd

@@ -1258,7 +1258,7 @@ struct fdr_args {
     int32_t ablate;      // timing-only diagnostics (FPT_ABLATE builds)
     int32_t n2_max;      // buffer capacity: power of two >= longest interval of the launch
     double inv_sqrt_k;
-    int32_t dbuf;            // a second pair of z buffers follows zb1: one barrier per pass instead of two
+    int32_t dbuf;            // a second set of z buffers follows the first: one barrier per pass instead of two
     const int32_t *iv_list;  // interval of workgroup b is iv_list[b], or iv_first + b when null
     int64_t iv_first;
     char *gws;               // GWS instances: per-workgroup buffers in global memory
@@ -1456,10 +1456,9 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     const int n2 = a.n2_max;
     double *par = GWS ? reinterpret_cast<double *>(a.gws + (size_t)blockIdx.x * a.gws_stride) : smem;  // 24
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
-    double *zb = skey + n2;                          // n2 tile prefix sums of z, even sample
-    double *zb1 = zb + n2;                           // n2 same for the odd sample of the pair
-    double *zalt = zb1 + n2;                         // 2 * n2 more when a.dbuf (passes alternate buffers)
-    int *sidx = reinterpret_cast<int *>(zalt + (a.dbuf ? 2 * n2 : 0));  // n2 original positions
+    double *zb = skey + n2;                          // 4 x n2: z of the pass's four samples (tile prefix sums of two with wide windows)
+    double *zalt = zb + 4 * n2;                      // 4 x n2 more when a.dbuf (passes alternate between the sets)
+    int *sidx = reinterpret_cast<int *>(zalt + (a.dbuf ? 4 * n2 : 0));  // n2 original positions
     int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
     int *hist = nf + n2;                             // n2 + 2 histogram / prefix
     int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
@@ -1486,21 +1485,30 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * (kGuide + 1);
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
-    // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last)
+    // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last); on the way
+    // in, count the values that are not NaN (m) and those below 1 (the rank of the edge positions'
+    // constant 1.0 among the thresholds)
+    int n_num = 0, n_below_one = 0;
     for (int i = tid; i < np2; i += NT) {
         double v = fptm::kInf;
         int id = -1;
         if (i < L) {
             v = a.winp[off + i];
             id = i;
+            n_num += isnan(v) ? 0 : 1;
+            n_below_one += (v < 1.0) ? 1 : 0;
             if (isnan(v)) v = fptm::kInf;
         }
         skey[i] = v;
         sidx[i] = id;
     }
     for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
-    if (tid == 0) misc[0] = 0;
+    if (tid < 4) misc[tid] = 0;
     __syncthreads();
+    if (n_num) atomicAdd(&misc[1], n_num);
+    if (n_below_one) atomicAdd(&misc[2], n_below_one);
+    // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
+    // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NT) {
@@ -1520,29 +1528,9 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             __syncthreads();
         }
     }
-    // m = number of observed values that are not NaN (NaN / pads were mapped to +inf)
-    if (tid == 0) {
-        int l = 0, h = np2;
-        while (l < h) {
-            const int mid = (l + h) >> 1;
-            if (skey[mid] == fptm::kInf) h = mid; else l = mid + 1;
-        }
-        misc[1] = l;
-    }
     __syncthreads();
-    const int m = misc[1];
-    // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold); the rank of
-    // the edge positions' constant 1.0 is the number of observed values below 1
-    if (tid == 0) {
-        int l = 0, h = m;
-        while (l < h) {
-            const int mid = (l + h) >> 1;
-            if (skey[mid] < 1.0) l = mid + 1; else h = mid;
-        }
-        misc[2] = l;
-    }
-    __syncthreads();
-    const int rank_one = misc[2];
+    const int m = misc[1];         // observed values that are not NaN (NaN / pads were mapped to +inf)
+    const int rank_one = misc[2];  // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
     for (int i = tid; i < m; i += NT) skey[i] = ndtr_threshold(skey[i]);
     __syncthreads();
     // rank guide: y of a null window is about standard normal; nb slices of [-kYR, kYR) (the first
@@ -1566,7 +1554,8 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     __syncthreads();
 
-    // ---- 2. null tracks, two samples per pass (one Philox block feeds both)
+    // ---- 2. null tracks, four samples per pass with narrow windows (one Philox block feeds the
+    //         four), two with wide ones
     const int hs = a.hw;
     // Narrow windows (the reference only ever uses hw = 3) are summed directly from the raw z in
     // LDS, left to right like windowing.h:53-67: 2*hs+1 reads and adds are fewer instructions than
@@ -1577,114 +1566,131 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         for (int t = tid; t < L; t += NT) nf[t] = table_row_of(a.exp[off + t], a.memo_exp);
         // (each lane reads back only the entries it wrote: no barrier needed)
     }
-    // With two pairs of z buffers a pass writes one pair while slower wavefronts may still be
+    // With a second set of z buffers a pass writes one set while slower wavefronts may still be
     // reading the other, so the barrier at the end of a pass is not needed (direct windows only).
     const bool alternate = a.dbuf && direct;
-    double *const zb_even = zb, *const zb1_even = zb1;
-    for (int s = 0; s < a.times; s += 2) {
-        const bool two = s + 1 < a.times;
-        if (alternate) {
-            const bool odd_pass = (s >> 1) & 1;
-            zb = odd_pass ? zalt : zb_even;
-            zb1 = odd_pass ? zalt + n2 : zb1_even;
-        }
+    const int spp = direct ? 4 : 2;  // samples per pass
+    double *const zset0 = zb, *const zset1 = zalt;  // 4 (direct) or 2 buffers of n2 each
+    int pass = 0;
+    for (int s = 0; s < a.times; s += spp, ++pass) {
+        const int ns = a.times - s < spp ? a.times - s : spp;  // samples of this pass
+        double *const zq = (alternate && (pass & 1)) ? zset1 : zset0;
         for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
-            double z0 = 0.0, z1 = 0.0;
-            int zc = 0;
+            uint32_t o[4] = {0u, 0u, 0u, 0u};  // the Philox block of this base and pass (words = samples)
+            int ei = -1;
+            const double *up = a.null_uniform ? a.null_uniform + (size_t)(off + (t < L ? t : 0)) * a.times + s : nullptr;
             if (t < L) {
-                double u0, u1 = 0.5;
-                if (ABL(512)) {
-                    u0 = 0.37 + 1e-3 * s;
-                    u1 = 0.63 - 1e-3 * s;
-                } else if (a.null_uniform) {
-                    const double *up = a.null_uniform + (size_t)(off + t) * a.times + s;
-                    u0 = up[0];
-                    if (two) u1 = up[1];
-                } else {
-                    philox_uniform2(a.seed, (uint64_t)(a.base_index0 + off + t), (uint32_t)(s >> 1), u0, u1);
+                if (!up && !ABL(512)) {
+                    const uint64_t base = (uint64_t)(a.base_index0 + off + t);
+                    philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)(s >> 2), 0x66707464u,
+                                  (uint32_t)a.seed, (uint32_t)(a.seed >> 32), o);
+                    if (s & 2) {  // a pass of two samples (wide windows) on the upper half of a block
+                        o[0] = o[2];
+                        o[1] = o[3];
+                    }
                 }
-                if (ABL(1024)) {
-                    z0 = u0 - 0.5;
-                    z1 = u1 - 0.5;
-                } else {
-                    // the table row of a position does not change from pass to pass: with direct
-                    // windows `nf` is free and holds it (filled below, before the first pass)
-                    const int ei = direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp);
-                    nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, u0, u1, z0, z1);
-                }
-                if (!direct) {
-                    const bool f0 = isfinite(z0), f1 = isfinite(z1);
-                    z0 = f0 ? z0 : 0.0;
-                    z1 = f1 ? z1 : 0.0;
-                    zc = (f0 ? 0 : 1) | (f1 ? 0 : 1 << 16);
-                }
+                // the table row of a position does not change from pass to pass: with direct
+                // windows `nf` is free and holds it (filled above, before the first pass)
+                ei = direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp);
             }
-            if (direct) {
-                if (t < L) {
-                    zb[t] = z0;
-                    zb1[t] = z1;
+            // one pair of draws at a time (ONE copy of the sampler's code, few live registers): with
+            // direct windows the pair's z go straight to their buffers, with wide ones through the scans
+            const int npairs = (direct && ns > 2) ? 2 : 1;
+#pragma clang loop unroll(disable)
+            for (int pr = 0; pr < npairs; ++pr) {
+                // u = (word + 1/2) 2^-32 (philox_uniform4), or the caller's uniforms (tests)
+                double ua = ((double)(pr ? o[2] : o[0]) + 0.5) * (1.0 / 4294967296.0);
+                double ub = ((double)(pr ? o[3] : o[1]) + 0.5) * (1.0 / 4294967296.0);
+                if (up && t < L) {
+                    ua = up[2 * pr];
+                    ub = 2 * pr + 1 < ns ? up[2 * pr + 1] : 0.5;
                 }
-            } else {
-                zb[t] = scan_add(z0);
-                zb1[t] = scan_add(z1);
-                nf[t] = scan_add(zc);
+                if (ABL(512)) {
+                    ua = 0.37 + 1e-3 * s + 0.04 * pr;
+                    ub = 0.63 - 1e-3 * s - 0.04 * pr;
+                }
+                double za = 0.0, zb_ = 0.0;
+                if (t < L) {
+                    if (ABL(1024)) {
+                        za = ua - 0.5;
+                        zb_ = ub - 0.5;
+                    } else {
+                        nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, ua, ub, za, zb_);
+                    }
+                }
+                if (direct) {
+                    if (t < L) {
+                        zq[(2 * pr) * n2 + t] = za;
+                        zq[(2 * pr + 1) * n2 + t] = zb_;
+                    }
+                } else {
+                    const bool f0 = isfinite(za), f1 = isfinite(zb_);
+                    const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
+                    zq[t] = scan_add(f0 ? za : 0.0);
+                    zq[n2 + t] = scan_add(f1 ? zb_ : 0.0);
+                    nf[t] = scan_add(zc);
+                }
             }
         }
         __syncthreads();
         for (int t = tid; t < L; t += NT) {
-            // y of the two null windows: NaN when a z in the window is not finite, +inf stands for
+            // y of the null windows: NaN when a z in the window is not finite, +inf stands for
             // the edges, whose window p-value is the constant 1.0 (windowing.pyx:51) and which are
             // part of the pooled null
-            double y0 = fptm::kInf, y1 = fptm::kInf;
+            double y[4] = {fptm::kInf, fptm::kInf, fptm::kInf, fptm::kInf};
             if (direct) {
                 if (t >= hs && t < L - hs) {
-                    double s0 = 0.0, s1 = 0.0;
+                    double sm[4] = {0.0, 0.0, 0.0, 0.0};
                     for (int j = t - hs; j <= t + hs; ++j) {
-                        s0 += zb[j];
-                        s1 += zb1[j];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) sm[w] += zq[w * n2 + j];
                     }
-                    y0 = isfinite(s0) ? -(s0 * a.inv_sqrt_k) : NAN;
-                    y1 = isfinite(s1) ? -(s1 * a.inv_sqrt_k) : NAN;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) y[w] = isfinite(sm[w]) ? -(sm[w] * a.inv_sqrt_k) : NAN;
                 }
             } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
-                const double s0 = le3 ? tile_range_sum3(zb, t - hs, t + hs) : tile_range_sum(zb, t - hs, t + hs);
-                const double s1 = le3 ? tile_range_sum3(zb1, t - hs, t + hs) : tile_range_sum(zb1, t - hs, t + hs);
+                const double s0 = le3 ? tile_range_sum3(zq, t - hs, t + hs) : tile_range_sum(zq, t - hs, t + hs);
+                const double s1 = le3 ? tile_range_sum3(zq + n2, t - hs, t + hs) : tile_range_sum(zq + n2, t - hs, t + hs);
                 const int sc = le3 ? tile_range_sum3(nf, t - hs, t + hs) : tile_range_sum(nf, t - hs, t + hs);
-                y0 = (sc & 0xffff) ? NAN : -(s0 * a.inv_sqrt_k);
-                y1 = (sc >> 16) ? NAN : -(s1 * a.inv_sqrt_k);
+                y[0] = (sc & 0xffff) ? NAN : -(s0 * a.inv_sqrt_k);
+                y[1] = (sc >> 16) ? NAN : -(s1 * a.inv_sqrt_k);
             }
             if (a.null_out) {  // the p-values themselves only when somebody wants them
                 double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
-                np_[0] = y0 == fptm::kInf ? 1.0 : fptm::ndtr(y0);
-                if (two) np_[1] = y1 == fptm::kInf ? 1.0 : fptm::ndtr(y1);
+                for (int w = 0; w < ns; ++w) np_[w] = y[w] == fptm::kInf ? 1.0 : fptm::ndtr(y[w]);
             }
             if (ABL(4096)) {
-                if (y0 == 12345.0 || y1 == 12345.0) atomicAdd(&misc[0], 1);
+                if (y[0] == 12345.0 || y[1] == 12345.0 || y[2] == 12345.0 || y[3] == 12345.0) atomicAdd(&misc[0], 1);
                 continue;
             }
-            // rank = #{thresholds <= y}: bisect inside the guide's bracket, both samples in step
+            // rank = #{thresholds <= y}: bisect inside the guide's bracket, two samples in step
             // (for NaN the result is unused; +inf gets the precomputed rank of 1.0)
-            int b0 = (y0 > -kYR) ? (int)((y0 + kYR) * yscale) : 0, b1 = (y1 > -kYR) ? (int)((y1 + kYR) * yscale) : 0;
-            b0 = (b0 < nb && y0 < kYR) ? b0 : nb - 1;
-            b1 = (b1 < nb && y1 < kYR) ? b1 : nb - 1;
-            int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
-            while (l0 < h0 || l1 < h1) {
-                const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;  // < m whenever that side is live
-                const bool g0 = skey[m0] <= y0, g1 = skey[m1] <= y1;
-                if (l0 < h0) {
-                    l0 = g0 ? m0 + 1 : l0;
-                    h0 = g0 ? h0 : m0;
+            const int npairs = ns > 2 ? 2 : 1;
+#pragma clang loop unroll(disable)
+            for (int pr = 0; pr < npairs; ++pr) {
+                const double y0 = pr ? y[2] : y[0], y1 = pr ? y[3] : y[1];
+                int b0 = (y0 > -kYR) ? (int)((y0 + kYR) * yscale) : 0, b1 = (y1 > -kYR) ? (int)((y1 + kYR) * yscale) : 0;
+                b0 = (b0 < nb && y0 < kYR) ? b0 : nb - 1;
+                b1 = (b1 < nb && y1 < kYR) ? b1 : nb - 1;
+                int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
+                while (l0 < h0 || l1 < h1) {
+                    const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;  // < m whenever that side is live
+                    const bool g0 = skey[m0] <= y0, g1 = skey[m1] <= y1;
+                    if (l0 < h0) {
+                        l0 = g0 ? m0 + 1 : l0;
+                        h0 = g0 ? h0 : m0;
+                    }
+                    if (l1 < h1) {
+                        l1 = g1 ? m1 + 1 : l1;
+                        h1 = g1 ? h1 : m1;
+                    }
                 }
-                if (l1 < h1) {
-                    l1 = g1 ? m1 + 1 : l1;
-                    h1 = g1 ? h1 : m1;
-                }
+                l0 = y0 == fptm::kInf ? rank_one : l0;
+                l1 = y1 == fptm::kInf ? rank_one : l1;
+                atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
+                if (2 * pr + 1 < ns) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
             }
-            l0 = y0 == fptm::kInf ? rank_one : l0;
-            l1 = y1 == fptm::kInf ? rank_one : l1;
-            atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
-            if (two) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
         }
         if (!alternate) __syncthreads();
     }
@@ -2112,7 +2118,7 @@ size_t nb_guide_bytes(int n_models, int memo_exp) {
 }
 
 size_t fdr_lds_bytes(int n2, bool dbuf) {
-    return (size_t)(24 + (dbuf ? 5 : 3) * (size_t)n2) * sizeof(double) +
+    return (size_t)(24 + (dbuf ? 9 : 5) * (size_t)n2) * sizeof(double) +
            (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
 }
 

@@ -1101,13 +1101,11 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 void orc_philox_raw(uint32_t *c4, uint32_t k0, uint32_t k1) { philox4x32_10(c4, k0, k1); }
 
-/* sample 2j uses words (0,1), sample 2j+1 words (2,3) of the Philox block with counter word 2 = j */
+/* sample 4j + w uses word w of the Philox block with counter word 2 = j: u = (word + 1/2) 2^-32 */
 double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
-    uint32_t c[4] = {(uint32_t)base, (uint32_t)(base >> 32), sample >> 1, 0x66707464u};
+    uint32_t c[4] = {(uint32_t)base, (uint32_t)(base >> 32), sample >> 2, 0x66707464u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    int w = (sample & 1u) ? 2 : 0;
-    uint64_t x = ((uint64_t)c[w + 1] << 32) | c[w];
-    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    return ((double)c[sample & 3u] + 0.5) * (1.0 / 4294967296.0);
 }
 
 /* smallest k with cdf(k) >= u -> cdf(k); table_k = number of tabulated k per integer exp */
