@@ -474,6 +474,12 @@ def main():
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),
                         traffic_bytes_per_launch=traffic_bytes,
+                        # `traffic` is NOT a counter read in this run: it is the HBM bytes per launch that
+                        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measured in a separate run of the same
+                        # command (profiles/traffic.json, summaries under profiles/), over this run's kernel time
+                        traffic_source=("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this "
+                                        "workload in a separate run (gfx950 corrections applied), divided by "
+                                        "this run's kernel_ms") if traffic_bytes else None,
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))
         out = {
             "metric": "bases/sec per-nucleotide footprint stats",

@@ -948,6 +948,19 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     return launch_ok("k_posterior");
 }
 
+int fpt_detect_columns_dev(fpt_ctx *c, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off_dev,
+                           int64_t total_bases, const int32_t *status_dev, const double *exp_dev, const double *obs_dev,
+                           const double *pval_dev, const double *winp_dev, const double *efdr_dev, double *out_dev) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_intervals < 0 || total_bases < 0) return fail(FPT_ERR_INVALID, "negative size");
+    if (total_bases == 0) return FPT_OK;
+    if (!exp_dev || !obs_dev || !pval_dev || !winp_dev || !efdr_dev || !out_dev) return fail(FPT_ERR_INVALID, "null track");
+    if (status_dev && !interval_off_dev && interval_len <= 0) return fail(FPT_ERR_INVALID, "interval_len must be positive");
+    fptk::launch_detect_columns(c->stream, n_intervals, interval_len, interval_off_dev, status_dev, exp_dev, obs_dev,
+                                pval_dev, winp_dev, efdr_dev, total_bases, out_dev);
+    return launch_ok("k_detect_columns");
+}
+
 int fpt_hist2d_dev(fpt_ctx *c, const double *exp_dev, const double *obs_dev, int64_t n, int rows, int cols,
                    uint64_t *hist_dev) {
     if (int rc = check_ctx(c)) return rc;

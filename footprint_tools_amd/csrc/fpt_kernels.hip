@@ -1732,6 +1732,47 @@ template __global__ void k_fdr_null<192, false>(const fdr_args);  // 129..192 ba
 template __global__ void k_fdr_null<256, true>(const fdr_args);
 
 // ===========================================================================
+// k_detect_columns: the record columns of `ftd detect` for a whole batch (cli/detect.py:136-146):
+//   stats = column_stack((exp, obs, -log(pvals), -log(win_pvals), efdr)), rows = bases
+// and, for an interval whose statistics the reference could not compute (its `except Exception`
+// branch, here: the status word of the scan), pvals = win_pvals = efdr = 1.  One lane per base;
+// the five values of a base are 40 consecutive bytes of the output.
+// ===========================================================================
+__global__ void __launch_bounds__(256) k_detect_columns(int64_t n_intervals, int32_t interval_len,
+                                                        const int64_t *__restrict__ interval_off,
+                                                        const int32_t *__restrict__ status,
+                                                        const double *__restrict__ ex, const double *__restrict__ ob,
+                                                        const double *__restrict__ pv, const double *__restrict__ wp,
+                                                        const double *__restrict__ ef, int64_t total,
+                                                        double *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        bool failed = false;
+        if (status) {
+            int64_t iv;
+            if (interval_off) {  // the interval of base g: last offset <= g
+                int64_t lo = 0, hi = n_intervals;
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (interval_off[mid] <= g) lo = mid; else hi = mid;
+                }
+                iv = lo;
+            } else {
+                iv = g / interval_len;
+            }
+            failed = status[iv] != 0;
+        }
+        const double p = failed ? 1.0 : pv[g], w = failed ? 1.0 : wp[g], f = failed ? 1.0 : ef[g];
+        double *o = out + g * 5;
+        o[0] = ex[g];
+        o[1] = ob[g];
+        o[2] = -log(p);
+        o[3] = -log(w);
+        o[4] = f;
+    }
+}
+
+// ===========================================================================
 // k_hist2d: hist[int(exp), int(obs)] += 1 (cli/learn_dm.py:276-287), pairs outside the
 // histogram ignored.  The dense low corner (64 x 64 bins) is accumulated per workgroup in LDS,
 // the rest goes straight to global atomics.
@@ -2197,6 +2238,14 @@ void launch_segment(hipStream_t st, const segment_launch &sl, bool fill) {
     const unsigned grid = (unsigned)((sl.n_intervals + 3) / 4);
     if (fill) hipLaunchKernelGGL(k_segment<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_segment<false>, dim3(grid), dim3(256), 0, st, a);
+}
+
+void launch_detect_columns(hipStream_t st, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off,
+                           const int32_t *status, const double *ex, const double *ob, const double *pv,
+                           const double *wp, const double *ef, int64_t total, double *out) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_detect_columns, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, n_intervals, interval_len,
+                       interval_off, status, ex, ob, pv, wp, ef, total, out);
 }
 
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,

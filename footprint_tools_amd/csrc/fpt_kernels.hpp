@@ -142,6 +142,9 @@ void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo
                     int32_t *clear = nullptr, int64_t n_clear = 0, int32_t *state = nullptr);
 void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
                      int memo_obs, int rows, int stride, void *memo2);
+void launch_detect_columns(hipStream_t st, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off,
+                           const int32_t *status, const double *ex, const double *ob, const double *pv,
+                           const double *wp, const double *ef, int64_t total, double *out);
 void launch_hist2d(hipStream_t st, const double *ex, const double *ob, int64_t n, int rows, int cols,
                    unsigned long long *hist);
 void launch_synth(hipStream_t st, uint64_t seed, int64_t pos0_counts, int64_t n_counts,

@@ -129,14 +129,21 @@ class deviation_stats(object):
                                d_out.ptr + (3 + S) * t8 + int(off[a]) * 8, times=self.fdr_shuffle_n, seed=self.seed,
                                half_win_width=3, interval_off_dev=d_roff.ptr,
                                base_index0=int(self._bases_before[indices[a]]))
+            if self.dm:
+                # the five record columns (detect.py:142-144, and the fallback rows of :136-140)
+                # assembled on the device: one download of the (bases, 5) matrix
+                d_tab = DeviceArray(ctx, max(5 * t8, 16)); bufs.append(d_tab)
+                _lib.check(ctx.L.fpt_detect_columns_dev(ctx.h, n_iv, 0, d_off.ptr, total, d_st.ptr, d_out.ptr,
+                                                        d_out.ptr + t8, d_out.ptr + 2 * t8, d_out.ptr + 3 * t8,
+                                                        d_out.ptr + (3 + S) * t8, d_tab.ptr))
+                ctx.synchronize()
+                return d_tab.download(np.float64, 5 * total).reshape(total, 5), None
             ctx.synchronize()
-            flat = d_out.download(np.float64, n_tracks * total).reshape(n_tracks, total)
-            status = d_st.download(np.int32, n_iv)
+            flat = d_out.download(np.float64, 2 * total).reshape(2, total)
         finally:
             for x in bufs:
                 x.free()
-        res = dict(exp=flat[0], obs=flat[1], pval=flat[2], winp=flat[3:3 + S], status=status)
-        return res, (flat[3 + S] if self.dm else None)
+        return dict(exp=flat[0], obs=flat[1]), None
 
     def compute(self, indices):
         """statistics of intervals `indices` (one GPU batch); list of {"interval", "stats"}"""
@@ -149,6 +156,8 @@ class deviation_stats(object):
         sc = self._scanner()
         if self._device_inputs():  # (strand '-' intervals included: cut_counts_dev mirrors and swaps their counts)
             res, efdr = self._compute_on_device(indices, ivs, lens, off)
+            if self.dm:  # the (bases, 5) table came back assembled
+                return [{"interval": iv, "stats": res[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])]
         else:
             cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
             for L, cp, sq in zip(lens, cps, sqs):

@@ -271,6 +271,17 @@ typedef struct fpt_posterior_desc {
 } fpt_posterior_desc;
 int fpt_posterior_dev(fpt_ctx *ctx, const fpt_posterior_desc *desc);
 
+/* The record columns of `ftd detect` for a whole batch, on the device (cli/detect.py:136-146):
+ *     stats = np.column_stack((exp, obs, -np.log(pvals), -np.log(win_pvals), efdr))
+ * into out_dev, a DEVICE (total_bases, 5) row-major matrix whose slice per interval is that
+ * interval's `stats`; where status[i] != 0 (the scan's per-interval status: the reference's
+ * `except Exception` branch, detect.py:136-140) interval i gets pvals = win_pvals = efdr = 1.
+ * All tracks are DEVICE arrays of total_bases doubles; status may be NULL.  Enqueued on the
+ * context's stream; no synchronisation. */
+int fpt_detect_columns_dev(fpt_ctx *ctx, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off_dev,
+                           int64_t total_bases, const int32_t *status_dev, const double *exp_dev, const double *obs_dev,
+                           const double *pval_dev, const double *winp_dev, const double *efdr_dev, double *out_dev);
+
 /* (exp, obs) histogram of `ftd learn_dm` (cli/learn_dm.py:276-287): hist[int(exp), int(obs)] += 1
  * for the n pairs of two DEVICE tracks, pairs outside the rows x cols histogram (the reference
  * uses 200 x 1000) ignored like its IndexError branch; negative or non-finite values are

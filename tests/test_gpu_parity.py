@@ -1140,7 +1140,9 @@ def test_detect_driver_against_the_reference_driver(fpt, tmp_path):
     ds_host = detect.deviation_stats(ivs, OnlyLookup(), OnlyFetch(), bm, dm, fdr_shuffle_n=50, seed=7, **kw)
     assert not ds_host._device_inputs()
     for r1, r2 in zip(recs, ds_host.compute([0, 1]) + ds_host.compute([2, 3, 4])):
-        assert np.array_equal(r1["stats"], r2["stats"], equal_nan=True)
+        # the batched path takes -log on the device, this one with numpy: an ulp apart at most
+        assert np.array_equal(r1["stats"][:, [0, 1, 4]], r2["stats"][:, [0, 1, 4]], equal_nan=True)
+        assert np.allclose(r1["stats"][:, 2:4], r2["stats"][:, 2:4], rtol=1e-14, atol=0, equal_nan=True)
     for r1, r2 in zip(recs[1:4], ds.compute([1, 2, 3])):  # a sub-batch on the device: same records
         assert np.array_equal(r1["stats"], r2["stats"], equal_nan=True)
     n_called = 0
