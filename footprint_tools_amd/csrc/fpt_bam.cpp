@@ -35,39 +35,14 @@
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
 
+#include "fpt_bgzf.hpp"
+
 namespace {
 
+using fptz::bgzf_block;
+using fptz::bgzf_member_size;
+using fptz::kMaxBlock;
 constexpr size_t kChunk = (size_t)32 << 20;  // compressed bytes taken from the file at a time
-constexpr size_t kMaxBlock = 1 << 16;        // a BGZF member is at most 64 KiB, and so is what it holds
-
-struct bgzf_block {
-    size_t cpos;   // deflate payload inside the chunk
-    uint32_t clen; // its length
-    uint32_t isize, crc;
-    size_t opos;   // where the inflated bytes go
-};
-
-// header of the gzip member at p (n bytes available): total member size through the BC subfield.
-// Returns 0 when more bytes are needed, -1 when it is not a BGZF member.
-long bgzf_member_size(const unsigned char *p, size_t n, size_t *payload_off) {
-    if (n < 18) return 0;
-    if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return -1;
-    const size_t xlen = p[10] | (size_t)p[11] << 8;
-    if (n < 12 + xlen) return xlen > 4096 ? -1 : 0;
-    size_t q = 12;
-    long bsize = -1;
-    while (q + 4 <= 12 + xlen) {
-        const size_t slen = p[q + 2] | (size_t)p[q + 3] << 8;
-        if (q + 4 + slen > 12 + xlen) return -1;
-        if (p[q] == 66 && p[q + 1] == 67 && slen == 2) bsize = (long)(p[q + 4] | (size_t)p[q + 5] << 8);
-        q += 4 + slen;
-    }
-    if (bsize < 0) return -1;
-    const long total = bsize + 1;
-    if ((size_t)total < 12 + xlen + 8) return -1;  // no room for CRC32 + ISIZE
-    *payload_off = 12 + xlen;
-    return total;
-}
 
 }  // namespace
 
@@ -124,28 +99,11 @@ struct fpt_bam {
         std::atomic<size_t> next(0);
         std::atomic<int> bad(0);
         auto work = [&]() {
-            z_stream zs;
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= blocks.size() || bad.load()) return;
                 const bgzf_block &b = blocks[i];
-                if (b.isize == 0) {  // the end-of-file marker (and any other empty member) holds nothing
-                    if (b.crc != 0) bad.store(2);
-                    continue;
-                }
-                std::memset(&zs, 0, sizeof zs);
-                if (inflateInit2(&zs, -15) != Z_OK) {
-                    bad.store(1);
-                    return;
-                }
-                zs.next_in = in.data() + b.cpos;
-                zs.avail_in = b.clen;
-                zs.next_out = out.data() + base + b.opos;
-                zs.avail_out = b.isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                const bool ok = (rc == Z_STREAM_END) && zs.avail_out == 0 && zs.avail_in == 0;
-                inflateEnd(&zs);
-                if (!ok || (uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + base + b.opos, b.isize) != b.crc) {
+                if (!fptz::inflate_block(in.data() + b.cpos, b.clen, out.data() + base + b.opos, b.isize, b.crc)) {
                     bad.store(2);
                     return;
                 }
@@ -160,7 +118,7 @@ struct fpt_bam {
             for (std::thread &t : team) t.join();
         }
         if (bad.load()) {
-            error = bad.load() == 1 ? "inflateInit2 failed" : "corrupt BGZF block";
+            error = "corrupt BGZF block";
             return false;
         }
         std::memmove(in.data(), in.data() + p, in_len - p);

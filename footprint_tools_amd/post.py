@@ -46,23 +46,22 @@ class posterior_stats(object):
 
     def load_batch(self, intervals):
         """The (datasets, bases) arrays obs, exp, fdr, w of cli/post.py:57-87 for `intervals` back
-        to back, and the offsets of the intervals in them."""
+        to back, and the offsets of the intervals in them.  One batched, threaded fetch per dataset
+        (tabix.TabixFile.fetch_batch): column 3 = exp, 4 = obs, 7 = fdr, w = 1 where the track has a row."""
         if len(self.tabix_files) == 0:
             self._open_tabix_files()
         off = np.concatenate([[0], np.cumsum([len(iv) for iv in intervals])]).astype(np.int64)
         n, total = len(self.tabix_files), int(off[-1])
         obs, exp = np.zeros((n, total)), np.zeros((n, total))
         fdr, w = np.ones((n, total)), np.zeros((n, total))
+        chroms = [iv.chrom for iv in intervals]
+        starts = np.array([iv.start for iv in intervals], dtype=np.int64)
+        ends = np.array([iv.end for iv in intervals], dtype=np.int64)
         for i, tbf in enumerate(self.tabix_files):
-            for iv, a in zip(intervals, off[:-1]):
-                try:
-                    pos, vals = tbf.fetch_columns(iv.chrom, iv.start, iv.end)
-                except Exception:  # the reference logs and carries on with what it has (post.py:84-85)
-                    continue
-                if pos.size == 0:
-                    continue
-                j = a + (pos - iv.start)
-                exp[i, j], obs[i, j], fdr[i, j], w[i, j] = vals[:, 2], vals[:, 3], vals[:, 6], 1.0
+            try:
+                tbf.fetch_batch(chroms, starts, ends, [3, 4, 7], out_off=off, out=[exp[i], obs[i], fdr[i]], present=w[i])
+            except Exception:  # the reference logs and carries on with what it has (post.py:84-85)
+                continue
         return obs, exp, fdr, w, off
 
     def _load_data(self, interval):

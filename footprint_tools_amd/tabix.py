@@ -1,55 +1,103 @@
 """Per-nucleotide statistics tracks written by `ftd detect` (bgzip-compressed bedGraph, indexed
-with tabix in the reference's workflow) -- read access without pysam / htslib.
+with tabix in the reference's workflow) -- indexed region access without pysam / htslib.
 
 The reference opens them with `pysam.TabixFile(fn)` and walks `fetch(chrom, start, end,
-parser=pysam.asTuple())` per interval (cli/post.py:52-87).  BGZF is a chain of gzip members, which
-the standard library inflates; the track is parsed once into columns and `fetch` answers from
-memory by binary search (rows of a track are sorted by position within a chromosome).  This holds
-a whole track in memory: meant for the hotspot-restricted tracks the posterior caller reads, not
-for genome-wide dumps.  Parity of the reader is unpinned (no pysam here); the column meaning is
-the reference's writer's (cli/utils.py:119-144: chrom, start, start+1, exp, obs, -log p,
--log win-p, fdr).
+parser=pysam.asTuple())` per interval (cli/post.py:52-87).  `TabixFile` here keeps that call
+surface over the library's own reader (fpt_track_* of include/fpt.h, fpt_track.cpp): the file is
+mapped, `<file>.tbi` is used when present (else an index of the same shape is built by one pass at
+open), a query inflates only the BGZF members it needs, and `fetch_batch` serves a whole interval
+list on a team of threads, scattering the wanted columns straight into (bases) arrays -- the loop
+of `_load_data` (cli/post.py:70-83) for all intervals at once.  Parity of the reader is unpinned
+(no pysam here); the column meaning is the reference's writer's (cli/utils.py:119-144: chrom,
+start, start+1, exp, obs, -log p, -log win-p, fdr).
 """
-import gzip
-import io
+import ctypes as C
 
 import numpy as np
+
+from . import _lib
+
+
+def _bind(L):
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.fpt_track_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fpt_track_close.argtypes = [vp]
+    L.fpt_track_n_refs.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fpt_track_ref.argtypes = [vp, i32, C.c_char_p, i32]
+    L.fpt_track_fetch.argtypes = [vp, i64, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.fpt_track_fetch_rows.argtypes = [vp, C.c_char_p, i64, i64, i32, vp, i64, vp, vp, C.POINTER(i64)]
+    return L
 
 
 class TabixFile(object):
     def __init__(self, filename):
         self.filename = filename
-        self._by_chrom = None
-        with open(filename, "rb") as f:  # fail now, like pysam does, if the file is not there
-            magic = f.read(2)
-        self._gz = magic == b"\x1f\x8b"
+        self.L = _bind(_lib.load())
+        h = C.c_void_p()
+        try:
+            _lib.check(self.L.fpt_track_open(str(filename).encode(), C.byref(h)))
+        except ValueError as e:  # like pysam: a file that is not there (or not a track) fails at open
+            raise IOError(str(e))
+        self.h = h
+        n, idx = C.c_int32(), C.c_int32()
+        _lib.check(self.L.fpt_track_n_refs(h, C.byref(n), C.byref(idx)))
+        self.has_tbi = bool(idx.value)
+        buf = C.create_string_buffer(4096)
+        self.contigs = []
+        for i in range(n.value):
+            _lib.check(self.L.fpt_track_ref(h, i, buf, 4096))
+            self.contigs.append(buf.value.decode())
 
-    def _load(self):
-        import pandas as pd
-        opener = gzip.open if self._gz else open
-        with opener(self.filename, "rb") as f:
-            text = f.read()
-        tab = pd.read_csv(io.BytesIO(text), sep="\t", header=None, comment="#", dtype={0: str})
-        self._by_chrom = {}
-        for chrom, part in tab.groupby(0, sort=False):
-            part = part.sort_values(1, kind="stable")
-            self._by_chrom[chrom] = (part[1].to_numpy(np.int64), part.iloc[:, 1:].to_numpy(np.float64))
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fpt_track_close(self.h)
+            self.h = None
 
-    def fetch_columns(self, chrom, start, end):
-        """(positions, values): rows with start <= position < end; values[:, k] is file column k+1."""
-        if self._by_chrom is None:
-            self._load()
-        if chrom not in self._by_chrom:
-            return np.zeros(0, np.int64), np.zeros((0, 0))
-        pos, vals = self._by_chrom[chrom]
-        a, b = np.searchsorted(pos, start, "left"), np.searchsorted(pos, end, "left")
-        return pos[a:b], vals[a:b]
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fetch_columns(self, chrom, start, end, cols=None, n_cols=8):
+        """(positions, values): rows with start <= position < end.  values[:, k] is file column
+        cols[k] (0-based), by default columns 1 .. n_cols-1 (so values[:, k] is file column k+1)."""
+        cols = np.arange(1, n_cols, dtype=np.int32) if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        cap = max(int(end) - int(start), 0) + 16
+        while True:
+            pos = np.empty(cap, np.int64)
+            vals = np.empty((cap, cols.size), np.float64)
+            n = C.c_int64()
+            _lib.check(self.L.fpt_track_fetch_rows(self.h, str(chrom).encode(), int(start), int(end), cols.size,
+                                                   cols.ctypes.data, cap, pos.ctypes.data, vals.ctypes.data, C.byref(n)))
+            if n.value <= cap:
+                return pos[:n.value], vals[:n.value]
+            cap = n.value  # rows wider or denser than one per base: again with room
 
     def fetch(self, chrom, start, end, parser=None):
         """rows as tuples of strings, like pysam's asTuple parser"""
         pos, vals = self.fetch_columns(chrom, start, end)
         for p, row in zip(pos, vals):
-            yield (chrom,) + tuple(repr(int(v)) if k < 2 else repr(float(v)) for k, v in enumerate(row))
+            yield (chrom, repr(int(p))) + tuple(repr(int(v)) if k == 0 else repr(float(v)) for k, v in enumerate(row))
 
-    def close(self):
-        self._by_chrom = None
+    def fetch_batch(self, chroms, starts, ends, cols, out_off=None, out=None, present=None):
+        """The rows of many intervals scattered into (bases) arrays: for a row at position x of
+        interval i, out[k][out_off[i] + x - starts[i]] = file column cols[k] and present[...] = 1.
+        Returns (out, present, out_off); arrays not given are made (nan / 0-filled)."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        n = starts.size
+        if out_off is None:
+            out_off = np.concatenate([[0], np.cumsum(np.maximum(ends - starts, 0))]).astype(np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        total = int(out_off[-1]) if out_off.size > n else int((out_off + np.maximum(ends - starts, 0)).max(initial=0))
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        if out is None:
+            out = [np.full(total, np.nan) for _ in range(cols.size)]
+        if present is None:
+            present = np.zeros(total)
+        names = (C.c_char_p * max(n, 1))(*[str(c).encode() for c in chroms])
+        ptrs = (C.c_void_p * max(cols.size, 1))(*[a.ctypes.data for a in out])
+        _lib.check(self.L.fpt_track_fetch(self.h, n, names, starts.ctypes.data, ends.ctypes.data, out_off.ctypes.data,
+                                          cols.size, cols.ctypes.data, ptrs, present.ctypes.data))
+        return out, present, out_off

@@ -366,6 +366,27 @@ typedef struct fpt_cutcount_desc {
 } fpt_cutcount_desc;
 int fpt_cut_counts_dev(fpt_ctx *ctx, const fpt_cutcount_desc *d);
 
+/* ---- statistics tracks (host only): indexed region access to the
+ * bgzip-compressed bedGraph files `ftd detect` writes (cli/utils.py:119-144), which the posterior
+ * caller reads back per interval through pysam.TabixFile.fetch (cli/post.py:52-87).  The file is
+ * mapped; `<path>.tbi` (tabix's linear index) is used when present, else an index of the same shape
+ * is built by one pass at open.  Rows are selected by their start column: start <= row start < end.
+ * fpt_track_fetch serves a batch of intervals on a team of threads: for every row of interval i,
+ * out[c][out_off[i] + (row start - starts[i])] = the value of file column cols[c] (0-based; nan
+ * where it does not parse) and present[...] = 1 -- the loop of `_load_data` (cli/post.py:70-83);
+ * the caller pre-fills the defaults.  fpt_track_fetch_rows returns the rows of one region
+ * (*n_out = rows found; only the first `cap` are stored). */
+typedef struct fpt_track fpt_track;
+int fpt_track_open(const char *path, fpt_track **out);
+int fpt_track_close(fpt_track *t);
+int fpt_track_n_refs(fpt_track *t, int32_t *n_out, int32_t *indexed_out /* 1 = a .tbi was used */);
+int fpt_track_ref(fpt_track *t, int32_t i, char *name_out, int32_t cap);
+int fpt_track_fetch(fpt_track *t, int64_t n_intervals, const char *const *chroms, const int64_t *starts,
+                    const int64_t *ends, const int64_t *out_off, int32_t n_cols, const int32_t *cols,
+                    double *const *out, double *present);
+int fpt_track_fetch_rows(fpt_track *t, const char *chrom, int64_t start, int64_t end, int32_t n_cols,
+                         const int32_t *cols, int64_t cap, int64_t *pos_out, double *vals_out, int64_t *n_out);
+
 /* ---- the one collective of the sharded job (BASELINE.json north_star: "a
  * single RCCL all-gather over xGMI at the end to reassemble the per-base statistics track").
  * Intervals shard across GPUs with no communication during the scan (one process and one

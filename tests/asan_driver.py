@@ -14,6 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.bamwriter import _bgzf_block, write_bam  # noqa: E402
+from tests.tbiwriter import write_bgzf_with_tbi  # noqa: E402
 
 L = C.CDLL(os.path.join(ROOT, "footprint_tools_amd", "libfpt_host_asan.so"))
 vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
@@ -22,6 +23,24 @@ L.fpt_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
 L.fpt_bam_close.argtypes = [vp]
 L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
 L.fpt_format_stats.argtypes = [C.c_char_p, i64, vp, i64, i32, vp, i64, C.c_char, i32, vp, i64, C.POINTER(i64)]
+L.fpt_track_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+L.fpt_track_close.argtypes = [vp]
+L.fpt_track_fetch_rows.argtypes = [vp, C.c_char_p, i64, i64, i32, vp, i64, vp, vp, C.POINTER(i64)]
+L.fpt_track_fetch.argtypes = [vp, i64, vp, vp, vp, vp, i32, vp, vp, vp]
+
+
+def track_rows(path, chrom, a, b):
+    """(rc_open, rc_fetch, n_rows) of one region query"""
+    h = vp()
+    rc = L.fpt_track_open(path.encode(), C.byref(h))
+    if rc:
+        return rc, 0, 0
+    cols = np.array([3, 4, 7], np.int32)
+    cap = max(b - a, 1)
+    pos, vals, n = np.empty(cap, np.int64), np.empty((cap, 3)), i64()
+    rc2 = L.fpt_track_fetch_rows(h, chrom.encode(), a, b, 3, cols.ctypes.data, cap, pos.ctypes.data, vals.ctypes.data, C.byref(n))
+    L.fpt_track_close(h)
+    return 0, rc2, n.value
 
 
 def read_all(path, batch=500):
@@ -119,6 +138,49 @@ def main(tmp):
     case("n_cig_past.bam", bam_bytes([record(n_cig=60000)]), expect_reads=1)
     case("l_name_past.bam", bam_bytes([record(l_name=255)]), expect_reads=1)
     case("no_cigar.bam", bam_bytes([record(n_cig=0, cig=())]), expect_reads=1)
+
+    # ---- statistics tracks: region access with and without a tabix index, then damaged files
+    lines = [b"#header"]
+    tpos = np.sort(rs.choice(60000, 9000, replace=False))
+    for p_ in tpos:
+        lines.append(("chr1\t%d\t%d\t%.4f\t%.4f\t0.5\t0.5\t%.4f" % (p_, p_ + 1, rs.rand() * 9, rs.rand() * 9, rs.rand())).encode())
+    ttext = b"\n".join(lines) + b"\n"
+    for with_tbi in (True, False):
+        tp = os.path.join(tmp, "track%d.gz" % with_tbi)
+        write_bgzf_with_tbi(tp, ttext, block_bytes=2100, tbi=with_tbi)
+        for a, b in ((0, 60000), (100, 101), (16384, 40000), (59990, 70000)):
+            assert track_rows(tp, "chr1", a, b) == (0, 0, int(((tpos >= a) & (tpos < b)).sum())), (with_tbi, a, b)
+        assert track_rows(tp, "chr9", 0, 100) == (0, 0, 0)
+        traw = open(tp, "rb").read()
+        for k in range(40):
+            bb = bytearray(traw)
+            bb[int(rs.randint(0, len(traw) - 28))] ^= 1 << int(rs.randint(0, 8))
+            dp = os.path.join(tmp, "track_flip.gz")
+            with open(dp, "wb") as f:
+                f.write(bytes(bb))
+            if with_tbi:
+                import shutil
+                shutil.copy(tp + ".tbi", dp + ".tbi")
+            elif os.path.exists(dp + ".tbi"):
+                os.remove(dp + ".tbi")
+            track_rows(dp, "chr1", 0, 60000)  # an error or not: no sanitizer report
+        for cut in (10, len(traw) // 3, len(traw) - 40):
+            dp = os.path.join(tmp, "track_cut.gz")
+            with open(dp, "wb") as f:
+                f.write(traw[:cut])
+            track_rows(dp, "chr1", 0, 60000)
+    # a damaged index: bit flips in the .tbi
+    tp = os.path.join(tmp, "track1.gz")
+    iraw = open(tp + ".tbi", "rb").read()
+    for k in range(40):
+        bb = bytearray(iraw)
+        bb[int(rs.randint(0, len(iraw)))] ^= 1 << int(rs.randint(0, 8))
+        dp = os.path.join(tmp, "track_badidx.gz")
+        import shutil
+        shutil.copy(tp, dp)
+        with open(dp + ".tbi", "wb") as f:
+            f.write(bytes(bb))
+        track_rows(dp, "chr1", 0, 60000)
 
     # ---- text formatter: against Python's own formatting, serial and threaded, tight buffers
     for threads, n in (("1", 300), ("5", 40000)):

@@ -199,3 +199,102 @@ def test_sanitizer_build(tmp_path):
     text = out.stdout.decode()
     assert out.returncode == 0 and "ASAN-DRIVER OK" in text, text[-3000:]
     assert "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
+
+
+def _track_text(rs, chroms=(("chr1", 70000), ("chr2", 40000), ("chrX", 20000))):
+    """a position-sorted `detect` track with gaps; returns (text, {chrom: (pos, values)})"""
+    lines, truth = [b"# generated by a test"], {}
+    for name, length in chroms:
+        pos = np.flatnonzero(rs.rand(length) < 0.3) + 5
+        pos = pos[(pos < 100) | (pos > 20000)]  # windows of the linear index without a row
+        vals = np.round(rs.gamma(2.0, 5.0, (pos.size, 5)), 4)
+        truth[name] = (pos, vals)
+        for p, v in zip(pos, vals):
+            lines.append(("%s\t%d\t%d\t%.4f\t%.4f\t%.4f\t%.4f\t%.4f" % ((name, p, p + 1) + tuple(v))).encode())
+    return b"\n".join(lines) + b"\n", truth
+
+
+@pytest.mark.parametrize("form", ["bgzf+tbi", "bgzf", "plain"])
+def test_track_reader_region_access(tmp_path, form, monkeypatch):
+    """the library's tabix-style reader (fpt_track_*): region queries against the rows written, with
+    a .tbi (tabix linear index), with the index built at open, and on an uncompressed file; the
+    batched fetch scatters the wanted columns into (bases) arrays like cli/post.py:70-83."""
+    from footprint_tools_amd.tabix import TabixFile
+    from .tbiwriter import write_bgzf_with_tbi
+    rs = np.random.RandomState(12)
+    text, truth = _track_text(rs)
+    path = str(tmp_path / "t.bedgraph.gz")
+    if form == "plain":
+        path = str(tmp_path / "t.bedgraph")
+        open(path, "wb").write(text)
+    else:
+        write_bgzf_with_tbi(path, text, block_bytes=1777, tbi=(form == "bgzf+tbi"))
+    tb = TabixFile(path)
+    assert tb.has_tbi == (form == "bgzf+tbi") and tb.contigs == ["chr1", "chr2", "chrX"]
+    queries = [("chr1", 0, 50), ("chr1", 90, 20100), ("chr1", 5000, 9000), ("chr1", 30000, 30001), ("chr2", 39990, 50000),
+               ("chrX", 0, 20010), ("chr2", 16384, 32768), ("chrQ", 5, 50), ("chr1", 65000, 66000), ("chr1", 500000, 600000)]
+    for chrom, a, b in queries:
+        pos, vals = tb.fetch_columns(chrom, a, b)
+        tp, tv = truth.get(chrom, (np.zeros(0, int), np.zeros((0, 5))))
+        sel = (tp >= a) & (tp < b)
+        assert np.array_equal(pos, tp[sel]), (chrom, a, b)
+        assert np.array_equal(vals[:, 2:7], tv[sel]) and np.array_equal(vals[:, 0], tp[sel]) and np.array_equal(vals[:, 1], tp[sel] + 1)
+    rows = list(tb.fetch("chr2", 20005, 20300))
+    assert len(rows) == int(((truth["chr2"][0] >= 20005) & (truth["chr2"][0] < 20300)).sum()) and rows[0][0] == "chr2"
+    # batched, on one thread and on a team
+    ivs = [(c, int(a), int(a + l)) for c, a, l in zip(rs.choice(["chr1", "chr2", "chrX", "chrM"], 400),
+                                                      rs.randint(0, 45000, 400), rs.randint(1, 600, 400))]
+    for nt in ("1", "7"):
+        monkeypatch.setenv("FPT_TRACK_THREADS", nt)
+        tb2 = TabixFile(path)
+        out, present, off = tb2.fetch_batch([c for c, _, _ in ivs], [a for _, a, _ in ivs], [b for _, _, b in ivs], [3, 4, 7])
+        for k, (c, a, b) in enumerate(ivs):
+            want = np.full((3, b - a), np.nan)
+            wp = np.zeros(b - a)
+            if c in truth:
+                tp, tv = truth[c]
+                sel = (tp >= a) & (tp < b)
+                want[:, tp[sel] - a] = tv[sel][:, [0, 1, 4]].T
+                wp[tp[sel] - a] = 1.0
+            sl = slice(off[k], off[k + 1])
+            for j in range(3):
+                assert np.array_equal(out[j][sl], want[j], equal_nan=True), (nt, k)
+            assert np.array_equal(present[sl], wp)
+        tb2.close()
+    tb.close()
+    with pytest.raises(IOError):
+        TabixFile(str(tmp_path / "missing.gz"))
+
+
+def test_track_reader_damage(tmp_path):
+    """a truncated or bit-flipped track file is an error (at open without an index, at the query with
+    one), never a crash"""
+    from footprint_tools_amd.tabix import TabixFile
+    from .tbiwriter import write_bgzf_with_tbi
+    rs = np.random.RandomState(13)
+    text, truth = _track_text(rs, chroms=(("chr1", 30000),))
+    path = str(tmp_path / "t.gz")
+    write_bgzf_with_tbi(path, text, block_bytes=2500, tbi=False)
+    raw = open(path, "rb").read()
+    bad = tmp_path / "cut.gz"
+    bad.write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(IOError):
+        TabixFile(str(bad))
+    for k in range(20):
+        b = bytearray(raw)
+        b[int(rs.randint(0, len(raw) - 28))] ^= 1 << int(rs.randint(0, 8))
+        bad.write_bytes(bytes(b))
+        try:
+            tb = TabixFile(str(bad))
+            tb.fetch_columns("chr1", 0, 30000)
+            tb.close()
+        except (IOError, ValueError):
+            pass
+    write_bgzf_with_tbi(path, text, block_bytes=2500, tbi=True)  # with an index the damage shows at the query
+    raw = open(path, "rb").read()
+    b = bytearray(raw)
+    b[len(raw) // 2] ^= 0x10
+    open(path, "wb").write(bytes(b))
+    tb = TabixFile(path)
+    with pytest.raises((IOError, ValueError)):
+        tb.fetch_columns("chr1", 0, 30000)
