@@ -64,10 +64,48 @@ __global__ void __launch_bounds__(256) k_cut_counts(fpt_cutcount_desc d) {
     }
 }
 
+// Sequence gather: the ASCII bytes of every interval's [start, start + len) of its chromosome, back
+// to back, from the bytes of a FASTA file resident on the device -- what `fasta_func.fetch` returns
+// per interval (modeling/predict.pyx:136-140), for a whole batch.  A chromosome is described by its
+// .fai line (length, byte offset of the first base, bases per line, bytes per line); positions
+// outside it read as 'N' (pysam truncates; the scan then uses the default propensity).  One
+// workgroup per interval.
+__global__ void __launch_bounds__(256) k_seq_gather(const uint8_t *__restrict__ fasta, int64_t fasta_bytes,
+                                                    const int64_t *__restrict__ iv, int64_t n_iv,
+                                                    uint8_t *__restrict__ out) {
+    const int64_t i = blockIdx.x;
+    if (i >= n_iv) return;
+    const int64_t *d = iv + i * 7;  // start, len, out offset, chromosome length, first-base offset, line bases, line bytes
+    const int64_t start = d[0], n = d[1], o = d[2], clen = d[3], coff = d[4], lb = d[5], lw = d[6];
+    for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const int64_t g = start + k;
+        uint8_t ch = 'N';
+        if (g >= 0 && g < clen && lb > 0) {
+            const int64_t pos = coff + (g / lb) * lw + g % lb;
+            if (pos >= 0 && pos < fasta_bytes) ch = fasta[pos];
+        }
+        out[o + k] = ch;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 #pragma GCC visibility push(default)
+
+int fpt_seq_gather_dev(fpt_ctx *c, const uint8_t *fasta_dev, int64_t fasta_bytes, const int64_t *intervals_dev,
+                       int64_t n_intervals, uint8_t *seq_out_dev) {
+    if (int rc = fpt_internal_check_ctx(c)) return rc;
+    if (n_intervals < 0 || fasta_bytes < 0) return fpt_internal_fail(FPT_ERR_INVALID, "negative size");
+    if (n_intervals == 0) return FPT_OK;
+    if (!fasta_dev || !intervals_dev || !seq_out_dev) return fpt_internal_fail(FPT_ERR_INVALID, "null buffer");
+    if (n_intervals > 0x7fffffff) return fpt_internal_fail(FPT_ERR_INVALID, "too many intervals in one call");
+    hipLaunchKernelGGL(k_seq_gather, dim3((unsigned)n_intervals), dim3(256), 0, fpt_internal_stream(c), fasta_dev,
+                       fasta_bytes, intervals_dev, n_intervals, seq_out_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fpt_internal_fail(FPT_ERR_HIP, "k_seq_gather launch failed: %s", hipGetErrorString(e));
+    return FPT_OK;
+}
 
 int fpt_cut_counts_dev(fpt_ctx *c, const fpt_cutcount_desc *d) {
     if (int rc = fpt_internal_check_ctx(c)) return rc;

@@ -110,10 +110,14 @@ class deviation_stats(object):
         d_cp, d_cm = self.read_func.cut_counts_dev(ivs, self.padding)
         bufs = [d_cp, d_cm]
         try:
-            sq = self.fasta_func.fetch_batch(ivs, self.padding)
-            if sq.size != total + n_iv * (2 * self.padding + 7):
+            if hasattr(self.fasta_func, "fetch_batch_dev"):  # the FASTA bytes live on the device too
+                d_sq, n_sq = self.fasta_func.fetch_batch_dev(ctx, ivs, self.padding)
+            else:
+                sq = self.fasta_func.fetch_batch(ivs, self.padding)
+                d_sq, n_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq), sq.size
+            bufs.append(d_sq)
+            if n_sq != total + n_iv * (2 * self.padding + 7):
                 raise ValueError("fasta_func returned sequence of the wrong length")
-            d_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq); bufs.append(d_sq)
             d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
             d_out = DeviceArray(ctx, max(n_tracks * total * 8, 16)); bufs.append(d_out)
             d_st = DeviceArray(ctx, max(n_iv * 4, 16)).upload(np.zeros(max(n_iv, 1), np.int32)); bufs.append(d_st)

@@ -3,7 +3,10 @@ gives the reference (cli/detect.py:100-110, modeling/predict.pyx:136-140), witho
 
 `FastaFile.fetch` returns the bases of [start, end) as `str`; `fetch_batch` returns the ASCII bytes
 of a whole interval list in the fused scan's CSR layout (L + 2*pad + 7 bases per interval: the
-padded interval plus 3 bases either side for the 6-mer context, predict.pyx:136-140).  Positions
+padded interval plus 3 bases either side for the 6-mer context, predict.pyx:136-140);
+`fetch_batch_dev` does the same gather ON THE DEVICE from a copy of the file kept there (uploaded
+once: a genome is a few GB of 288), so a batch costs one small upload of interval descriptors
+instead of a host-side gather and an upload of the bytes.  Positions
 outside the chromosome read as 'N' (pysam truncates; the scan then uses the default propensity,
 as `kmer_model.__getitem__` does for any 6-mer it does not know, bias.py:16-17).
 
@@ -100,3 +103,37 @@ class FastaFile(object):
             data = np.frombuffer(self._mm, dtype=np.uint8)
             out[inside] = data[pos[inside]]
         return out
+
+    # ---- the same gather on the device -------------------------------------------------------------
+    def to_device(self, ctx):
+        """Keep the file's bytes on the device of `ctx` (once)."""
+        from . import _lib  # noqa: F401
+        from .scan import DeviceArray
+        if getattr(self, "_dev", None) is None or self._dev_ctx is not ctx:
+            data = np.frombuffer(self._mm, dtype=np.uint8) if self._mm else np.zeros(0, np.uint8)
+            self._dev = DeviceArray(ctx, max(data.size, 16))
+            if data.size:
+                self._dev.upload(data)
+            self._dev_bytes, self._dev_ctx = int(data.size), ctx
+        return self._dev
+
+    def fetch_batch_dev(self, ctx, intervals, pad, context=3):
+        """`fetch_batch` without the host gather: a DeviceArray holding the `seq` bytes of the
+        interval list in the scan's layout (fpt_seq_gather_dev)."""
+        from . import _lib
+        from .scan import DeviceArray
+        ivs = list(intervals)
+        fa = self.to_device(ctx)
+        starts = np.array([iv.start for iv in ivs], dtype=np.int64) - (pad + 1 + context)
+        n = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64) + (2 * pad + 1 + 2 * context)
+        off = np.concatenate([[0], np.cumsum(n)])
+        desc = np.empty((len(ivs), 7), dtype=np.int64)
+        desc[:, 0], desc[:, 1], desc[:, 2] = starts, n, off[:-1]
+        desc[:, 3:] = np.array([self.index.get(iv.chrom, (0, 0, 0, 1)) for iv in ivs], dtype=np.int64).reshape(len(ivs), 4)
+        out = DeviceArray(ctx, max(int(off[-1]), 16))
+        if ivs:
+            d_desc = DeviceArray(ctx, desc.nbytes).upload(desc)
+            _lib.check(ctx.L.fpt_seq_gather_dev(ctx.h, fa.ptr, self._dev_bytes, d_desc.ptr, len(ivs), out.ptr))
+            ctx.synchronize()
+            d_desc.free()
+        return out, int(off[-1])

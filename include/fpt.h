@@ -366,6 +366,16 @@ typedef struct fpt_cutcount_desc {
 } fpt_cutcount_desc;
 int fpt_cut_counts_dev(fpt_ctx *ctx, const fpt_cutcount_desc *d);
 
+/* Sequence gather on the device (the FASTA half): `seq_out` = the ASCII bytes
+ * of every interval's [start, start + len) of its chromosome, back to back at the given offsets --
+ * what `fasta_func.fetch(chrom, start, end)` returns per interval (modeling/predict.pyx:136-140;
+ * the scan wants start - pad - 1 - 3 .. end + pad + 3) -- from the bytes of a FASTA file resident
+ * on the device.  intervals_dev: DEVICE int64[n_intervals][7] = start, len, output offset, and the
+ * chromosome's .fai fields: length, byte offset of its first base, bases per line, bytes per
+ * line.  Positions outside the chromosome read 'N'. */
+int fpt_seq_gather_dev(fpt_ctx *ctx, const uint8_t *fasta_dev, int64_t fasta_bytes, const int64_t *intervals_dev,
+                       int64_t n_intervals, uint8_t *seq_out_dev);
+
 /* ---- statistics tracks (host only): indexed region access to the
  * bgzip-compressed bedGraph files `ftd detect` writes (cli/utils.py:119-144), which the posterior
  * caller reads back per interval through pysam.TabixFile.fetch (cli/post.py:52-87).  The file is

@@ -1382,6 +1382,14 @@ def test_cut_count_ingestion(fpt, orc, tmp_path):
         for name, s_ in gseq.items():
             f.write(">%s\n" % name + "\n".join(s_[a:a + 70] for a in range(0, len(s_), 70)) + "\n")
     fa = FastaFile(str(fa_path))
+    # the sequence gather on the device (fpt_seq_gather_dev) = the host gather, chromosome ends and
+    # unknown chromosomes ('N') included
+    edge = ivs + [Iv("chr1", 2, 40), Iv("chr2", refs[1][1] - 30, refs[1][1] + 20), Iv("chrNope", 100, 200)]
+    d_seq, n_seq = fa.fetch_batch_dev(bf._ctx or fpt.get_ctx(), edge, pad)
+    host_seq = fa.fetch_batch(edge, pad)
+    assert n_seq == host_seq.size and np.array_equal(d_seq.download(np.uint8, n_seq), host_seq)
+    assert (host_seq == ord("N")).sum() > 100
+    d_seq.free()
     inner = [iv for iv in ivs if iv.start > 100 and iv.end < refs[[n for n, _ in refs].index(iv.chrom)][1] - 100]
     cp2, cm2 = bf.cut_counts_dev(inner, pad)
     sq = fa.fetch_batch(inner, pad)
