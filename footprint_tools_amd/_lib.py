@@ -74,6 +74,7 @@ class FdrDesc(C.Structure):
         ("efdr_out", C.c_void_p),
         ("null_uniform", C.c_void_p),
         ("null_winp_out", C.c_void_p),
+        ("obs", C.c_void_p),
     ]
 
 

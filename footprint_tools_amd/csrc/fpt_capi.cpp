@@ -821,6 +821,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.memo_obs = c->fdr_memo_obs;
     fl.exp = d->exp;
     fl.winp = d->winp;
+    fl.obs = d->obs;
     fl.efdr = d->efdr_out;
     fl.null_uniform = d->null_uniform;
     fl.null_out = d->null_winp_out;

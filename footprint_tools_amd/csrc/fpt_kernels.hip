@@ -1251,13 +1251,14 @@ struct fdr_args {
     int32_t memo_exp, memo_obs;
     const double *exp;
     const double *winp;
+    const double *obs;       // optional: observed counts -> the observed windows are ranked in y, ties exact
     double *efdr;
     const double *null_uniform;
     double *null_out;       // optional [base][times] null window p-values
     const int32_t *dm_ids;  // per interval model slot relative to `model`, or nullptr
     int32_t ablate;      // timing-only diagnostics (FPT_ABLATE builds)
     int32_t n2_max;      // buffer capacity: power of two >= longest interval of the launch
-    double inv_sqrt_k;
+    double inv_sqrt_k, sqrt_k;  // y = -(sum of z) / sqrt(K) exactly as windowing.h:64 divides (div_invariant)
     int32_t dbuf;            // a second set of z buffers follows the first: one barrier per pass instead of two
     const int32_t *iv_list;  // interval of workgroup b is iv_list[b], or iv_first + b when null
     int64_t iv_first;
@@ -1485,6 +1486,33 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * (kGuide + 1);
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
+    // ---- 0. with the observed counts at hand, the observed window p-values are re-made here by the
+    // very operations the null windows go through below -- z of the (exp, obs) pair from the same
+    // table, summed left to right, and the SAME normal cdf that the thresholds are searched with --
+    // so that "null <= observed" is decided as in the reference, which compares two p-values that
+    // went through one function: a null window made of the same counts ties exactly, and so does
+    // one whose z sum differs in the last bits only (the same counts in another order; the cdf is
+    // flat to double precision near 1).  Taken from the p-value track of the scan, whose cdf is a
+    // different (faster) evaluation, such ties fall either way by rounding -- and with sparse counts
+    // ties are a large share of the null: an all-zero window is its own most likely null draw.
+    if (a.obs) {
+        for (int t = tid; t < L; t += NT) {
+            const double ex = a.exp[off + t];
+            const int ei = table_row_of(ex, a.memo_exp);
+            const int32_t k = fptm::c_int(a.obs[off + t]);
+            double z;
+            if (ei >= 0 && k >= 0 && k < a.memo_obs) {
+                z = memo[(size_t)ei * a.memo_obs + k].y;
+            } else {  // beyond the table: evaluated directly (rare)
+                bool zd = false;
+                const double *par_src = a.model + (size_t)dm * 24;
+                const double r = fptm::fit_r(par_src + 9, ex, &zd), mu = fptm::fit_mu(par_src, ex);
+                z = nb_pz_direct(r, mu, k).y;
+            }
+            zb[t] = z;
+        }
+        __syncthreads();
+    }
     // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last); on the way
     // in, count the values that are not NaN (m) and those below 1 (the rank of the edge positions'
     // constant 1.0 among the thresholds)
@@ -1493,11 +1521,31 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         double v = fptm::kInf;
         int id = -1;
         if (i < L) {
-            v = a.winp[off + i];
+            const double P = a.winp[off + i];
             id = i;
-            n_num += isnan(v) ? 0 : 1;
-            n_below_one += (v < 1.0) ? 1 : 0;
-            if (isnan(v)) v = fptm::kInf;
+            if (isnan(P)) {
+                // not a number: compares as +inf, ends up last, is not counted
+            } else if (!a.obs) {
+                v = P;  // becomes a threshold in y after the sort (ndtr_threshold)
+                n_num += 1;
+                n_below_one += (P < 1.0) ? 1 : 0;
+            } else if (!(P < 1.0)) {
+                v = P;
+                n_num += 1;  // an edge position (or p = 1): above every null window
+            } else {
+                // this position's window p-value once more, from its own y through the function the
+                // thresholds below are searched with
+                double sm = NAN;
+                if (i >= a.hw && i < L - a.hw) {
+                    sm = 0.0;
+                    for (int j = i - a.hw; j <= i + a.hw; ++j) sm += zb[j];
+                }
+                if (isfinite(sm)) {
+                    v = fptm::ndtr(-div_invariant(sm, a.sqrt_k, a.inv_sqrt_k));
+                    n_num += 1;
+                    n_below_one += (v < 1.0) ? 1 : 0;
+                }  // else: the tracks disagree (a p-value where the counts give none): not a number
+            }
         }
         skey[i] = v;
         sidx[i] = id;
@@ -1646,15 +1694,15 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                         for (int w = 0; w < 4; ++w) sm[w] += zq[w * n2 + j];
                     }
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) y[w] = isfinite(sm[w]) ? -(sm[w] * a.inv_sqrt_k) : NAN;
+                    for (int w = 0; w < 4; ++w) y[w] = isfinite(sm[w]) ? -div_invariant(sm[w], a.sqrt_k, a.inv_sqrt_k) : NAN;
                 }
             } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
                 const double s0 = le3 ? tile_range_sum3(zq, t - hs, t + hs) : tile_range_sum(zq, t - hs, t + hs);
                 const double s1 = le3 ? tile_range_sum3(zq + n2, t - hs, t + hs) : tile_range_sum(zq + n2, t - hs, t + hs);
                 const int sc = le3 ? tile_range_sum3(nf, t - hs, t + hs) : tile_range_sum(nf, t - hs, t + hs);
-                y[0] = (sc & 0xffff) ? NAN : -(s0 * a.inv_sqrt_k);
-                y[1] = (sc >> 16) ? NAN : -(s1 * a.inv_sqrt_k);
+                y[0] = (sc & 0xffff) ? NAN : -div_invariant(s0, a.sqrt_k, a.inv_sqrt_k);
+                y[1] = (sc >> 16) ? NAN : -div_invariant(s1, a.sqrt_k, a.inv_sqrt_k);
             }
             if (a.null_out) {  // the p-values themselves only when somebody wants them
                 double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
@@ -2179,13 +2227,15 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.memo_obs = fl.memo_obs;
     a.exp = fl.exp;
     a.winp = fl.winp;
+    a.obs = fl.obs;
     a.efdr = fl.efdr;
     a.null_uniform = fl.null_uniform;
     a.null_out = fl.null_out;
     a.dm_ids = fl.dm_ids;
     a.ablate = fl.ablate;
     a.n2_max = fl.n2_max;
-    a.inv_sqrt_k = 1.0 / sqrt((double)(2 * fl.hw + 1));
+    a.sqrt_k = sqrt((double)(2 * fl.hw + 1));
+    a.inv_sqrt_k = 1.0 / a.sqrt_k;
     a.iv_list = fl.iv_list;
     a.dbuf = 0;
     a.gws = (char *)fl.gws;

@@ -69,6 +69,7 @@ struct fdr_launch {
     const void *guide;  // nb_guide_bytes(), filled by launch_nb_guide after launch_nb_memo
     int32_t memo_exp, memo_obs;
     const double *exp, *winp;
+    const double *obs;  // optional (see fpt_fdr_desc.obs)
     double *efdr;
     const double *null_uniform;
     double *null_out;

@@ -132,7 +132,7 @@ class deviation_stats(object):
                     sc.fdr_dev(b - a, d_out.ptr + int(off[a]) * 8, d_out.ptr + 3 * t8 + int(off[a]) * 8,
                                d_out.ptr + (3 + S) * t8 + int(off[a]) * 8, times=self.fdr_shuffle_n, seed=self.seed,
                                half_win_width=3, interval_off_dev=d_roff.ptr,
-                               base_index0=int(self._bases_before[indices[a]]))
+                               base_index0=int(self._bases_before[indices[a]]), obs=d_out.ptr + t8 + int(off[a]) * 8)
             if self.dm:
                 # the five record columns (detect.py:142-144, and the fallback rows of :136-140)
                 # assembled on the device: one download of the (bases, 5) matrix
@@ -178,7 +178,7 @@ class deviation_stats(object):
                 sl = slice(off[a], off[b])
                 efdr[sl] = sc.fdr(res["exp"][sl], res["winp"][0][sl], times=self.fdr_shuffle_n, seed=self.seed,
                                   half_win_width=3, interval_off=off[a:b + 1] - off[a],
-                                  base_index0=int(self._bases_before[indices[a]]))
+                                  base_index0=int(self._bases_before[indices[a]]), obs=res["obs"][sl])
         # the five columns for the whole batch at once; a record's `stats` is its block of rows
         pv, wp, ef = np.array(res["pval"], copy=True), np.array(res["winp"][0], copy=True), np.array(efdr, copy=True)
         for j in np.nonzero(res["status"])[0]:  # the reference's `except Exception` branch (detect.py:136-140)

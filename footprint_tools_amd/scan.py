@@ -220,8 +220,10 @@ class FootprintScanner(object):
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
     def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,
                 interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None, dm_ids_dev=None,
-                null_winp_out=None):
-        """Enqueue the null sampling + ranking on device pointers; does not synchronise."""
+                null_winp_out=None, obs=None):
+        """Enqueue the null sampling + ranking on device pointers; does not synchronise.
+        obs: the observed counts track (device pointer): ties between null and observed windows
+        are then decided exactly, as in the reference (see fpt_fdr_desc.obs)."""
         ctx = self.ctx
         d = _lib.FdrDesc()
         d.n_intervals = int(n_intervals)
@@ -233,12 +235,14 @@ class FootprintScanner(object):
         d.dm_ids, d.n_dm = dm_ids_dev, len(self.models)
         d.exp, d.winp, d.efdr_out, d.null_uniform = exp, winp, efdr_out, null_uniform
         d.null_winp_out = null_winp_out
+        d.obs = obs
         _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))
 
     def fdr(self, exp, winp, times=100, seed=0, half_win_width=3, interval_len=None, interval_off=None,
-            base_index0=0, null_uniform=None, dm_ids=None, return_null=False):
+            base_index0=0, null_uniform=None, dm_ids=None, return_null=False, obs=None):
         """Empirical FDR of observed window p-values (host arrays in / out).  return_null=True
-        also returns the (total_bases, times) null window p-values (detect.py:133)."""
+        also returns the (total_bases, times) null window p-values (detect.py:133).  obs: the
+        observed counts the p-values were made from (exact ties, see fdr_dev)."""
         ctx = self.ctx
         exp, winp = _lib.f64(exp).ravel(), _lib.f64(winp).ravel()
         total = exp.size
@@ -260,7 +264,12 @@ class FootprintScanner(object):
                 if nu.size != total * times:
                     raise ValueError("null_uniform needs total_bases * times values")
                 d_u = DeviceArray(ctx, nu.nbytes).upload(nu); bufs.append(d_u)
-            d_dm = d_n = None
+            d_dm = d_n = d_obs = None
+            if obs is not None:
+                ob = _lib.f64(obs).ravel()
+                if ob.size != total:
+                    raise ValueError("obs needs one value per base")
+                d_obs = DeviceArray(ctx, max(ob.nbytes, 16)).upload(ob); bufs.append(d_obs)
             if dm_ids is not None:
                 ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
                 if ids.size != n_iv or (ids.size and (ids.min() < 0 or ids.max() >= len(self.models))):
@@ -271,7 +280,8 @@ class FootprintScanner(object):
             self.fdr_dev(n_iv, d_e.ptr, d_w.ptr, d_o.ptr, times, seed, half_win_width,
                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
                          base_index0=base_index0, null_uniform=d_u.ptr if d_u else None,
-                         dm_ids_dev=d_dm.ptr if d_dm else None, null_winp_out=d_n.ptr if d_n else None)
+                         dm_ids_dev=d_dm.ptr if d_dm else None, null_winp_out=d_n.ptr if d_n else None,
+                         obs=d_obs.ptr if d_obs else None)
             ctx.synchronize()
             ef = d_o.download(np.float64, total)
             if d_n:

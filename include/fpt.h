@@ -225,6 +225,15 @@ typedef struct fpt_fdr_desc {
                                        * (row-major base x sample): deterministic tests */
     double *null_winp_out;            /* optional DEVICE [sum(L) * times]: the null window p-values
                                        * (detect.py:133 win_pvals_null, row-major base x sample) */
+    const double *obs;                /* optional DEVICE: the observed counts track the p-values were made
+                                       * from.  With it the observed window p-values are re-made inside the
+                                       * call by the operations (and the normal cdf) the null windows go
+                                       * through, so that a null window of the same counts TIES with the
+                                       * observed one exactly, as in the reference (both go through one
+                                       * stouffers_z); `winp` then only says which positions are NaN or 1.
+                                       * Without it observed values are ranked as given, and such ties -- a
+                                       * large share of the null for sparse counts -- fall either way by the
+                                       * rounding of whatever made `winp`. */
 } fpt_fdr_desc;
 
 /* Enqueue the null sampling + ranking on the context's stream (no synchronisation).

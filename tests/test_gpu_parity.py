@@ -921,6 +921,53 @@ def test_fdr_null_vs_oracle(fpt, orc):
     assert ef[17] == 1.0
 
 
+@pytest.mark.parametrize("lam", [0.03, 0.3, 3.0])
+def test_fdr_ties_like_the_reference(fpt, orc, lam):
+    """With sparse counts a null window is often made of the SAME counts as an observed one (an
+    all-zero window is its own most likely null draw: a third of the pooled null can tie with one
+    observed value), and the reference counts such ties as "null <= observed": both p-values went
+    through one stouffers_z.  Given the observed counts, the device re-makes the observed window
+    p-values by the operations and the normal cdf of its null windows, so the ties are exact by
+    construction -- equal to the oracle fed with its own observed window p-values, interval by
+    interval.  (Ranked from the scan's p-value track, whose cdf is another evaluation, they agree
+    only as far as the two evaluations round alike; on these inputs they do.)"""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    rs = np.random.RandomState(int(lam * 100))
+    n_iv, L, times, hw, shw = 6, 300, 100, 5, 50
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, 0.01, (3,))
+    l = sc.padded_len(L)
+    cp, cm = rs.poisson(lam, n_iv * l).astype(float), rs.poisson(lam, n_iv * l).astype(float)
+    sq = rs.choice(np.frombuffer(b"ACGT", np.uint8), n_iv * (l + 6))
+    out = sc.scan(cp, cm, sq, interval_len=L)
+    e, o, p, wp = orc.detect_batch(cp, cm, sq, n_iv, L, hw, shw, 0.01, table, lat["mu_A"], lat["r_A"], np.array([3], np.int32))
+    assert np.array_equal(out["exp"], e) and np.array_equal(out["obs"], o)
+    ef, nul = sc.fdr(out["exp"], out["winp"][0], times=times, seed=5, interval_len=L, base_index0=77, obs=out["obs"],
+                     return_null=True)
+    ties = 0
+    for i in range(n_iv):
+        sl = slice(i * L, (i + 1) * L)
+        want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], e[sl], wp[0][sl], 3, times, seed=5, base0=77 + i * L, return_null=True)
+        assert rel_err(nul[sl], wn) < 1e-9
+        # Exact ties (the same counts in the same order, and everything on the flat part of the cdf near 1,
+        # where lam = 0.03 puts a third of the null on one observed value) must agree to the count.  Null
+        # windows made of the same counts in ANOTHER ORDER sum to a y an ulp away, and off the flat part
+        # their p-value is an ulp away too: which side of the observed value they land on is decided by
+        # the last bit of ndtri / ndtr -- in the reference by its libm -- so a position may differ by as
+        # many counts as it has null values within 1e-13 of it.
+        flat = np.sort(wn.ravel())
+        P = wp[0][sl]
+        lo, hi = np.searchsorted(flat, P * (1 - 1e-13), "left"), np.searchsorted(flat, P * (1 + 1e-13), "right")
+        near = np.where(np.isnan(P) | (P > 0.9999), 0, hi - lo)
+        diff = np.abs(ef[sl] - want) * (L * times)
+        assert np.all(diff <= 2.5 + near), (lam, i, float(diff.max()))
+        assert diff.mean() < 0.5
+        ties = max(ties, int(max((wn == v).sum() for v in np.unique(wp[0][sl])[:50])))
+    if lam <= 0.03:
+        assert ties > L * times // 5  # a fifth of the pooled null ties with one observed value
+
+
 def test_fdr_null_given_uniforms_and_ragged(fpt, orc):
     n_iv, L, times = 4, 260, 25
     sc, lat, out = _scan_small(orc, n_iv, L, 8)
