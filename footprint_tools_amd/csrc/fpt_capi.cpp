@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-constexpr int kSlots = 12;
+constexpr int kSlots = 13;
 constexpr int kModelDoubles = 24;
 
 }  // namespace
@@ -556,12 +556,24 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
             for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
             for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
-            void *d_new;
+            // the same tiles as 32-byte records for the lean kernel (interval offset and length included:
+            // one scalar load instead of two dependent ones)
+            std::vector<fptk::lean_tile_rec> recs((size_t)n_tiles);
+            for (int64_t t = 0; t < n_tiles; ++t) {
+                const int32_t iv = flat[(size_t)t];
+                recs[(size_t)t] = fptk::lean_tile_rec{off[iv], iv, flat[(size_t)(n_tiles + t)], flat[(size_t)(2 * n_tiles + t)],
+                                                       (int32_t)(off[iv + 1] - off[iv]), {0, 0}};
+            }
+            void *d_new, *d_recs;
             c->plan_H = -1;  // invalid while the table is being replaced
             if (int rc = ws_get(c, 9, flat.size() * 4, &d_new)) return rc;
-            if (!flat.empty())
+            if (int rc = ws_get(c, 12, recs.size() * sizeof(fptk::lean_tile_rec), &d_recs)) return rc;
+            if (!flat.empty()) {
                 HIP_TRY(hipMemcpyAsync(d_new, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` is pageable host memory
+                HIP_TRY(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(fptk::lean_tile_rec), hipMemcpyHostToDevice,
+                                       c->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));  // the staging vectors are pageable host memory
             c->plan_off.assign(off, off + n_off);
             c->plan_tiles = n_tiles;
             c->plan_max_len = max_len;
@@ -573,6 +585,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         sl.tile_iv = (const int32_t *)c->ws[9];
         sl.tile_t0 = sl.tile_iv + c->plan_tiles;
         sl.tile_tl = sl.tile_t0 + c->plan_tiles;
+        sl.tile_recs = c->ws[12];
         int64_t first = 0;
         for (int cls = 0; cls < fptk::kLeanClasses; ++cls) {
             const int64_t n = c->plan_cls_count[cls];

@@ -15,6 +15,7 @@ struct scan_launch {
     const int32_t *tile_iv;
     const int32_t *tile_t0;
     const int32_t *tile_tl;
+    const void *tile_recs;  // the same table as lean_tile_rec records (the lean kernel reads those)
     int64_t tile_first;
     int32_t tiles_per_interval;
     int32_t tile_len;
@@ -48,6 +49,12 @@ struct scan_launch {
 };
 
 // fpt_scan_lean.hip: the first pass of memo mode for the `detect` defaults (hw 5, shw 50, clip 0.01)
+struct lean_tile_rec {  // a tile of a ragged batch, read by the kernel with one scalar load
+    int64_t out_off;    // offset of the tile's interval in the output tracks (= interval_off[iv])
+    int32_t iv, t0, tl, len;
+    int32_t pad_[2];
+};
+static_assert(sizeof(lean_tile_rec) == 32, "one s_load_dwordx8");
 constexpr int kLeanClasses = 7;
 constexpr int kLeanNT[kLeanClasses] = {128, 192, 256, 384, 512, 768, 1024};  // its workgroup sizes
 bool scan_lean_applies(const scan_launch &sl);

@@ -62,9 +62,8 @@ struct lean_coef {
 struct lean_args {
     int32_t interval_len;        // uniform mode when interval_off == nullptr
     const int64_t *interval_off; // ragged: output offsets
-    const int32_t *tile_iv;      // ragged: tile table
-    const int32_t *tile_t0;
-    const int32_t *tile_tl;
+    const fptk::lean_tile_rec *tile_recs;  // ragged: one 32-byte record per tile (ONE scalar load: a short
+                                           // workgroup lives ~7 us, and every dependent load is ~5 % of it)
     int64_t tile_first;
     int32_t tiles_per_interval, tile_len;
     int32_t n_scales;
@@ -237,11 +236,13 @@ __device__ __forceinline__ lean_tile lean_geometry(const Args &a, int64_t tile) 
     lean_tile g;
     int64_t iv;
     if (a.interval_off) {
-        iv = uniform_load(a.tile_iv, tile);
-        g.t0 = uniform_load(a.tile_t0, tile);
-        g.tl = uniform_load(a.tile_tl, tile);
-        g.out_off = uniform_load(a.interval_off, iv);
-        g.L = (int)(uniform_load(a.interval_off, iv + 1) - g.out_off);
+        typedef const __attribute__((address_space(4))) fptk::lean_tile_rec krec;
+        krec *r = (krec *)(a.tile_recs + tile);
+        g.out_off = r->out_off;
+        iv = r->iv;
+        g.t0 = r->t0;
+        g.tl = r->tl;
+        g.L = r->len;
     } else {
         if (a.tiles_per_interval == 1) {  // a 64-bit scalar division costs ~150 instructions
             iv = tile;
@@ -351,6 +352,9 @@ template <int NT>
 __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double2 *table2, int ncs, int tid) {
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     bool bad = false;
+    // the table gathers of both of a lane's positions go out first: one trip to L2 instead of two
+    // in a row (a short workgroup lives ~7 us, most of it such trips)
+    double2 tt[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i * NT + wave * kWave >= ncs) break;
@@ -358,7 +362,12 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         const int w32 = v >> 5, sh = v & 31;
         const u32 f0 = __builtin_amdgcn_alignbit(m.bits0[w32 + 1], m.bits0[w32], sh) & 63u;
         const u32 f1 = __builtin_amdgcn_alignbit(m.bits1[w32 + 1], m.bits1[w32], sh) & 63u;
-        const double2 tt = table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+        tt[i] = table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i * NT + wave * kWave >= ncs) break;
+        const int v = i * NT + tid;
         const u32 *pw = m.pk + 8 + v - kHW;
         u32 W = pw[0];
 #pragma unroll
@@ -380,8 +389,8 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8;
         rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8;
         bad |= ((rP | rM) & kFirst) != 0;
-        m.PP[v] = tt.x;
-        m.PM[v] = tt.y;
+        m.PP[v] = tt[i].x;
+        m.PM[v] = tt[i].y;
     }
     return bad;
 }
@@ -662,9 +671,7 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     lean_args a;
     a.interval_len = sl.interval_len;
     a.interval_off = sl.interval_off;
-    a.tile_iv = sl.tile_iv;
-    a.tile_t0 = sl.tile_t0;
-    a.tile_tl = sl.tile_tl;
+    a.tile_recs = (const fptk::lean_tile_rec *)sl.tile_recs;
     a.tile_first = sl.tile_first;
     a.tiles_per_interval = sl.tiles_per_interval;
     a.tile_len = sl.tile_len;
