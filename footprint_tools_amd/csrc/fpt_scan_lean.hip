@@ -515,20 +515,29 @@ __device__ __forceinline__ bool lean_windows(const lean_args &a, kcoef *kc, cons
     const u32 t8 = (u32)o.t * 8u;
     // a window of half-width hs fits iff hs <= the distance to the nearer end (-1: not this lane's base)
     const int room = o.mine ? min(o.t, o.L - 1 - o.t) : -1;
-    double lowest = 0.0;  // the edge lanes' argument is +1e4 / sqrt(K): it never lowers the minimum
+    // The lane's two prefix slots as 32-bit LDS addresses, made ONCE (the empty asm keeps the
+    // compiler from re-deriving them from the array base inside the loop: machine LICM is off for
+    // this library), so that a scale costs an add, a subtract, a compare and two selects.
+    typedef const __attribute__((address_space(3))) double lds_double;
+    u32 ahi0 = (u32)(size_t)(lds_double *)(Z + 16 + tid), alo0 = (u32)(size_t)(lds_double *)(Z + 15 + tid);
+    u32 aedge = (u32)(size_t)(lds_double *)(Z + kEdge), afirst = (u32)(size_t)(lds_double *)(Z + 15);
+    asm volatile("" : "+v"(ahi0), "+v"(alo0), "+v"(aedge), "+v"(afirst));  // (vector registers: a select cannot read a scalar next to vcc)
+    const double neg_limit = -kc->limit;
+    bool low = false;  // an argument below -26: the tile needs the restated ndtr.c (see ndtr_fast_s)
     for (int s = 0; s < a.n_scales; ++s) {
         const int hs = a.scales[s];
+        const u32 hs8 = (u32)hs * 8u;
         const bool inside = hs <= room;
-        const int hi = inside ? 16 + tid + hs : kEdge, lo = inside ? 15 + tid - hs : 15;
-        const double sv = Z[hi] - Z[lo];
+        const u32 ah = inside ? ahi0 + hs8 : aedge, al = inside ? alo0 - hs8 : afirst;
+        const double sv = *(lds_double *)(size_t)ah - *(lds_double *)(size_t)al;
         const double arg = -(sv * a.scale_rsqrt[s]);
-        lowest = fmin(lowest, arg);
+        low |= !(arg > neg_limit);  // (the edge lanes' argument is +1e4 / sqrt(K); z is finite here, so is every argument)
         const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
         double *row_s = row + (int64_t)s * a.total_bases;
         asm volatile("" : "+s"(row_s));  // keeps the scale's base in scalar registers (no per-lane pointer carried through the loop)
         if (o.mine) store_at(row_s, t8, pw);
     }
-    return !(lowest > -kc->limit);  // one-sided: see ndtr_fast_s (z is finite here, so is every argument)
+    return low;
 }
 // one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right
 template <int NT>
