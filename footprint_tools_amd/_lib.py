@@ -25,7 +25,7 @@ EXPORTS = [
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
-    "fpt_set_memo_dims", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
+    "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
 
@@ -177,6 +177,7 @@ def load():
         L.fpt_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.fpt_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.fpt_set_memo_dims.argtypes = [vp, i32, i32]
+        L.fpt_drop_kept_tables.argtypes = [vp]
         L.fpt_timing_enable.argtypes = [vp, i32]
         L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]
         _lib = L
@@ -309,6 +310,10 @@ class Context(object):
         t, r, m = C.c_int64(0), C.c_int64(0), (C.c_int32 * 2)(-1, -1)
         check(self.L.fpt_scan_stats(self.h, C.byref(t), C.byref(r), C.byref(m)))
         return t.value, r.value, (m[0], m[1])
+
+    def drop_kept_tables(self):
+        """Empty the second-level (exp, obs) table memo mode keeps across calls (see fpt.h)."""
+        check(self.L.fpt_drop_kept_tables(self.h))
 
     def timing_enable(self, max_records):
         check(self.L.fpt_timing_enable(self.h, int(max_records)))

@@ -54,6 +54,7 @@ struct fpt_ctx {
     bool have_model[FPT_MAX_DISPERSION_MODELS] = {};
     void *ws[kSlots] = {};
     size_t ws_bytes[kSlots] = {};
+    uint64_t ws_gen[kSlots] = {};  // counts the (re)allocations of a slot: its contents are gone after one
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::vector<hipEvent_t> tev;  // event pairs of recorded scans (fpt_timing_enable)
@@ -62,7 +63,22 @@ struct fpt_ctx {
     int memo_exp = 256, memo_obs = 256;
     // second-level table of the redo pass: capacity (entries beyond what a batch needs are never
     // computed), 16 bytes per entry and model; batches with more models than memo2_models skip it
-    int memo2_rows = 1024, memo2_stride = 4096, memo2_models = 4;
+    int memo2_rows = 4096, memo2_stride = 4096, memo2_models = 4;
+    // The second-level table is a pure function of the dispersion models, and unlike the 256 x 256
+    // first level it is too large to rebuild per call, so it is KEPT: d_flags[16..17] hold the
+    // bounds (exp, obs) up to which it is filled for the models described by m2_*; a call that
+    // misses beyond them extends it between its two passes.  The lean first pass reads it, so only
+    // the first batch that reaches a new (exp, obs) range pays the redo pass for it.  Changing a
+    // model of the range (fpt_set_dispersion with other values), another model range or a
+    // reallocated slot empties it.
+    uint64_t model_epoch[FPT_MAX_DISPERSION_MODELS] = {};
+    double h_models[FPT_MAX_DISPERSION_MODELS][kModelDoubles] = {};
+    uint64_t epoch_next = 1;
+    int m2_dm_id = -1, m2_n_dm = 0, m2_memo_exp = 0, m2_memo_obs = 0;
+    uint64_t m2_epoch[FPT_MAX_DISPERSION_MODELS] = {};
+    uint64_t m2_ws_gen = 0;
+    bool m2_extended = false;  // the last scan call launched k_nb_memo2: its misses become bounds at the next call
+    bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
@@ -106,6 +122,7 @@ int ws_get(fpt_ctx *c, int slot, size_t bytes, void **out) {
             return fail(FPT_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
         }
         c->ws_bytes[slot] = want;
+        ++c->ws_gen[slot];
     }
     *out = c->ws[slot];
     return FPT_OK;
@@ -182,6 +199,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
                     device_id, prop.gcnArchName);
     fpt_ctx *c = new fpt_ctx();
     if (const char *e = getenv("FPT_SCAN_LEAN")) c->use_lean = atoi(e) != 0;
+    if (const char *e = getenv("FPT_MEMO2_KEEP")) c->memo2_cold = atoi(e) == 0;
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
@@ -192,9 +210,9 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
         HIP_TRY(hipMalloc(&c->d_table, (FPT_KMER_TABLE + 1) * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_table2, 2 * FPT_KMER_TABLE * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_models, FPT_MAX_DISPERSION_MODELS * kModelDoubles * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_flags, 16 * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->d_flags, 24 * sizeof(int)));
         HIP_TRY(hipMalloc(&c->d_sum, 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_flags, 0, 16 * sizeof(int)));
+        HIP_TRY(hipMemset(c->d_flags, 0, 24 * sizeof(int)));
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
         return FPT_OK;
@@ -269,8 +287,11 @@ int fpt_set_dispersion(fpt_ctx *c, int dm_id, const double *mu9, const double *r
     double m[kModelDoubles];
     std::memcpy(m, mu9, 9 * sizeof(double));
     std::memcpy(m + 9, r15, 15 * sizeof(double));
+    if (c->have_model[dm_id] && std::memcmp(m, c->h_models[dm_id], sizeof m) == 0) return FPT_OK;  // unchanged
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_models + (size_t)dm_id * kModelDoubles, m, sizeof m, hipMemcpyHostToDevice));
+    std::memcpy(c->h_models[dm_id], m, sizeof m);
+    c->model_epoch[dm_id] = c->epoch_next++;
     c->have_model[dm_id] = true;
     return FPT_OK;
 }
@@ -625,12 +646,26 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
     // pass missed): only with the lean first pass, which records those maxima
     void *d_memo2 = nullptr;
     int32_t *d_miss = c->d_flags + 8;
+    int memo2_state = 0;  // for k_nb_memo: 0 bounds as they are, 1 the last call's misses join them, 2 emptied
     if (use_memo && sl.table_global && c->use_lean && n_dm <= c->memo2_models && fptk::scan_lean_applies_hw(hw, shw, k)) {
         if (int rc = ws_get(c, 10, (size_t)c->memo2_rows * c->memo2_stride * 16 * n_dm, &d_memo2)) return rc;
         sl.memo2 = d_memo2;
         sl.memo2_max = d_miss;
+        sl.memo2_have = c->d_flags + 16;
         sl.memo2_rows = c->memo2_rows;
         sl.memo2_stride = c->memo2_stride;
+        // is what the slot holds the table of these models?
+        bool same = c->m2_ws_gen == c->ws_gen[10] && c->m2_dm_id == d->dm_id && c->m2_n_dm == n_dm &&
+                    c->m2_memo_exp == c->memo_exp && c->m2_memo_obs == c->memo_obs && !c->memo2_cold;
+        for (int i = 0; i < n_dm && same; ++i) same = c->m2_epoch[i] == c->model_epoch[d->dm_id + i];
+        memo2_state = !same ? 2 : (c->m2_extended ? 1 : 0);
+        c->m2_ws_gen = c->ws_gen[10];
+        c->m2_dm_id = d->dm_id;
+        c->m2_n_dm = n_dm;
+        c->m2_memo_exp = c->memo_exp;
+        c->m2_memo_obs = c->memo_obs;
+        for (int i = 0; i < n_dm; ++i) c->m2_epoch[i] = c->model_epoch[d->dm_id + i];
+        c->m2_extended = false;
     }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used] : c->ev0, c->stream));
     // memo mode runs two passes per size class: the light memo-only instance over every tile,
@@ -648,7 +683,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         // same launch zeroes the redo flags and resets d_flags[8..15]: the largest missed pair
         // (-1, -1) and the (count, cursor) pairs of the second pass, one per workgroup size
         fptk::launch_nb_memo(c->stream, sl.model, n_dm, c->memo_exp, c->memo_obs, d_memo, (int32_t *)d_redo,
-                             d_redo ? tiles_total : 0, d_miss);
+                             d_redo ? tiles_total : 0, d_miss, d_memo2 ? c->d_flags + 16 : nullptr, memo2_state,
+                             c->memo2_rows, c->memo2_stride);
         if (int rc = launch_ok("k_nb_memo")) return rc;
     }
     // pass 0 (memo mode only): memo-only instance over every tile; pass 1: full instance (over
@@ -692,9 +728,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         }
         if (rec && main_pass) HIP_TRY(hipEventRecord(c->tev[c->tev_used + 2], c->stream));
         if (memo_only && d_memo2) {  // between the passes: the table for what the first pass missed
-            fptk::launch_nb_memo2(c->stream, sl.model, n_dm, d_miss, c->memo_exp, c->memo_obs, c->memo2_rows,
-                                  c->memo2_stride, d_memo2);
+            fptk::launch_nb_memo2(c->stream, sl.model, n_dm, d_miss, c->d_flags + 16, c->memo_exp, c->memo_obs,
+                                  c->memo2_rows, c->memo2_stride, d_memo2);
             if (int rc = launch_ok("k_nb_memo2")) return rc;
+            c->m2_extended = true;
         }
     }
     HIP_TRY(hipEventRecord(rec ? c->tev[c->tev_used + 3] : c->ev1, c->stream));
@@ -899,6 +936,13 @@ int fpt_set_memo_dims(fpt_ctx *c, int memo_exp, int memo_obs) {
     c->memo_exp = memo_exp;
     c->memo_obs = memo_obs;
     c->fdr_memo_obs = memo_obs;
+    return FPT_OK;
+}
+
+int fpt_drop_kept_tables(fpt_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    c->m2_dm_id = -1;  // the next scan call finds no table of its models and starts an empty one
+    c->m2_extended = false;
     return FPT_OK;
 }
 

@@ -312,6 +312,7 @@ struct scan_args {
     // missed, found without a host round trip), or nullptr
     const double2 *memo2;
     const int32_t *memo2_max;
+    const int32_t *memo2_have;  // ... or held already (kept across calls): valid up to the larger of the two
     int32_t memo2_rows, memo2_stride;
 };
 #ifdef FPT_ABLATE
@@ -343,11 +344,21 @@ constexpr long long kZeroDivZBits = 0x7ff800005a440000ll;
 __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ models, int memo_exp,
                                                     int memo_obs, double2 *__restrict__ memos,
                                                     int32_t *__restrict__ clear, int64_t n_clear,
-                                                    int32_t *__restrict__ state) {
+                                                    int32_t *__restrict__ state, int32_t *__restrict__ have,
+                                                    int have_state, int rows, int stride) {
     if (blockIdx.y == 0) {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_clear; i += (int64_t)gridDim.x * blockDim.x)
             clear[i] = 0;
-        if (state && blockIdx.x == 0 && threadIdx.x < 8) state[threadIdx.x] = threadIdx.x < 2 ? -1 : 0;
+        if (state && blockIdx.x == 0 && threadIdx.x < 8) {
+            // bounds of the kept second-level table: what the last call's k_nb_memo2 filled it up to
+            // (that call's largest missed pair, still in state[0..1]) becomes part of them
+            if (have && threadIdx.x < 2) {
+                const int cap = (threadIdx.x == 0 ? rows : stride) - 1;
+                const int h = have[threadIdx.x];
+                have[threadIdx.x] = have_state == 2 ? -1 : (have_state == 1 ? max(h, min(state[threadIdx.x], cap)) : h);
+            }
+            state[threadIdx.x] = threadIdx.x < 2 ? -1 : 0;
+        }
     }
     // blockIdx.y = model slot: one table per dispersion model in use
     __shared__ double par[24];
@@ -374,20 +385,25 @@ __global__ void __launch_bounds__(256, 4) k_nb_memo(const double *__restrict__ m
 // corner the first-level table already holds.  Heavy-tailed data (hotspots with counts in the
 // hundreds) would otherwise send every base of a flagged tile through the direct incbet.
 __global__ void __launch_bounds__(256, 4) k_nb_memo2(const double *__restrict__ models, const int32_t *__restrict__ mx,
-                                                     int memo_exp, int memo_obs, int rows, int stride,
-                                                     double2 *__restrict__ memos) {
+                                                     const int32_t *__restrict__ have, int memo_exp, int memo_obs,
+                                                     int rows, int stride, double2 *__restrict__ memos) {
     __shared__ double par[24];
     const double *model = models + (size_t)blockIdx.y * 24;
     double2 *memo = memos + (size_t)blockIdx.y * rows * stride;
     if (threadIdx.x < 24) par[threadIdx.x] = model[threadIdx.x];
     __syncthreads();
-    const int ne = min(mx[0] + 1, rows), nk = min(mx[1] + 1, stride);
+    // the table is kept across calls (fpt_capi.cpp): filled up to `have` already; this call reaches
+    // max(have, missed) and computes what lies between
+    const int he = have[0] + 1, hk = have[1] + 1;
+    if (mx[0] < he && mx[1] < hk) return;  // nothing missed beyond what is there
+    const int ne = min(max(mx[0] + 1, he), rows), nk = min(max(mx[1] + 1, hk), stride);
     if (ne <= 0 || nk <= 0) return;
     // one entry per thread, then the next block row: no loop around the incbet body (see k_nb_values)
     const long long n = (long long)ne * nk;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int ei = (int)(idx / nk), k = (int)(idx % nk);
         if (ei < memo_exp && k < memo_obs) continue;  // first-level table
+        if (ei < he && k < hk) continue;              // kept from an earlier call
         bool zd = false;
         const double ex = (double)ei;
         double r = fptm::fit_r(par + 9, ex, &zd);
@@ -1045,7 +1061,8 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
             pv = z = NAN;
             a.redo[tile] = 1;  // the full instance recomputes this tile
         } else if (a.memo2 && ex >= 0.0 && ex < (double)a.memo2_rows && (double)ei == ex && k >= 0 &&
-                   k < a.memo2_stride && ei <= a.memo2_max[0] && k <= a.memo2_max[1]) {
+                   k < a.memo2_stride && ei <= max(a.memo2_max[0], a.memo2_have[0]) &&
+                   k <= max(a.memo2_max[1], a.memo2_have[1])) {
             // second-level table, built between the passes for the pairs the first pass missed
             const double2 pz = a.memo2[((size_t)dm * a.memo2_rows + ei) * a.memo2_stride + k];
             pv = pz.x;
@@ -2162,6 +2179,7 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
     a.dm_ids = sl.dm_ids;
     a.memo2 = (const double2 *)sl.memo2;
     a.memo2_max = sl.memo2_max;
+    a.memo2_have = sl.memo2_have;
     a.memo2_rows = sl.memo2_rows;
     a.memo2_stride = sl.memo2_stride;
     a.fast_trim = (sl.k_trim == 1 && sl.shw >= 32 && sl.nc_max <= 3 * nt) ? 1 : 0;
@@ -2185,16 +2203,17 @@ void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch
 }
 
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs,
-                    void *memo, int32_t *clear, int64_t n_clear, int32_t *state) {
+                    void *memo, int32_t *clear, int64_t n_clear, int32_t *state, int32_t *have, int have_state,
+                    int rows, int stride) {
     int n = memo_exp * memo_obs;
     hipLaunchKernelGGL(k_nb_memo, dim3((n + 255) / 256, n_models), dim3(256), 0, st, models, memo_exp,
-                       memo_obs, (double2 *)memo, clear, n_clear, state);
+                       memo_obs, (double2 *)memo, clear, n_clear, state, have, have_state, rows, stride);
 }
 
-void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
-                     int memo_obs, int rows, int stride, void *memo2) {
-    hipLaunchKernelGGL(k_nb_memo2, dim3(1024, n_models), dim3(256), 0, st, models, miss_max, memo_exp, memo_obs, rows,
-                       stride, (double2 *)memo2);
+void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, const int32_t *have,
+                     int memo_exp, int memo_obs, int rows, int stride, void *memo2) {
+    hipLaunchKernelGGL(k_nb_memo2, dim3(1024, n_models), dim3(256), 0, st, models, miss_max, have, memo_exp, memo_obs,
+                       rows, stride, (double2 *)memo2);
 }
 
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {

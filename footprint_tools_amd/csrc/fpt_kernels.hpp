@@ -45,6 +45,7 @@ struct scan_launch {
     // second-level (exp, obs) table of the redo pass (launch_nb_memo2), or nullptr
     const void *memo2;
     int32_t *memo2_max;    // device: [0] largest exp, [1] largest obs the first pass missed (-1: none)
+    const int32_t *memo2_have;  // device: the table is filled for exp <= [0] and obs <= [1] already (kept across calls)
     int32_t memo2_rows, memo2_stride;
 };
 
@@ -146,10 +147,15 @@ hipError_t scan_set_lds(int nt, int hw, int shw, bool tblg, bool memo_only, bool
 void launch_scan(hipStream_t st, int nt, int grid, size_t lds, const scan_launch &sl, bool memo_only);
 // clear / n_clear: int32 words set to 0; state: 8 ints set to (-1, -1, 0 x 6) -- the largest missed pair
 // and three (count, cursor) pairs of the second pass; both optional
+// have / have_state: the bounds of the kept second-level table (2 ints) -- 0 left as they are, 1 the
+// missed pair recorded in `state` (which the last launch_nb_memo2 filled the table up to) joins
+// them, 2 set to (-1, -1): nothing kept; rows / stride: that table's capacity
 void launch_nb_memo(hipStream_t st, const double *models, int n_models, int memo_exp, int memo_obs, void *memo,
-                    int32_t *clear = nullptr, int64_t n_clear = 0, int32_t *state = nullptr);
-void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, int memo_exp,
-                     int memo_obs, int rows, int stride, void *memo2);
+                    int32_t *clear = nullptr, int64_t n_clear = 0, int32_t *state = nullptr, int32_t *have = nullptr,
+                    int have_state = 0, int rows = 0, int stride = 0);
+// fills the entries up to max(have, miss_max) that lie outside `have` and outside the first-level table
+void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const int32_t *miss_max, const int32_t *have,
+                     int memo_exp, int memo_obs, int rows, int stride, void *memo2);
 void launch_detect_columns(hipStream_t st, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off,
                            const int32_t *status, const double *ex, const double *ob, const double *pv,
                            const double *wp, const double *ef, int64_t total, double *out);

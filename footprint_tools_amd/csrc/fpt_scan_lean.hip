@@ -80,6 +80,10 @@ struct lean_args {
     int32_t *redo;
     int32_t *miss_max;  // [0] largest exp, [1] largest obs among the pairs that missed the table
     int32_t miss_rows, miss_stride;  // ... as far as the second-level table could hold them
+    // the second-level table the context keeps (fpt_capi.cpp): filled for exp <= memo2_have[0] and
+    // obs <= memo2_have[1] by earlier calls; a pair that misses the first level is looked up there
+    const double2 *memo2;
+    const int32_t *memo2_have;
     const int32_t *dm_ids;
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
     int64_t *trace;  // -DFPT_ABLATE builds: per-workgroup timestamps (FPT_LEAN_TRACE)
@@ -406,11 +410,13 @@ struct lean_tracks {
 // (exp, obs) table.  Lanes beyond nt return z = 0.
 template <int NT>
 __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_args &a, kcoef *kc, const double2 *memo,
-                                              int nt, int tid, lean_tracks &tr, double &z) {
+                                              int dm, int nt, int tid, lean_tracks &tr, double &z) {
     bool bad = false;
     z = 0.0;
     tr.ex = tr.pv = 0.0;
     tr.k = 0;
+    bool miss = false;  // a lane whose (exp, obs) pair lies outside the table but inside the second-level bounds
+    u32 miss_e = 0;
     if (tid < nt) {
         double e2[2];
 #pragma unroll
@@ -440,14 +446,34 @@ __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_
         tr.ex = e2[0] + e2[1];
         tr.k = (m.pk[8 + kPad + 1 + tid] & 0xffffu) + (m.pk[8 + kPad + tid] >> 16);
         const u32 ei = (u32)(int)tr.ex;
-        const bool hit = ei < (u32)a.memo_exp && tr.k < (u32)a.memo_obs;
-        const double2 pz = memo[hit ? ei * (u32)a.memo_obs + tr.k : 0u];
+        bool hit = ei < (u32)a.memo_exp && tr.k < (u32)a.memo_obs;
+        double2 pz = memo[hit ? ei * (u32)a.memo_obs + tr.k : 0u];
+        if (!hit && a.memo2) {  // (rare: hotspots) the kept second-level table, as far as it is filled
+            const int h0 = a.memo2_have[0], h1 = a.memo2_have[1];
+            if (h0 >= 0 && h1 >= 0 && ei <= (u32)h0 && tr.k <= (u32)h1) {
+                pz = a.memo2[((size_t)dm * a.miss_rows + ei) * a.miss_stride + tr.k];
+                hit = true;
+            }
+        }
         tr.pv = pz.x;
         z = pz.y;
         bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
-        if (!hit && a.miss_max && ei < (u32)a.miss_rows && tr.k < (u32)a.miss_stride) {
-            atomicMax(&a.miss_max[0], (int)ei);  // sizes the second-level table of the redo pass
-            atomicMax(&a.miss_max[1], (int)tr.k);
+        miss = !hit && a.miss_max && ei < (u32)a.miss_rows && tr.k < (u32)a.miss_stride;
+        miss_e = ei;
+    }
+    // the largest missed pair sizes the second-level table of the redo pass: one pair of atomics per
+    // wavefront that has a miss (a hotspot tile has hundreds of missing lanes; one atomic per lane
+    // on the same two words cost 1.4 ms of the 24.9 ms heavy-tailed launch)
+    if (__builtin_amdgcn_ballot_w64(miss)) {
+        int me = miss ? (int)miss_e : -1, mk = miss ? (int)tr.k : -1;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) {
+            me = max(me, __shfl_xor(me, d));
+            mk = max(mk, __shfl_xor(mk, d));
+        }
+        if ((tid & 63) == 0) {
+            atomicMax(&a.miss_max[0], me);
+            atomicMax(&a.miss_max[1], mk);
         }
     }
     return bad;
@@ -598,7 +624,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
 
     lean_tracks tr;
     double z;
-    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.nt, tid, tr, z);
+    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.dm, g.nt, tid, tr, z);
     const lean_owner o = lean_own(g, tid, LEAN_STOP(6));
     lean_store_tracks(a, o, tr);
 
@@ -709,6 +735,8 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     a.miss_max = sl.memo2 ? sl.memo2_max : nullptr;
     a.miss_rows = sl.memo2_rows;
     a.miss_stride = sl.memo2_stride;
+    a.memo2 = (const double2 *)sl.memo2;
+    a.memo2_have = sl.memo2_have;
     a.dm_ids = sl.dm_ids;
     a.stop = sl.ablate;
     a.trace = nullptr;

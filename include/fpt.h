@@ -189,6 +189,17 @@ enum fpt_nb_mode { FPT_NB_AUTO = 0, FPT_NB_DIRECT = 1, FPT_NB_MEMO = 2, FPT_NB_N
  * table has the same rows and by default 2048 obs columns; this call sets its columns too. */
 int fpt_set_memo_dims(fpt_ctx *ctx, int memo_exp, int memo_obs);
 
+/* FPT_NB_MEMO keeps one thing across calls: the second-level (exp, obs) table for pairs beyond the
+ * first-level one (hotspots: counts in the hundreds).  It is a function of the dispersion models
+ * alone, up to 4096 x 4096 entries per model, and grows to the largest pair any call has met: the
+ * call that first meets a range computes it between its two passes (and sends the tiles that
+ * needed it through the general kernel), later calls look it up in the first pass.  It is emptied
+ * when a model of the batch changes (fpt_set_dispersion with other values), when the batch uses
+ * other model slots, and by this call (measurements of the cold path; FPT_MEMO2_KEEP=0 in the
+ * environment of fpt_ctx_create empties it at every call).  No reference counterpart: the reference
+ * evaluates scipy's nbinom.cdf per base (modeling/dispersion.pyx:311-314). */
+int fpt_drop_kept_tables(fpt_ctx *ctx);
+
 /* Enqueue the fused scan on the context's stream (no synchronisation). */
 int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
 
