@@ -1465,16 +1465,43 @@ __device__ __forceinline__ double ndtr_threshold(double P) {
     return from_ordered_bits(hi);
 }
 
+// The same threshold when a y with ndtr(y) == P is at hand (the observed window's own y): the upper
+// end of P's plateau is a gallop and a bisection away from it -- about five evaluations of ndtr
+// where the search from ndtri(P) needs ten and the ndtri.
+__device__ __forceinline__ double ndtr_threshold_from(double y, double P) {
+    long long lo = ordered_bits(y), hi, step = 1;  // ndtr(lo) <= P
+    for (;;) {
+        const long long c = lo + step;
+        if (fptm::ndtr(from_ordered_bits(c)) > P) {
+            hi = c;
+            break;
+        }
+        lo = c;
+        step <<= 1;
+    }
+    while (hi - lo > 1) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (fptm::ndtr(from_ordered_bits(mid)) > P) hi = mid; else lo = mid;
+    }
+    return from_ordered_bits(hi);
+}
+// threshold of an observed value that is not below 1 (the edge positions' constant 1.0): above every
+// finite y, below the +inf that stands for "not a number" in the sort
+constexpr double kThresholdOfOne = 1e300;
+
 // GWS: the per-interval buffers live in global memory instead of LDS -- the same code for
 // intervals too long for the 160 KB of a CU (one workgroup still owns one interval, and a
 // workgroup's own global writes are visible to it after __syncthreads()).
-template <int NT, bool GWS>
+// HSC: the half window width at compile time (3, the only one the reference uses: the window sums
+// unroll into 14 LDS reads with immediate offsets), or 0 for any width.
+template <int NT, bool GWS, int HSC>
 __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
     double *par = GWS ? reinterpret_cast<double *>(a.gws + (size_t)blockIdx.x * a.gws_stride) : smem;  // 24
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
-    double *zb = skey + n2;                          // 4 x n2: z of the pass's four samples (tile prefix sums of two with wide windows)
+    double *zb = skey + n2;                          // 4 x n2: z of the pass's four samples, the four of a position side by side
+                                                     // (with wide windows: two arrays of n2 tile prefix sums)
     double *zalt = zb + 4 * n2;                      // 4 x n2 more when a.dbuf (passes alternate between the sets)
     int *sidx = reinterpret_cast<int *>(zalt + (a.dbuf ? 4 * n2 : 0));  // n2 original positions
     int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
@@ -1484,6 +1511,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
+    const int hs = HSC ? HSC : a.hw;
     const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
     int64_t off;
     int L;
@@ -1547,20 +1575,21 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 n_num += 1;
                 n_below_one += (P < 1.0) ? 1 : 0;
             } else if (!(P < 1.0)) {
-                v = P;
+                v = kThresholdOfOne;
                 n_num += 1;  // an edge position (or p = 1): above every null window
             } else {
                 // this position's window p-value once more, from its own y through the function the
                 // thresholds below are searched with
                 double sm = NAN;
-                if (i >= a.hw && i < L - a.hw) {
+                if (i >= hs && i < L - hs) {
                     sm = 0.0;
-                    for (int j = i - a.hw; j <= i + a.hw; ++j) sm += zb[j];
+                    for (int j = i - hs; j <= i + hs; ++j) sm += zb[j];
                 }
                 if (isfinite(sm)) {
-                    v = fptm::ndtr(-div_invariant(sm, a.sqrt_k, a.inv_sqrt_k));
+                    // the sort key is this y: the order of the p-values (ndtr is monotone; the order
+                    // among equal p-values does not matter), and what the threshold search starts from
+                    v = -div_invariant(sm, a.sqrt_k, a.inv_sqrt_k);
                     n_num += 1;
-                    n_below_one += (v < 1.0) ? 1 : 0;
                 }  // else: the tracks disagree (a p-value where the counts give none): not a number
             }
         }
@@ -1574,7 +1603,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     if (n_below_one) atomicAdd(&misc[2], n_below_one);
     // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
     // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
-    for (int k = 2; k <= np2; k <<= 1) {
+    for (int k = 2; k <= (ABL(16384) ? 0 : np2); k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NT) {
                 const int ixj = i ^ j;
@@ -1595,11 +1624,31 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     __syncthreads();
     const int m = misc[1];         // observed values that are not NaN (NaN / pads were mapped to +inf)
-    const int rank_one = misc[2];  // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
-    for (int i = tid; i < m; i += NT) skey[i] = ndtr_threshold(skey[i]);
-    __syncthreads();
+    // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
+    // (after the sort: neighbouring lanes then search neighbouring values, whose searches are about
+    // equally long -- in the order of the positions a wavefront waits for its one value in the tail)
+    if (!a.obs) {
+        for (int i = tid; i < m; i += NT) skey[i] = ABL(8192) ? fptm::ndtri(skey[i]) : ndtr_threshold(skey[i]);
+        __syncthreads();
+    } else {
+        int below = 0;
+        for (int i = tid; i < m; i += NT) {
+            const double yo = skey[i];
+            if (yo == kThresholdOfOne) continue;
+            const double pv = fptm::ndtr(yo);  // the observed window p-value, by the function the search uses
+            if (pv < 1.0) {
+                skey[i] = ABL(8192) ? yo : ndtr_threshold_from(yo, pv);
+                below += 1;
+            } else {
+                skey[i] = kThresholdOfOne;
+            }
+        }
+        if (below) atomicAdd(&misc[2], below);
+        __syncthreads();
+    }
     // rank guide: y of a null window is about standard normal; nb slices of [-kYR, kYR) (the first
     // and last reach to infinity) bracket #{T <= y}, so a rank needs a probe or two, not log2(L)
+    const int rank_one = misc[2];  // thresholds of values below 1
     constexpr double kYR = 4.5;
     const int nb = np2 < 2048 ? np2 : 2048;
     const double yscale = (double)nb / (2.0 * kYR);
@@ -1621,7 +1670,6 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 
     // ---- 2. null tracks, four samples per pass with narrow windows (one Philox block feeds the
     //         four), two with wide ones
-    const int hs = a.hw;
     // Narrow windows (the reference only ever uses hw = 3) are summed directly from the raw z in
     // LDS, left to right like windowing.h:53-67: 2*hs+1 reads and adds are fewer instructions than
     // three prefix scans plus three tile-range sums, and a non-finite z shows up as a non-finite
@@ -1684,10 +1732,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                     }
                 }
                 if (direct) {
-                    if (t < L) {
-                        zq[(2 * pr) * n2 + t] = za;
-                        zq[(2 * pr + 1) * n2 + t] = zb_;
-                    }
+                    if (t < L) *reinterpret_cast<double2 *>(zq + 4 * t + 2 * pr) = make_double2(za, zb_);
                 } else {
                     const bool f0 = isfinite(za), f1 = isfinite(zb_);
                     const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
@@ -1706,9 +1751,18 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             if (direct) {
                 if (t >= hs && t < L - hs) {
                     double sm[4] = {0.0, 0.0, 0.0, 0.0};
-                    for (int j = t - hs; j <= t + hs; ++j) {
+                    const double2 *zw = reinterpret_cast<const double2 *>(zq + 4 * (t - hs));
+                    if constexpr (HSC > 0) {
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) sm[w] += zq[w * n2 + j];
+                        for (int j = 0; j <= 2 * HSC; ++j) {
+                            const double2 p01 = zw[2 * j], p23 = zw[2 * j + 1];
+                            sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
+                        }
+                    } else {
+                        for (int j = 0; j <= 2 * hs; ++j) {
+                            const double2 p01 = zw[2 * j], p23 = zw[2 * j + 1];
+                            sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
+                        }
                     }
 #pragma unroll
                     for (int w = 0; w < 4; ++w) y[w] = isfinite(sm[w]) ? -div_invariant(sm[w], a.sqrt_k, a.inv_sqrt_k) : NAN;
@@ -1790,11 +1844,16 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
 }
 
-template __global__ void k_fdr_null<256, false>(const fdr_args);
-template __global__ void k_fdr_null<128, false>(const fdr_args);  // size classes of short intervals: fewer idle lanes
-template __global__ void k_fdr_null<64, false>(const fdr_args);
-template __global__ void k_fdr_null<192, false>(const fdr_args);  // 129..192 bases in one pass, 257..384 in two
-template __global__ void k_fdr_null<256, true>(const fdr_args);
+template __global__ void k_fdr_null<256, false, 3>(const fdr_args);
+template __global__ void k_fdr_null<128, false, 3>(const fdr_args);  // size classes of short intervals: fewer idle lanes
+template __global__ void k_fdr_null<64, false, 3>(const fdr_args);
+template __global__ void k_fdr_null<192, false, 3>(const fdr_args);  // 129..192 bases in one pass, 257..384 in two
+template __global__ void k_fdr_null<256, true, 3>(const fdr_args);
+template __global__ void k_fdr_null<256, false, 0>(const fdr_args);
+template __global__ void k_fdr_null<128, false, 0>(const fdr_args);
+template __global__ void k_fdr_null<64, false, 0>(const fdr_args);
+template __global__ void k_fdr_null<192, false, 0>(const fdr_args);
+template __global__ void k_fdr_null<256, true, 0>(const fdr_args);
 
 // ===========================================================================
 // k_detect_columns: the record columns of `ftd detect` for a whole batch (cli/detect.py:136-146):
@@ -2266,7 +2325,8 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             fdr_args b = a;
             if (b.iv_list) b.iv_list += done; else b.iv_first = done;
             const int64_t n = n_blocks - done < per ? n_blocks - done : per;
-            hipLaunchKernelGGL((k_fdr_null<256, true>), dim3((unsigned)n), dim3(256), 0, st, b);
+            if (fl.hw == 3) hipLaunchKernelGGL((k_fdr_null<256, true, 3>), dim3((unsigned)n), dim3(256), 0, st, b);
+            else hipLaunchKernelGGL((k_fdr_null<256, true, 0>), dim3((unsigned)n), dim3(256), 0, st, b);
         }
         return hipSuccess;
     }
@@ -2275,9 +2335,13 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     size_t lds = fdr_lds_bytes(fl.n2_max, a.dbuf != 0);
     // one lane per base and null track: intervals of up to 64 / 128 bases get workgroups of that size
     const int nt = fl.nt ? fl.nt : (fl.n2_max <= 64 ? 64 : (fl.n2_max <= 128 ? 128 : 256));
-    void (*kern)(const fdr_args) = nt == 64 ? k_fdr_null<64, false>
-                                   : nt == 128 ? k_fdr_null<128, false>
-                                   : nt == 192 ? k_fdr_null<192, false> : k_fdr_null<256, false>;
+    void (*kern)(const fdr_args);
+    if (fl.hw == 3)
+        kern = nt == 64 ? k_fdr_null<64, false, 3> : nt == 128 ? k_fdr_null<128, false, 3>
+               : nt == 192 ? k_fdr_null<192, false, 3> : k_fdr_null<256, false, 3>;
+    else
+        kern = nt == 64 ? k_fdr_null<64, false, 0> : nt == 128 ? k_fdr_null<128, false, 0>
+               : nt == 192 ? k_fdr_null<192, false, 0> : k_fdr_null<256, false, 0>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {

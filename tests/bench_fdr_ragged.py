@@ -12,6 +12,7 @@ from footprint_tools_amd import _lib  # noqa: E402
 from footprint_tools_amd.scan import DeviceArray, FootprintScanner  # noqa: E402
 
 n_iv = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+NO_OBS = len(sys.argv) > 3 and sys.argv[3] == "noobs"  # the observed windows taken from the p-value track
 g = np.load("tests/golden/kmer_probs.npz")
 lat = np.load("tests/golden/nb_lattice.npz")
 
@@ -35,9 +36,10 @@ t8 = total * 8
 sc.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr, d_out.ptr + t8, d_out.ptr + 2 * t8, d_out.ptr + 3 * t8,
             interval_off_dev=d_off.ptr, interval_off_host=off)
 ctx.synchronize()
-for times in (4, 52, 100):
+for times in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4, 52, 100)):
     def step():
-        sc.fdr_dev(n_iv, d_out.ptr, d_out.ptr + 3 * t8, d_out.ptr + 4 * t8, times=times, seed=1, interval_off_dev=d_off.ptr)
+        sc.fdr_dev(n_iv, d_out.ptr, d_out.ptr + 3 * t8, d_out.ptr + 4 * t8, times=times, seed=1, interval_off_dev=d_off.ptr,
+                   obs=None if NO_OBS else d_out.ptr + t8)
     step()
     ctx.synchronize()
     t0 = time.perf_counter()
