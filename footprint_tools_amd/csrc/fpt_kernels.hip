@@ -1283,30 +1283,25 @@ struct fdr_args {
     int64_t gws_stride;
 };
 
-// Guide table of the inverse-CDF sampler: guide[row][slot] = smallest k with
-// cdf(k) >= guide_edge(slot) (or the last tabulated k), so a draw u starts its search at
-// guide[row][guide_slot(u)], knows the answer is no later than the next entry, and walks a step
-// or two instead of bisecting the whole row (every step is a divergent gather, and a wavefront
-// waits for its slowest lane).  Each row has kGuide + 1 entries, the last is the table end.
-constexpr int kGuide = fptm::kGuideSlots;
+// Guide table of the inverse-CDF sampler: guide[row][idx] = smallest k with
+// cdf(k) >= guide_edge(idx) (or the last tabulated k), so a draw starts its search between
+// guide[row][guide_index(w)] and the next entry, and walks a step or two instead of bisecting the
+// whole row (every step is a divergent gather, and a wavefront waits for its slowest lane).
+constexpr int kGuide = fptm::kGuideEntries;
 
 __global__ void __launch_bounds__(256) k_nb_guide(const double2 *__restrict__ memo, int memo_exp, int memo_obs,
                                                   uint16_t *__restrict__ guide) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= memo_exp * (kGuide + 1)) return;
-    const int ei = i / (kGuide + 1), g = i % (kGuide + 1);
+    if (i >= memo_exp * kGuide) return;
+    const int ei = i / kGuide, g = i % kGuide;
     const double2 *row = memo + ((size_t)blockIdx.y * memo_exp + ei) * memo_obs;
-    int l = memo_obs - 1;  // entry kGuide: the end of the table
-    if (g < kGuide) {
-        const double t = fptm::guide_edge(g);
-        int h = memo_obs - 1;
-        l = 0;
-        while (l < h) {
-            const int mid = (l + h) >> 1;
-            if (row[mid].x >= t) h = mid; else l = mid + 1;
-        }
+    const double t = fptm::guide_edge(g);
+    int l = 0, h = memo_obs - 1;  // (an edge no tabulated cdf reaches: the end of the table)
+    while (l < h) {
+        const int mid = (l + h) >> 1;
+        if (row[mid].x >= t) h = mid; else l = mid + 1;
     }
-    guide[((size_t)blockIdx.y * memo_exp + ei) * (kGuide + 1) + g] = (uint16_t)l;
+    guide[((size_t)blockIdx.y * memo_exp + ei) * kGuide + g] = (uint16_t)l;
 }
 
 // Draw beyond the table (or at a non-integer expected value): gallop, then bisect on the direct
@@ -1350,18 +1345,21 @@ __device__ __forceinline__ int table_row_of(double ex, int memo_exp) {
 }
 
 __device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_obs,
-                                           const double *par, int ei, const double *exp_ptr, double u0, double u1,
-                                           double &z0, double &z1) {
+                                           const double *par, int ei, const double *exp_ptr, uint32_t w0, uint32_t w1,
+                                           double u0, double u1, double &z0, double &z1) {
     int lo0 = -1, lo1 = -1;
     bool d0 = true, d1 = true;  // still to be evaluated directly
     if (ei >= 0) {
         const double2 *row = memo + (size_t)ei * memo_obs;
-        const uint16_t *gr = guide + (size_t)ei * (kGuide + 1);
+        const uint16_t *gr = guide + (size_t)ei * kGuide;
         const int kl = memo_obs - 1;
-        double f0, f1;
-        const int s0 = fptm::guide_locate(u0, f0), s1 = fptm::guide_locate(u1, f1);
+        float f0, f1;
+        const int s0 = fptm::guide_index(w0, f0), s1 = fptm::guide_index(w1, f1);
         const int a0 = gr[s0], b0 = gr[s0 + 1], a1 = gr[s1], b1 = gr[s1 + 1];  // answer in [a, b]
-        int k0 = a0 + (int)(f0 * (double)(b0 - a0)), k1 = a1 + (int)(f1 * (double)(b1 - a1));
+        // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
+        // outermost slot, open towards the end of the table: start at its near end)
+        int k0 = a0 + (b0 - a0 > 64 ? 0 : (int)(f0 * (float)(b0 - a0)));
+        int k1 = a1 + (b1 - a1 > 64 ? 0 : (int)(f1 * (float)(b1 - a1)));
         double2 e0 = row[k0], e1 = row[k1];
         // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
         // below has to be looked at unless the guide already says it is < u (k == a).
@@ -1489,6 +1487,18 @@ __device__ __forceinline__ double ndtr_threshold_from(double y, double P) {
 // finite y, below the +inf that stands for "not a number" in the sort
 constexpr double kThresholdOfOne = 1e300;
 
+// A null window's y is x / sqrt(K) rounded once, x = -(sum of z) (windowing.h:64), and that division
+// is monotone in x: "T <= y" is "X(T) <= x" with X(T) the smallest x whose quotient reaches T.  With
+// the thresholds translated once more, from y to x, a null window is ranked by its raw sum and the
+// division per null value goes away.  (T sqrt(K) is within two ulps of X: a step or two.)
+__device__ __forceinline__ double sum_threshold(double T, double sqrt_k, double inv_sqrt_k) {
+    if (!(fabs(T) < 1e299)) return T;  // kThresholdOfOne and the infinities stay what they are
+    long long k = ordered_bits(T * sqrt_k);
+    while (div_invariant(from_ordered_bits(k - 1), sqrt_k, inv_sqrt_k) >= T) --k;
+    while (!(div_invariant(from_ordered_bits(k), sqrt_k, inv_sqrt_k) >= T)) ++k;
+    return from_ordered_bits(k);
+}
+
 // GWS: the per-interval buffers live in global memory instead of LDS -- the same code for
 // intervals too long for the 160 KB of a CU (one workgroup still owns one interval, and a
 // workgroup's own global writes are visible to it after __syncthreads()).
@@ -1529,7 +1539,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
-    const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * (kGuide + 1);
+    const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * kGuide;
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
     // ---- 0. with the observed counts at hand, the observed window p-values are re-made here by the
     // very operations the null windows go through below -- z of the (exp, obs) pair from the same
@@ -1628,7 +1638,8 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     // (after the sort: neighbouring lanes then search neighbouring values, whose searches are about
     // equally long -- in the order of the positions a wavefront waits for its one value in the tail)
     if (!a.obs) {
-        for (int i = tid; i < m; i += NT) skey[i] = ABL(8192) ? fptm::ndtri(skey[i]) : ndtr_threshold(skey[i]);
+        for (int i = tid; i < m; i += NT)
+            skey[i] = sum_threshold(ABL(8192) ? fptm::ndtri(skey[i]) : ndtr_threshold(skey[i]), a.sqrt_k, a.inv_sqrt_k);
         __syncthreads();
     } else {
         int below = 0;
@@ -1637,7 +1648,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             if (yo == kThresholdOfOne) continue;
             const double pv = fptm::ndtr(yo);  // the observed window p-value, by the function the search uses
             if (pv < 1.0) {
-                skey[i] = ABL(8192) ? yo : ndtr_threshold_from(yo, pv);
+                skey[i] = sum_threshold(ABL(8192) ? yo : ndtr_threshold_from(yo, pv), a.sqrt_k, a.inv_sqrt_k);
                 below += 1;
             } else {
                 skey[i] = kThresholdOfOne;
@@ -1646,10 +1657,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         if (below) atomicAdd(&misc[2], below);
         __syncthreads();
     }
-    // rank guide: y of a null window is about standard normal; nb slices of [-kYR, kYR) (the first
-    // and last reach to infinity) bracket #{T <= y}, so a rank needs a probe or two, not log2(L)
+    // rank guide: x / sqrt(K) of a null window is about standard normal; nb slices of [-kYR, kYR) (the
+    // first and last reach to infinity) bracket #{X <= x}, so a rank needs a probe or two, not log2(L)
     const int rank_one = misc[2];  // thresholds of values below 1
-    constexpr double kYR = 4.5;
+    const double kYR = 4.5 * a.sqrt_k;
     const int nb = np2 < 2048 ? np2 : 2048;
     const double yscale = (double)nb / (2.0 * kYR);
     for (int b = tid; b <= nb; b += NT) {
@@ -1712,11 +1723,14 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 #pragma clang loop unroll(disable)
             for (int pr = 0; pr < npairs; ++pr) {
                 // u = (word + 1/2) 2^-32 (philox_uniform4), or the caller's uniforms (tests)
-                double ua = ((double)(pr ? o[2] : o[0]) + 0.5) * (1.0 / 4294967296.0);
-                double ub = ((double)(pr ? o[3] : o[1]) + 0.5) * (1.0 / 4294967296.0);
+                uint32_t wa = pr ? o[2] : o[0], wb = pr ? o[3] : o[1];
+                double ua = fma((double)wa, 1.0 / 4294967296.0, 0.5 / 4294967296.0);
+                double ub = fma((double)wb, 1.0 / 4294967296.0, 0.5 / 4294967296.0);
                 if (up && t < L) {
                     ua = up[2 * pr];
                     ub = 2 * pr + 1 < ns ? up[2 * pr + 1] : 0.5;
+                    wa = fptm::guide_word(ua);
+                    wb = fptm::guide_word(ub);
                 }
                 if (ABL(512)) {
                     ua = 0.37 + 1e-3 * s + 0.04 * pr;
@@ -1728,7 +1742,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                         za = ua - 0.5;
                         zb_ = ub - 0.5;
                     } else {
-                        nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, ua, ub, za, zb_);
+                        nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, wa, wb, ua, ub, za, zb_);
                     }
                 }
                 if (direct) {
@@ -1744,10 +1758,11 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         }
         __syncthreads();
         for (int t = tid; t < L; t += NT) {
-            // y of the null windows: NaN when a z in the window is not finite, +inf stands for
-            // the edges, whose window p-value is the constant 1.0 (windowing.pyx:51) and which are
-            // part of the pooled null
-            double y[4] = {fptm::kInf, fptm::kInf, fptm::kInf, fptm::kInf};
+            // x = -(sum of z) of the null windows (y = x / sqrt(K) is what the thresholds were translated
+            // from): NaN when a z in the window is not finite, +inf stands for the edges, whose window
+            // p-value is the constant 1.0 (windowing.pyx:51) and which are part of the pooled null
+            // (four named values: an array indexed by the pair would live in scratch memory)
+            double x0 = fptm::kInf, x1 = fptm::kInf, x2 = fptm::kInf, x3 = fptm::kInf;
             if (direct) {
                 if (t >= hs && t < L - hs) {
                     double sm[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1764,23 +1779,29 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                             sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
                         }
                     }
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) y[w] = isfinite(sm[w]) ? -div_invariant(sm[w], a.sqrt_k, a.inv_sqrt_k) : NAN;
+                    x0 = isfinite(sm[0]) ? -sm[0] : NAN;
+                    x1 = isfinite(sm[1]) ? -sm[1] : NAN;
+                    x2 = isfinite(sm[2]) ? -sm[2] : NAN;
+                    x3 = isfinite(sm[3]) ? -sm[3] : NAN;
                 }
             } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
                 const double s0 = le3 ? tile_range_sum3(zq, t - hs, t + hs) : tile_range_sum(zq, t - hs, t + hs);
                 const double s1 = le3 ? tile_range_sum3(zq + n2, t - hs, t + hs) : tile_range_sum(zq + n2, t - hs, t + hs);
                 const int sc = le3 ? tile_range_sum3(nf, t - hs, t + hs) : tile_range_sum(nf, t - hs, t + hs);
-                y[0] = (sc & 0xffff) ? NAN : -div_invariant(s0, a.sqrt_k, a.inv_sqrt_k);
-                y[1] = (sc >> 16) ? NAN : -div_invariant(s1, a.sqrt_k, a.inv_sqrt_k);
+                x0 = (sc & 0xffff) ? NAN : -s0;
+                x1 = (sc >> 16) ? NAN : -s1;
             }
             if (a.null_out) {  // the p-values themselves only when somebody wants them
                 double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
-                for (int w = 0; w < ns; ++w) np_[w] = y[w] == fptm::kInf ? 1.0 : fptm::ndtr(y[w]);
+#pragma clang loop unroll(disable)
+                for (int w = 0; w < ns; ++w) {
+                    const double xw = w == 0 ? x0 : (w == 1 ? x1 : (w == 2 ? x2 : x3));
+                    np_[w] = xw == fptm::kInf ? 1.0 : fptm::ndtr(div_invariant(xw, a.sqrt_k, a.inv_sqrt_k));
+                }
             }
             if (ABL(4096)) {
-                if (y[0] == 12345.0 || y[1] == 12345.0 || y[2] == 12345.0 || y[3] == 12345.0) atomicAdd(&misc[0], 1);
+                if (x0 == 12345.0 || x1 == 12345.0 || x2 == 12345.0 || x3 == 12345.0) atomicAdd(&misc[0], 1);
                 continue;
             }
             // rank = #{thresholds <= y}: bisect inside the guide's bracket, two samples in step
@@ -1788,7 +1809,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             const int npairs = ns > 2 ? 2 : 1;
 #pragma clang loop unroll(disable)
             for (int pr = 0; pr < npairs; ++pr) {
-                const double y0 = pr ? y[2] : y[0], y1 = pr ? y[3] : y[1];
+                const double y0 = pr ? x2 : x0, y1 = pr ? x3 : x1;
                 int b0 = (y0 > -kYR) ? (int)((y0 + kYR) * yscale) : 0, b1 = (y1 > -kYR) ? (int)((y1 + kYR) * yscale) : 0;
                 b0 = (b0 < nb && y0 < kYR) ? b0 : nb - 1;
                 b1 = (b1 < nb && y1 < kYR) ? b1 : nb - 1;
@@ -2276,12 +2297,12 @@ void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const i
 }
 
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {
-    hipLaunchKernelGGL(k_nb_guide, dim3((memo_exp * (kGuide + 1) + 255) / 256, n_models), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_nb_guide, dim3((memo_exp * kGuide + 255) / 256, n_models), dim3(256), 0, st,
                        (const double2 *)memo, memo_exp, memo_obs, (uint16_t *)guide);
 }
 
 size_t nb_guide_bytes(int n_models, int memo_exp) {
-    return (size_t)n_models * memo_exp * (kGuide + 1) * sizeof(uint16_t);
+    return (size_t)n_models * memo_exp * kGuide * sizeof(uint16_t);
 }
 
 size_t fdr_lds_bytes(int n2, bool dbuf) {

@@ -747,59 +747,36 @@ FPT_HD double fit_r(const double *r15, double x, bool *zero_div) {
 }
 
 // ---------------------------------------------------------------------------
-// Guide index of the inverse-CDF null sampler.  The unit interval is cut into kGuideSlots
-// buckets that are log-linear in the distance to the nearer end (8 buckets per octave of
-// min(u, 1 - u), down to 2^-21), so both NB tails are resolved as finely as the middle and a
-// draw starts its walk within a step or two of the answer.  guide_slot is monotone in u and
-// guide_edge(slot) <= every u of that slot.
+// Guide index of the inverse-CDF null sampler, on the 32-bit word a draw is made of
+// (u = (w + 1/2) 2^-32; a caller-supplied double u is floored to its word).  Two levels of uniform
+// slots, located with shifts: 256 slots on the top byte of w, and the first and the last of them --
+// the two NB tails -- cut into 256 again on the next byte, so every slot but the outermost two
+// (2^-16 of the draws each) holds a k or two and a draw starts its walk next to the answer.
+// Entry layout of a row: [0, 256] level 1 (edge j / 256), [257, 513] the low tail (edge j / 65536),
+// [514, 770] the high tail (edge 255/256 + j / 65536); entry idx + 1 always closes slot idx.
+// guide_index is monotone in w within a level and guide_edge(idx) <= u < guide_edge(idx + 1).
 // ---------------------------------------------------------------------------
-constexpr int kGuideHalf = 145;
-constexpr int kGuideSlots = 2 * kGuideHalf;
+constexpr int kGuideEntries = 3 * 257;
 
-FPT_HD int guide_half_lo(int i) {  // smallest w = floor(v * 2^21) of half-bucket i
-    if (i < 8) return i;
-    const int oct = (i - 8) >> 3, sub = (i - 8) & 7;
-    return (8 + sub) << oct;
+FPT_HD uint32_t guide_word(double u) {  // the word of a caller-supplied uniform (NaN and u < 0: 0)
+    const double x = u * 4294967296.0;
+    return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 0xffffffffu : (uint32_t)x);
 }
 
-FPT_HD int guide_slot(double u) {
-    const bool up = u >= 0.5;
-    const double v = up ? 1.0 - u : u;  // exact
-    int w = (v > 0.0) ? (int)(v * 2097152.0) : 0;
-    if (w > (1 << 20)) w = 1 << 20;
-    int ih = w;
-    if (w >= 8) {
-        const int hb = 31 - __builtin_clz((unsigned)w);  // position of the leading bit, 3..20
-        ih = 8 + ((hb - 3) << 3) + ((w >> (hb - 3)) - 8);
-    }
-    return up ? kGuideSlots - 1 - ih : ih;
+// index of the slot of w and the position of w inside it, frac in [0, 1)
+FPT_HD int guide_index(uint32_t w, float &frac) {
+    const uint32_t top = w >> 24;
+    const bool low = top == 0u, high = top == 255u;
+    const uint32_t sub = (low || high) ? ((w >> 16) & 255u) : top;
+    const uint32_t fb = (low || high) ? ((w & 0xffffu) << 8) : (w & 0xffffffu);
+    frac = (float)fb * (1.0f / 16777216.0f);
+    return (int)sub + (low ? 257 : (high ? 514 : 0));
 }
 
-// guide_slot(u) together with the position of u inside its slot, frac in [0, 1]
-FPT_HD int guide_locate(double u, double &frac) {
-    const bool up = u >= 0.5;
-    const double v = up ? 1.0 - u : u;
-    double x = (v > 0.0) ? v * 2097152.0 : 0.0;
-    if (x > 1048576.0) x = 1048576.0;
-    const int w = (int)x;
-    int ih = w, lo = w, sh = 0;
-    if (w >= 8) {
-        const int hb = 31 - __builtin_clz((unsigned)w);
-        sh = hb - 3;
-        const int top = w >> sh;  // 8..15
-        ih = 8 + (sh << 3) + (top - 8);
-        lo = top << sh;
-    }
-    const double fv = ldexp(x - (double)lo, -sh);  // [0, 1) of the way through the slot in v
-    frac = up ? 1.0 - fv : fv;
-    return up ? kGuideSlots - 1 - ih : ih;
-}
-
-FPT_HD double guide_edge(int slot) {
-    if (slot < kGuideHalf) return (double)guide_half_lo(slot) * (1.0 / 2097152.0);
-    const int i = kGuideSlots - 1 - slot;  // v < hi(i) * 2^-21  =>  u > 1 - hi(i) * 2^-21
-    if (i + 1 == kGuideHalf) return 0.5;  // that bucket holds u = 0.5 only
-    return 1.0 - (double)guide_half_lo(i + 1) * (1.0 / 2097152.0);
+FPT_HD double guide_edge(int idx) {
+    if (idx <= 256) return (double)idx * (1.0 / 256.0);
+    if (idx <= 513) return (double)(idx - 257) * (1.0 / 65536.0);
+    return 255.0 / 256.0 + (double)(idx - 514) * (1.0 / 65536.0);
 }
 
 }  // namespace fptm

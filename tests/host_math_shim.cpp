@@ -23,10 +23,10 @@ void hm_incbet(const double *a, const double *b, const double *x, long n, double
 void hm_chdtrc(const double *df, const double *x, long n, double *out) {
     for (long i = 0; i < n; i++) out[i] = fptm::chdtrc(df[i], x[i]);
 }
-int hm_guide_slots() { return fptm::kGuideSlots; }
-int hm_guide_slot(double u) { return fptm::guide_slot(u); }
-double hm_guide_edge(int slot) { return fptm::guide_edge(slot); }
-int hm_guide_locate(double u, double *frac) { return fptm::guide_locate(u, *frac); }
+int hm_guide_entries() { return fptm::kGuideEntries; }
+unsigned hm_guide_word(double u) { return fptm::guide_word(u); }
+double hm_guide_edge(int idx) { return fptm::guide_edge(idx); }
+int hm_guide_index(unsigned w, float *frac) { return fptm::guide_index(w, *frac); }
 // what: 0 cdf, 1 logpmf, 2 pmf; returns 1 if a zero division was flagged
 int hm_nb_values(int what, const double *mu9, const double *r15, const double *e, const double *o,
                  long n, double *out) {

@@ -88,39 +88,57 @@ def test_nb_lattice_host(hm):
 
 
 def test_guide_index_of_null_sampler(hm, orc):
-    """guide_slot is monotone, guide_edge(slot) never exceeds a u of that slot, and a walk that
-    starts at the guide entry is short for every expected value of the NB lattice."""
-    hm.hm_guide_slot.argtypes = [C.c_double]
+    """The slot of a draw's 32-bit word: guide_edge(idx) <= u < guide_edge(idx + 1), the index and the
+    position inside a slot grow with the word, and a walk that starts at the guide entry is short for
+    every expected value of the NB lattice."""
     hm.hm_guide_edge.argtypes = [C.c_int]
     hm.hm_guide_edge.restype = C.c_double
-    n = hm.hm_guide_slots()
+    hm.hm_guide_word.argtypes = [C.c_double]
+    hm.hm_guide_word.restype = C.c_uint32
+    hm.hm_guide_index.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+    n = hm.hm_guide_entries()
+    assert n == 3 * 257
     rs = np.random.RandomState(4)
-    u = np.concatenate([rs.random_sample(20000), 2.0 ** -rs.uniform(1, 40, 5000),
-                        1.0 - 2.0 ** -rs.uniform(1, 40, 5000), [0.0, 0.5, 1.0 - 2.0 ** -53, 2.0 ** -53]])
-    u.sort()
-    slot = np.array([hm.hm_guide_slot(float(x)) for x in u])
-    assert slot.min() == 0 and slot.max() == n - 1
-    assert np.all(np.diff(slot) >= 0)
+    w = np.concatenate([rs.randint(0, 2 ** 32, 20000, dtype=np.uint64), rs.randint(0, 2 ** 24, 5000, dtype=np.uint64),
+                        2 ** 32 - 1 - rs.randint(0, 2 ** 24, 5000, dtype=np.uint64),
+                        [0, 1, 2 ** 16 - 1, 2 ** 16, 2 ** 24 - 1, 2 ** 24, 255 * 2 ** 24 - 1, 255 * 2 ** 24,
+                         2 ** 32 - 2 ** 16 - 1, 2 ** 32 - 2 ** 16, 2 ** 32 - 1]]).astype(np.uint64)
+    w.sort()
+    u = (w.astype(np.float64) + 0.5) / 2.0 ** 32
+    fr = C.c_float()
+    loc = np.array([(hm.hm_guide_index(int(x), C.byref(fr)), fr.value) for x in w])
+    idx, frac = loc[:, 0].astype(int), loc[:, 1]
     edge = np.array([hm.hm_guide_edge(int(s)) for s in range(n)])
-    assert np.all(np.diff(edge) >= 0) and edge[0] == 0.0
-    assert np.all(edge[slot] <= u)
-    hm.hm_guide_locate.argtypes = [C.c_double, C.POINTER(C.c_double)]
-    fr = C.c_double()
-    loc = np.array([(hm.hm_guide_locate(float(x), C.byref(fr)), fr.value) for x in u])
-    assert np.array_equal(loc[:, 0], slot) and loc[:, 1].min() >= 0.0 and loc[:, 1].max() <= 1.0
-    same = np.diff(slot) == 0
-    assert np.all(np.diff(loc[:, 1])[same] >= 0)  # position inside a slot grows with u
-    # out-of-range / NaN draws (caller-supplied uniforms) still index inside the table
-    for bad in (-1.0, 1.0, 7.0, float("nan")):
-        assert 0 <= hm.hm_guide_slot(bad) < n
-    # walk length from the guide entry: number of k with edge <= cdf(k) < u
+    assert idx[0] == 257 and idx[-1] == 769 and idx.min() == 1 and 0 <= frac.min() and frac.max() < 1.0
+    assert not np.any((idx == 0) | ((idx >= 255) & (idx <= 256)) | (idx == 513) | (idx == 770))  # closing entries only
+    assert np.all(edge[idx] <= u) and np.all(u < edge[idx + 1])
+    for lo, hi in ((0, 256), (257, 513), (514, 770)):  # every level: edges and indices in order
+        assert np.all(np.diff(edge[lo:hi + 1]) > 0)
+        lvl = (idx >= lo) & (idx < hi)
+        assert np.all(np.diff(idx[lvl]) >= 0)
+    same = np.diff(idx) == 0
+    assert np.all(np.diff(frac)[same] >= 0)  # position inside a slot grows with the word
+    assert edge[256] == 1.0 and edge[513] == edge[1] and edge[770] == 1.0 and edge[514] == edge[255]
+    # the word of a caller-supplied double: floor(u 2^32), out-of-range / NaN inside the table
+    assert [hm.hm_guide_word(x) for x in (0.0, 0.5, 1.0 - 2.0 ** -53, -1.0, 7.0, float("nan"), 2.0 ** -33)] == \
+        [0, 2 ** 31, 2 ** 32 - 1, 0, 2 ** 32 - 1, 0, 0]
+    uu = rs.random_sample(2000)
+    ww = np.array([hm.hm_guide_word(float(x)) for x in uu], np.float64)
+    assert np.all(ww / 2.0 ** 32 <= uu) and np.all(uu < (ww + 1) / 2.0 ** 32)
+    # probes of the walk from the interpolated start (nb_draw_z2): up while cdf < u, down while the
+    # entry below still qualifies
     lat = golden("nb_lattice.npz")
     ks = np.arange(256, dtype=np.float64)
-    worst = 0
+    worst, mean = 0, 0.0
     for ex in (0.0, 1.0, 5.0, 19.0, 60.0):
         cdf = orc.nb_values("cdf", lat["mu_A"], lat["r_A"], np.full(256, ex), ks)
-        start = np.searchsorted(cdf, edge[slot], side="left")
-        stop = np.searchsorted(cdf, u, side="left")
-        inside = stop < 256
-        worst = max(worst, int((stop - start)[inside & (u < 1 - 2.0 ** -20) & (u > 2.0 ** -20)].max()))
-    assert worst <= 4
+        g = np.minimum(np.searchsorted(cdf, edge, side="left"), 255)
+        a, b = g[idx], g[idx + 1]
+        k0 = a + np.where(b - a > 64, 0, (frac.astype(np.float32) * (b - a).astype(np.float32)).astype(int))
+        stop = np.minimum(np.searchsorted(cdf, u, side="left"), 255)
+        steps = np.where(stop > k0, stop - k0, np.where(k0 > a, k0 - stop + 1, 0))
+        assert np.all((a <= stop) & (stop <= b))  # the bracket holds the answer
+        inner = (u < 1 - 2.0 ** -16) & (u > 2.0 ** -16)
+        worst = max(worst, int(steps[inner].max()))
+        mean = max(mean, float(steps.mean()))  # (two thirds of the words are uniform, the rest from the tails)
+    assert worst <= 8 and mean < 0.5, (worst, mean)
