@@ -895,6 +895,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         if (lmax > kLdsMax) return launch_long(nullptr, 0);
         fl.n2_max = pow2(lmax);
         fl.nt = cls_nt[cls_of(lmax)];
+        fl.max_len = lmax;
         HIP_TRY(fptk::launch_fdr(c->stream, fl));
         return launch_ok("k_fdr_null");
     }
@@ -920,6 +921,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         if (cls_list[k].empty()) continue;
         fl.n2_max = cls_n2[k];
         fl.nt = cls_nt[k];
+        fl.max_len = cls_len[k];
         fl.iv_list = d_cls[k];
         fl.n_list = (int64_t)cls_list[k].size();
         HIP_TRY(fptk::launch_fdr(c->stream, fl));

@@ -1344,30 +1344,39 @@ __device__ __forceinline__ int table_row_of(double ex, int memo_exp) {
     return (ex >= 0.0 && ex < (double)memo_exp && (double)ei == ex) ? ei : -1;
 }
 
+// (the tables are addressed base + 32-bit byte offset: one vector register and no 64-bit address
+// arithmetic per probe; a model's table is at most 4096 x 4096 x 16 bytes)
+__device__ __forceinline__ double2 table_entry(const double2 *base, uint32_t byte_off) {
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ uint32_t guide_pair(const uint16_t *base, uint32_t byte_off) {  // entries idx, idx + 1
+    const char *p = reinterpret_cast<const char *>(base) + byte_off;
+    return (uint32_t)*reinterpret_cast<const uint16_t *>(p) | ((uint32_t)*reinterpret_cast<const uint16_t *>(p + 2) << 16);
+}
 __device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_obs,
                                            const double *par, int ei, const double *exp_ptr, uint32_t w0, uint32_t w1,
                                            double u0, double u1, double &z0, double &z1) {
     int lo0 = -1, lo1 = -1;
     bool d0 = true, d1 = true;  // still to be evaluated directly
     if (ei >= 0) {
-        const double2 *row = memo + (size_t)ei * memo_obs;
-        const uint16_t *gr = guide + (size_t)ei * kGuide;
+        const uint32_t row = (uint32_t)ei * (uint32_t)memo_obs * 16u, gr = (uint32_t)ei * (uint32_t)(kGuide * 2);
         const int kl = memo_obs - 1;
         float f0, f1;
         const int s0 = fptm::guide_index(w0, f0), s1 = fptm::guide_index(w1, f1);
-        const int a0 = gr[s0], b0 = gr[s0 + 1], a1 = gr[s1], b1 = gr[s1 + 1];  // answer in [a, b]
+        const uint32_t g0 = guide_pair(guide, gr + 2u * (uint32_t)s0), g1 = guide_pair(guide, gr + 2u * (uint32_t)s1);
+        const int a0 = (int)(g0 & 0xffffu), b0 = (int)(g0 >> 16), a1 = (int)(g1 & 0xffffu), b1 = (int)(g1 >> 16);  // answer in [a, b]
         // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
         // outermost slot, open towards the end of the table: start at its near end)
         int k0 = a0 + (b0 - a0 > 64 ? 0 : (int)(f0 * (float)(b0 - a0)));
         int k1 = a1 + (b1 - a1 > 64 ? 0 : (int)(f1 * (float)(b1 - a1)));
-        double2 e0 = row[k0], e1 = row[k1];
+        double2 e0 = table_entry(memo, row + 16u * (uint32_t)k0), e1 = table_entry(memo, row + 16u * (uint32_t)k1);
         // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
         // below has to be looked at unless the guide already says it is < u (k == a).
         const bool up0 = e0.x < u0, up1 = e1.x < u1;
         bool m0 = up0 ? k0 < kl : k0 > a0, m1 = up1 ? k1 < kl : k1 > a1;
         while (m0 || m1) {
             const int n0 = k0 + (m0 ? (up0 ? 1 : -1) : 0), n1 = k1 + (m1 ? (up1 ? 1 : -1) : 0);
-            const double2 c0 = row[n0], c1 = row[n1];
+            const double2 c0 = table_entry(memo, row + 16u * (uint32_t)n0), c1 = table_entry(memo, row + 16u * (uint32_t)n1);
             if (m0) {
                 if (up0) {  // stop at the first entry >= u
                     k0 = n0;
@@ -1467,7 +1476,19 @@ __device__ __forceinline__ double ndtr_threshold(double P) {
 // end of P's plateau is a gallop and a bisection away from it -- about five evaluations of ndtr
 // where the search from ndtri(P) needs ten and the ndtri.
 __device__ __forceinline__ double ndtr_threshold_from(double y, double P) {
+    // The plateau is about ulp(P) / (phi(y) ulp(y)) values of y wide -- 1 for y < 0, tens in the upper
+    // tail, 2^40 next to 0, where y has small ulps and P = 0.5 + ... large ones -- and its upper end
+    // is up to that far from y: the gallop starts at a quarter of the estimate, not at 1 (measured
+    // on sorted standard-normal y, tools/micro/thr_evals.hip: the wavefront that holds y = 0 made
+    // 14.6 evaluations on average, the others 5-8).
     long long lo = ordered_bits(y), hi, step = 1;  // ndtr(lo) <= P
+    {
+        const double up = __longlong_as_double(__double_as_longlong(P) + 1) - P;  // ulp(P), P in (0, 1)
+        const double ay = fabs(y);
+        const double uy = ay > 0.0 ? __longlong_as_double(__double_as_longlong(ay) + 1) - ay : 4.9406564584124654e-324;
+        const double w = up * 2.5066282746310002 * exp(0.5 * y * y) / uy;  // plateau width in ulps of y
+        if (w >= 8.0) step = 1ll << min(ilogb(w) - 2, 60);
+    }
     for (;;) {
         const long long c = lo + step;
         if (fptm::ndtr(from_ordered_bits(c)) > P) {
@@ -1499,12 +1520,32 @@ __device__ __forceinline__ double sum_threshold(double T, double sqrt_k, double 
     return from_ordered_bits(k);
 }
 
+typedef void (*fdr_kernel_t)(const fdr_args);
+
+#ifdef FPT_ABLATE
+// -DFPT_ABLATE builds: cycles of the first wavefront of every workgroup between the phase marks,
+// summed over workgroups (FPT_FDR_PHASES=1 prints them after each launch)
+__device__ unsigned long long g_fdr_phase[16];
+#define FDR_MARK(n)                                                                  \
+    if (threadIdx.x == 0) {                                                           \
+        const unsigned long long now_ = wall_clock64();                               \
+        atomicAdd(&g_fdr_phase[n], now_ - mark_);                                     \
+        mark_ = now_;                                                                 \
+    }
+#define FDR_MARK_INIT unsigned long long mark_ = wall_clock64();
+#else
+#define FDR_MARK(n)
+#define FDR_MARK_INIT
+#endif
+
 // GWS: the per-interval buffers live in global memory instead of LDS -- the same code for
 // intervals too long for the 160 KB of a CU (one workgroup still owns one interval, and a
 // workgroup's own global writes are visible to it after __syncthreads()).
 // HSC: the half window width at compile time (3, the only one the reference uses: the window sums
 // unroll into 14 LDS reads with immediate offsets), or 0 for any width.
-template <int NT, bool GWS, int HSC>
+// ONE: no interval of the launch is longer than the workgroup -- a lane has one base, and what
+// belongs to the base (table row, Philox counter, addresses) is made once, not in every pass.
+template <int NT, bool GWS, int HSC, bool ONE>
 __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
@@ -1541,6 +1582,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * kGuide;
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
+    FDR_MARK_INIT
     // ---- 0. with the observed counts at hand, the observed window p-values are re-made here by the
     // very operations the null windows go through below -- z of the (exp, obs) pair from the same
     // table, summed left to right, and the SAME normal cdf that the thresholds are searched with --
@@ -1568,11 +1610,13 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         }
         __syncthreads();
     }
+    FDR_MARK(0)  // step 0: z of the observed counts
     // ---- 1. sort the observed window p-values (NaN compares as +inf and ends up last); on the way
     // in, count the values that are not NaN (m) and those below 1 (the rank of the edge positions'
     // constant 1.0 among the thresholds)
     int n_num = 0, n_below_one = 0;
-    for (int i = tid; i < np2; i += NT) {
+    double v_one = fptm::kInf;  // ONE: this lane's key
+    for (int i = tid; i < (ONE ? L : np2); i += NT) {
         double v = fptm::kInf;
         int id = -1;
         if (i < L) {
@@ -1603,17 +1647,48 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 }  // else: the tracks disagree (a p-value where the counts give none): not a number
             }
         }
-        skey[i] = v;
-        sidx[i] = id;
+        if (ONE) {
+            v_one = v;
+            zb[n2 + i] = v;  // (beside the z of step 0, which other lanes may still be reading)
+        } else {
+            skey[i] = v;
+            sidx[i] = id;
+        }
     }
     for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
     if (tid < 4) misc[tid] = 0;
     __syncthreads();
+    FDR_MARK(1)  // keys
     if (n_num) atomicAdd(&misc[1], n_num);
     if (n_below_one) atomicAdd(&misc[2], n_below_one);
+    if (ONE) {
+        // One key per lane: its place in the order is the number of keys that come before it -- a
+        // walk over the interval's keys (LDS broadcast reads), a compare and an add each: 4 L
+        // instructions per wavefront where the bitonic network below issues ~2,000 for 256 slots and
+        // meets at 36 barriers.  Keys of earlier wavefronts come before an equal key of this one,
+        // keys of later ones after; inside the wavefront's own 64 the position decides.
+        const double *key = zb + n2;
+        const int w0 = __builtin_amdgcn_readfirstlane(tid) & ~(kWave - 1);
+        const int e0 = w0 < L ? w0 : L, e1 = w0 + kWave < L ? w0 + kWave : L;
+        int rank = 0;
+        // (unrolled: the reads of eight keys go out together, a read per compare is a latency chain)
+#pragma unroll 8
+        for (int j = 0; j < e0; ++j) rank += key[j] <= v_one ? 1 : 0;
+#pragma unroll 8
+        for (int j = e0; j < e1; ++j) {
+            const double kj = key[j];
+            rank += (kj < v_one || (kj == v_one && j < tid)) ? 1 : 0;
+        }
+#pragma unroll 8
+        for (int j = e1; j < L; ++j) rank += key[j] < v_one ? 1 : 0;
+        if (tid < L) {
+            skey[rank] = v_one;
+            sidx[rank] = tid;
+        }
+    }
     // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
     // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
-    for (int k = 2; k <= (ABL(16384) ? 0 : np2); k <<= 1) {
+    for (int k = 2; k <= ((ONE || ABL(16384)) ? 0 : np2); k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NT) {
                 const int ixj = i ^ j;
@@ -1633,6 +1708,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         }
     }
     __syncthreads();
+    FDR_MARK(2)  // sort
     const int m = misc[1];         // observed values that are not NaN (NaN / pads were mapped to +inf)
     // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
     // (after the sort: neighbouring lanes then search neighbouring values, whose searches are about
@@ -1659,6 +1735,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     // rank guide: x / sqrt(K) of a null window is about standard normal; nb slices of [-kYR, kYR) (the
     // first and last reach to infinity) bracket #{X <= x}, so a rank needs a probe or two, not log2(L)
+    FDR_MARK(3)  // thresholds
     const int rank_one = misc[2];  // thresholds of values below 1
     const double kYR = 4.5 * a.sqrt_k;
     const int nb = np2 < 2048 ? np2 : 2048;
@@ -1679,6 +1756,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     __syncthreads();
 
+    FDR_MARK(4)  // rank guide
     // ---- 2. null tracks, four samples per pass with narrow windows (one Philox block feeds the
     //         four), two with wide ones
     // Narrow windows (the reference only ever uses hw = 3) are summed directly from the raw z in
@@ -1686,10 +1764,15 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     // three prefix scans plus three tile-range sums, and a non-finite z shows up as a non-finite
     // sum, so no separate count is needed.  Wider windows take the prefix-scan path.
     const bool direct = hs <= 8;
-    if (direct) {
+    int ei_one = -1;  // ONE: the table row of this lane's base
+    if (ONE) {
+        if (tid < L) ei_one = table_row_of(a.exp[off + tid], a.memo_exp);
+    } else if (direct) {
         for (int t = tid; t < L; t += NT) nf[t] = table_row_of(a.exp[off + t], a.memo_exp);
         // (each lane reads back only the entries it wrote: no barrier needed)
     }
+    // the loop over a lane's bases: a single trip when ONE
+    constexpr int kStride = ONE ? (1 << 30) : NT;
     // With a second set of z buffers a pass writes one set while slower wavefronts may still be
     // reading the other, so the barrier at the end of a pass is not needed (direct windows only).
     const bool alternate = a.dbuf && direct;
@@ -1699,7 +1782,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     for (int s = 0; s < a.times; s += spp, ++pass) {
         const int ns = a.times - s < spp ? a.times - s : spp;  // samples of this pass
         double *const zq = (alternate && (pass & 1)) ? zset1 : zset0;
-        for (int t = tid; t < Lr; t += NT) {  // wave-uniform bound
+        for (int t = tid; t < Lr; t += kStride) {  // wave-uniform bound
             uint32_t o[4] = {0u, 0u, 0u, 0u};  // the Philox block of this base and pass (words = samples)
             int ei = -1;
             const double *up = a.null_uniform ? a.null_uniform + (size_t)(off + (t < L ? t : 0)) * a.times + s : nullptr;
@@ -1715,7 +1798,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 }
                 // the table row of a position does not change from pass to pass: with direct
                 // windows `nf` is free and holds it (filled above, before the first pass)
-                ei = direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp);
+                ei = ONE ? ei_one : (direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp));
             }
             // one pair of draws at a time (ONE copy of the sampler's code, few live registers): with
             // direct windows the pair's z go straight to their buffers, with wide ones through the scans
@@ -1757,7 +1840,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
             }
         }
         __syncthreads();
-        for (int t = tid; t < L; t += NT) {
+        for (int t = tid; t < L; t += kStride) {
             // x = -(sum of z) of the null windows (y = x / sqrt(K) is what the thresholds were translated
             // from): NaN when a z in the window is not finite, +inf stands for the edges, whose window
             // p-value is the constant 1.0 (windowing.pyx:51) and which are part of the pooled null
@@ -1836,6 +1919,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     }
     __syncthreads();
 
+    FDR_MARK(5)  // the passes
     // ---- 3. counts: inclusive prefix of the histogram (one wavefront, carried over chunks)
     if (tid < kWave) {
         int carry = 0;
@@ -1851,7 +1935,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     const int n_finite = hist[m];
     const int n_nan = misc[0];
     const double denom = (double)L * (double)a.times;
-    for (int i = tid; i < np2; i += NT) {
+    for (int i = tid; i < (ONE ? L : np2); i += NT) {
         const int pos = sidx[i];
         if (pos < 0) continue;
         double f = 1.0;  // NaN observed: the two-pointer walk runs to the end (utils.pyx:76)
@@ -1863,18 +1947,16 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
         }
         a.efdr[off + pos] = f;
     }
+    FDR_MARK(6)  // prefix and output
 }
 
-template __global__ void k_fdr_null<256, false, 3>(const fdr_args);
-template __global__ void k_fdr_null<128, false, 3>(const fdr_args);  // size classes of short intervals: fewer idle lanes
-template __global__ void k_fdr_null<64, false, 3>(const fdr_args);
-template __global__ void k_fdr_null<192, false, 3>(const fdr_args);  // 129..192 bases in one pass, 257..384 in two
-template __global__ void k_fdr_null<256, true, 3>(const fdr_args);
-template __global__ void k_fdr_null<256, false, 0>(const fdr_args);
-template __global__ void k_fdr_null<128, false, 0>(const fdr_args);
-template __global__ void k_fdr_null<64, false, 0>(const fdr_args);
-template __global__ void k_fdr_null<192, false, 0>(const fdr_args);
-template __global__ void k_fdr_null<256, true, 0>(const fdr_args);
+// size classes of short intervals (64, 128, 192 lanes): fewer idle lanes; 192 lanes take 129..192
+// bases in one pass and 257..384 in two
+template <int HSC, bool ONE>
+fdr_kernel_t fdr_kernel(int nt) {
+    return nt == 64 ? k_fdr_null<64, false, HSC, ONE> : nt == 128 ? k_fdr_null<128, false, HSC, ONE>
+           : nt == 192 ? k_fdr_null<192, false, HSC, ONE> : k_fdr_null<256, false, HSC, ONE>;
+}
 
 // ===========================================================================
 // k_detect_columns: the record columns of `ftd detect` for a whole batch (cli/detect.py:136-146):
@@ -2346,23 +2428,24 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             fdr_args b = a;
             if (b.iv_list) b.iv_list += done; else b.iv_first = done;
             const int64_t n = n_blocks - done < per ? n_blocks - done : per;
-            if (fl.hw == 3) hipLaunchKernelGGL((k_fdr_null<256, true, 3>), dim3((unsigned)n), dim3(256), 0, st, b);
-            else hipLaunchKernelGGL((k_fdr_null<256, true, 0>), dim3((unsigned)n), dim3(256), 0, st, b);
+            if (fl.hw == 3) hipLaunchKernelGGL((k_fdr_null<256, true, 3, false>), dim3((unsigned)n), dim3(256), 0, st, b);
+            else hipLaunchKernelGGL((k_fdr_null<256, true, 0, false>), dim3((unsigned)n), dim3(256), 0, st, b);
         }
         return hipSuccess;
     }
     // the second pair of z buffers only where four workgroups still fit a CU's LDS
     a.dbuf = fdr_lds_bytes(fl.n2_max, true) <= 40 * 1024 ? 1 : 0;
+#ifdef FPT_ABLATE
+    if (const char *e = getenv("FPT_FDR_DBUF")) a.dbuf = atoi(e) && a.dbuf;
+#endif
     size_t lds = fdr_lds_bytes(fl.n2_max, a.dbuf != 0);
     // one lane per base and null track: intervals of up to 64 / 128 bases get workgroups of that size
     const int nt = fl.nt ? fl.nt : (fl.n2_max <= 64 ? 64 : (fl.n2_max <= 128 ? 128 : 256));
-    void (*kern)(const fdr_args);
-    if (fl.hw == 3)
-        kern = nt == 64 ? k_fdr_null<64, false, 3> : nt == 128 ? k_fdr_null<128, false, 3>
-               : nt == 192 ? k_fdr_null<192, false, 3> : k_fdr_null<256, false, 3>;
-    else
-        kern = nt == 64 ? k_fdr_null<64, false, 0> : nt == 128 ? k_fdr_null<128, false, 0>
-               : nt == 192 ? k_fdr_null<192, false, 0> : k_fdr_null<256, false, 0>;
+    // (the longest interval of the launch is known to be <= n2_max only; ONE when that says enough
+    // or the caller does: max_len)
+    const bool one = (fl.max_len > 0 ? fl.max_len : fl.n2_max) <= nt;
+    fdr_kernel_t kern = fl.hw == 3 ? (one ? fdr_kernel<3, true>(nt) : fdr_kernel<3, false>(nt))
+                                   : (one ? fdr_kernel<0, true>(nt) : fdr_kernel<0, false>(nt));
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
@@ -2371,6 +2454,17 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         const int64_t n = n_blocks - done < 0x7fffff00 ? n_blocks - done : 0x7fffff00;
         hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(nt), lds, st, b);
     }
+#ifdef FPT_ABLATE
+    if (getenv("FPT_FDR_PHASES")) {
+        unsigned long long h[16], z[16] = {};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fdr_phase), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fdr_phase), z, sizeof z);
+        fprintf(stderr, "fdr phases nt=%d n=%lld (100 MHz ticks per workgroup): obs-z %.1f keys %.1f sort %.1f thresholds %.1f guide %.1f passes %.1f out %.1f\n",
+                nt, (long long)n_blocks, h[0] / (double)n_blocks, h[1] / (double)n_blocks, h[2] / (double)n_blocks,
+                h[3] / (double)n_blocks, h[4] / (double)n_blocks, h[5] / (double)n_blocks, h[6] / (double)n_blocks);
+    }
+#endif
     return hipSuccess;
 }
 

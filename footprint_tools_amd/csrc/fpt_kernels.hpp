@@ -85,6 +85,7 @@ struct fdr_launch {
     int32_t ablate;
     int32_t n2_max;
     int32_t nt;              // lanes per workgroup: 64 / 128 / 192 / 256 (0: chosen from n2_max)
+    int32_t max_len;         // longest interval of the launch if known (0: n2_max is what is known)
     const int32_t *iv_list;  // optional DEVICE list of the intervals to process (n_list of them)
     int64_t n_list;
     void *gws;               // non-null: global-memory buffers, gws_stride bytes per workgroup,
