@@ -1353,70 +1353,96 @@ __device__ __forceinline__ uint32_t guide_pair(const uint16_t *base, uint32_t by
     const char *p = reinterpret_cast<const char *>(base) + byte_off;
     return (uint32_t)*reinterpret_cast<const uint16_t *>(p) | ((uint32_t)*reinterpret_cast<const uint16_t *>(p + 2) << 16);
 }
-__device__ __forceinline__ void nb_draw_z2(const double2 *memo, const uint16_t *guide, int memo_obs,
-                                           const double *par, int ei, const double *exp_ptr, uint32_t w0, uint32_t w1,
-                                           double u0, double u1, double &z0, double &z1) {
-    int lo0 = -1, lo1 = -1;
-    bool d0 = true, d1 = true;  // still to be evaluated directly
+// N draws (2 or 4) at the same expected value, in step: the N guide reads go out together, then the
+// N first probes, then every round of the walk -- a draw is two or three dependent trips to L2, and
+// a pass spends most of its time waiting for them (measured per phase), so the draws of a
+// Philox block share the trips instead of queueing behind each other.
+template <int N>
+__device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *guide, int memo_obs, const double *par,
+                                           int ei, const double *exp_ptr, const uint32_t (&w)[N],
+                                           const double (&u)[N], double (&z)[N]) {
+    bool d[N];  // still to be evaluated directly
+    int lo_tab = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) d[j] = true;
     if (ei >= 0) {
         const uint32_t row = (uint32_t)ei * (uint32_t)memo_obs * 16u, gr = (uint32_t)ei * (uint32_t)(kGuide * 2);
         const int kl = memo_obs - 1;
-        float f0, f1;
-        const int s0 = fptm::guide_index(w0, f0), s1 = fptm::guide_index(w1, f1);
-        const uint32_t g0 = guide_pair(guide, gr + 2u * (uint32_t)s0), g1 = guide_pair(guide, gr + 2u * (uint32_t)s1);
-        const int a0 = (int)(g0 & 0xffffu), b0 = (int)(g0 >> 16), a1 = (int)(g1 & 0xffffu), b1 = (int)(g1 >> 16);  // answer in [a, b]
-        // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
-        // outermost slot, open towards the end of the table: start at its near end)
-        int k0 = a0 + (b0 - a0 > 64 ? 0 : (int)(f0 * (float)(b0 - a0)));
-        int k1 = a1 + (b1 - a1 > 64 ? 0 : (int)(f1 * (float)(b1 - a1)));
-        double2 e0 = table_entry(memo, row + 16u * (uint32_t)k0), e1 = table_entry(memo, row + 16u * (uint32_t)k1);
+        int a[N], k[N];
+        bool up[N], m[N];
+        double2 e[N];
+        uint32_t g[N];
+        float f[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) g[j] = guide_pair(guide, gr + 2u * (uint32_t)fptm::guide_index(w[j], f[j]));
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            a[j] = (int)(g[j] & 0xffffu);  // answer in [a, b]
+            const int width = (int)(g[j] >> 16) - a[j];
+            // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
+            // outermost slot, open towards the end of the table: start at its near end)
+            k[j] = a[j] + (width > 64 ? 0 : (int)(f[j] * (float)width));
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) e[j] = table_entry(memo, row + 16u * (uint32_t)k[j]);
         // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
         // below has to be looked at unless the guide already says it is < u (k == a).
-        const bool up0 = e0.x < u0, up1 = e1.x < u1;
-        bool m0 = up0 ? k0 < kl : k0 > a0, m1 = up1 ? k1 < kl : k1 > a1;
-        while (m0 || m1) {
-            const int n0 = k0 + (m0 ? (up0 ? 1 : -1) : 0), n1 = k1 + (m1 ? (up1 ? 1 : -1) : 0);
-            const double2 c0 = table_entry(memo, row + 16u * (uint32_t)n0), c1 = table_entry(memo, row + 16u * (uint32_t)n1);
-            if (m0) {
-                if (up0) {  // stop at the first entry >= u
-                    k0 = n0;
-                    e0 = c0;
-                    m0 = c0.x < u0 && k0 < kl;
-                } else if (c0.x >= u0) {  // the entry below qualifies too: keep going down
-                    k0 = n0;
-                    e0 = c0;
-                    m0 = k0 > a0;
-                } else {
-                    m0 = false;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            up[j] = e[j].x < u[j];
+            m[j] = up[j] ? k[j] < kl : k[j] > a[j];
+            any |= m[j];
+        }
+        while (any) {
+            double2 c[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                c[j] = table_entry(memo, row + 16u * (uint32_t)(k[j] + (m[j] ? (up[j] ? 1 : -1) : 0)));
+            any = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (m[j]) {
+                    if (up[j]) {  // stop at the first entry >= u
+                        k[j] += 1;
+                        e[j] = c[j];
+                        m[j] = c[j].x < u[j] && k[j] < kl;
+                    } else if (c[j].x >= u[j]) {  // the entry below qualifies too: keep going down
+                        k[j] -= 1;
+                        e[j] = c[j];
+                        m[j] = k[j] > a[j];
+                    } else {
+                        m[j] = false;
+                    }
                 }
-            }
-            if (m1) {
-                if (up1) {
-                    k1 = n1;
-                    e1 = c1;
-                    m1 = c1.x < u1 && k1 < kl;
-                } else if (c1.x >= u1) {
-                    k1 = n1;
-                    e1 = c1;
-                    m1 = k1 > a1;
-                } else {
-                    m1 = false;
-                }
+                any |= m[j];
             }
         }
-        z0 = e0.y;
-        z1 = e1.y;
-        d0 = e0.x < u0;  // ran off the table; false for NaN rows: those return the NaN entry
-        d1 = e1.x < u1;
-        lo0 = lo1 = kl;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            z[j] = e[j].y;
+            d[j] = e[j].x < u[j];  // ran off the table; false for NaN rows: those return the NaN entry
+        }
+        lo_tab = kl;
     }
-    if (d0 || d1) {  // rare: beyond the table or a non-integer expected value
+    bool any_direct = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) any_direct |= d[j];
+    if (any_direct) {  // rare: beyond the table or a non-integer expected value
         const double ex = ei >= 0 ? (double)ei : *exp_ptr;
 #pragma clang loop unroll(disable)
-        for (int j = 0; j < 2; ++j) {
-            if (j ? d1 : d0) {
-                const double z = nb_inverse_cdf_direct(par, ex, j ? u1 : u0, j ? lo1 : lo0).y;
-                if (j) z1 = z; else z0 = z;
+        for (int j = 0; j < N; ++j) {  // (one copy of the evaluation; selects instead of indexed arrays)
+            bool dj = d[0];
+            double uj = u[0];
+#pragma unroll
+            for (int i = 1; i < N; ++i) {
+                dj = j == i ? d[i] : dj;
+                uj = j == i ? u[i] : uj;
+            }
+            if (dj) {
+                const double zz = nb_inverse_cdf_direct(par, ex, uj, lo_tab).y;
+#pragma unroll
+                for (int i = 0; i < N; ++i) z[i] = j == i ? zz : z[i];
             }
         }
     }
@@ -1738,7 +1764,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     FDR_MARK(3)  // thresholds
     const int rank_one = misc[2];  // thresholds of values below 1
     const double kYR = 4.5 * a.sqrt_k;
-    const int nb = np2 < 2048 ? np2 : 2048;
+    const int nb = np2 < 2048 ? np2 : 2048;  // (four times as many slices: no faster, measured)
     const double yscale = (double)nb / (2.0 * kYR);
     for (int b = tid; b <= nb; b += NT) {
         int l = 0;
@@ -1800,46 +1826,57 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 // windows `nf` is free and holds it (filled above, before the first pass)
                 ei = ONE ? ei_one : (direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp));
             }
-            // one pair of draws at a time (ONE copy of the sampler's code, few live registers): with
-            // direct windows the pair's z go straight to their buffers, with wide ones through the scans
-            const int npairs = (direct && ns > 2) ? 2 : 1;
-#pragma clang loop unroll(disable)
-            for (int pr = 0; pr < npairs; ++pr) {
-                // u = (word + 1/2) 2^-32 (philox_uniform4), or the caller's uniforms (tests)
-                uint32_t wa = pr ? o[2] : o[0], wb = pr ? o[3] : o[1];
-                double ua = fma((double)wa, 1.0 / 4294967296.0, 0.5 / 4294967296.0);
-                double ub = fma((double)wb, 1.0 / 4294967296.0, 0.5 / 4294967296.0);
-                if (up && t < L) {
-                    ua = up[2 * pr];
-                    ub = 2 * pr + 1 < ns ? up[2 * pr + 1] : 0.5;
-                    wa = fptm::guide_word(ua);
-                    wb = fptm::guide_word(ub);
+            // u = (word + 1/2) 2^-32 (philox_uniform4), or the caller's uniforms (tests)
+            if (direct) {  // the four draws of the block in step, their z side by side in the buffer
+                const uint32_t w4_[4] = {o[0], o[1], o[2], o[3]};
+                uint32_t w4[4];
+                double u4[4], z4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w4[j] = w4_[j];
+                    u4[j] = fma((double)w4[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
+                    if (up && t < L) {
+                        u4[j] = j < ns ? up[j] : 0.5;
+                        w4[j] = fptm::guide_word(u4[j]);
+                    }
+                    if (ABL(512)) u4[j] = 0.37 + 1e-3 * s + 0.04 * j, w4[j] = fptm::guide_word(u4[j]);
                 }
-                if (ABL(512)) {
-                    ua = 0.37 + 1e-3 * s + 0.04 * pr;
-                    ub = 0.63 - 1e-3 * s - 0.04 * pr;
-                }
-                double za = 0.0, zb_ = 0.0;
                 if (t < L) {
                     if (ABL(1024)) {
-                        za = ua - 0.5;
-                        zb_ = ub - 0.5;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z4[j] = u4[j] - 0.5;
                     } else {
-                        nb_draw_z2(memo, guide, a.memo_obs, par, ei, a.exp + off + t, wa, wb, ua, ub, za, zb_);
+                        nb_draw_zn<4>(memo, guide, a.memo_obs, par, ei, a.exp + off + t, w4, u4, z4);
                     }
+                    *reinterpret_cast<double2 *>(zq + 4 * t) = make_double2(z4[0], z4[1]);
+                    *reinterpret_cast<double2 *>(zq + 4 * t + 2) = make_double2(z4[2], z4[3]);
                 }
-                if (direct) {
-                    if (t < L) *reinterpret_cast<double2 *>(zq + 4 * t + 2 * pr) = make_double2(za, zb_);
-                } else {
-                    const bool f0 = isfinite(za), f1 = isfinite(zb_);
-                    const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
-                    zq[t] = scan_add(f0 ? za : 0.0);
-                    zq[n2 + t] = scan_add(f1 ? zb_ : 0.0);
-                    nf[t] = scan_add(zc);
+            } else {  // wide windows: two draws per pass, through the scans
+                uint32_t w2[2] = {o[0], o[1]};
+                double u2[2], z2[2] = {0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u2[j] = fma((double)w2[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
+                    if (up && t < L) {
+                        u2[j] = j < ns ? up[j] : 0.5;
+                        w2[j] = fptm::guide_word(u2[j]);
+                    }
+                    if (ABL(512)) u2[j] = 0.37 + 1e-3 * s + 0.04 * j, w2[j] = fptm::guide_word(u2[j]);
                 }
+                if (t < L) {
+                    if (ABL(1024)) z2[0] = u2[0] - 0.5, z2[1] = u2[1] - 0.5;
+                    else nb_draw_zn<2>(memo, guide, a.memo_obs, par, ei, a.exp + off + t, w2, u2, z2);
+                }
+                const bool f0 = isfinite(z2[0]), f1 = isfinite(z2[1]);
+                const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
+                zq[t] = scan_add(f0 ? z2[0] : 0.0);
+                zq[n2 + t] = scan_add(f1 ? z2[1] : 0.0);
+                nf[t] = scan_add(zc);
             }
         }
+        FDR_MARK(7)  // a pass: Philox + draws
         __syncthreads();
+        FDR_MARK(8)  // a pass: the barrier
         for (int t = tid; t < L; t += kStride) {
             // x = -(sum of z) of the null windows (y = x / sqrt(K) is what the thresholds were translated
             // from): NaN when a z in the window is not finite, +inf stands for the edges, whose window
@@ -1915,6 +1952,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 if (2 * pr + 1 < ns) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
             }
         }
+        FDR_MARK(9)  // a pass: windows + ranks
         if (!alternate) __syncthreads();
     }
     __syncthreads();
@@ -2462,7 +2500,9 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fdr_phase), z, sizeof z);
         fprintf(stderr, "fdr phases nt=%d n=%lld (100 MHz ticks per workgroup): obs-z %.1f keys %.1f sort %.1f thresholds %.1f guide %.1f passes %.1f out %.1f\n",
                 nt, (long long)n_blocks, h[0] / (double)n_blocks, h[1] / (double)n_blocks, h[2] / (double)n_blocks,
-                h[3] / (double)n_blocks, h[4] / (double)n_blocks, h[5] / (double)n_blocks, h[6] / (double)n_blocks);
+                h[3] / (double)n_blocks, h[4] / (double)n_blocks, (h[5] + h[7] + h[8] + h[9]) / (double)n_blocks, h[6] / (double)n_blocks);
+        fprintf(stderr, "    of the passes: draws %.1f barrier %.1f windows+ranks %.1f\n", h[7] / (double)n_blocks,
+                h[8] / (double)n_blocks, h[9] / (double)n_blocks);
     }
 #endif
     return hipSuccess;
