@@ -1887,7 +1887,10 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 if (t >= hs && t < L - hs) {
                     double sm[4] = {0.0, 0.0, 0.0, 0.0};
                     const double2 *zw = reinterpret_cast<const double2 *>(zq + 4 * (t - hs));
-                    if constexpr (HSC > 0) {
+                    if (ABL(2048)) {  // no window: the position's own four z
+                        const double2 p01 = zw[2 * hs], p23 = zw[2 * hs + 1];
+                        sm[0] = p01.x, sm[1] = p01.y, sm[2] = p23.x, sm[3] = p23.y;
+                    } else if constexpr (HSC > 0) {
 #pragma unroll
                         for (int j = 0; j <= 2 * HSC; ++j) {
                             const double2 p01 = zw[2 * j], p23 = zw[2 * j + 1];
