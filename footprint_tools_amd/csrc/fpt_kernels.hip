@@ -1430,20 +1430,28 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
     for (int j = 0; j < N; ++j) any_direct |= d[j];
     if (any_direct) {  // rare: beyond the table or a non-integer expected value
         const double ex = ei >= 0 ? (double)ei : *exp_ptr;
-#pragma clang loop unroll(disable)
-        for (int j = 0; j < N; ++j) {  // (one copy of the evaluation; selects instead of indexed arrays)
-            bool dj = d[0];
-            double uj = u[0];
+        // one copy of the evaluation (it is ~8,000 instructions): a lane's draws that need it take
+        // turns, picked with selects (an array indexed by the turn would live in scratch memory)
+        for (;;) {
+            int j = -1;
+            double uj = 0.0;
 #pragma unroll
-            for (int i = 1; i < N; ++i) {
-                dj = j == i ? d[i] : dj;
-                uj = j == i ? u[i] : uj;
+            for (int i = N - 1; i >= 0; --i) {
+                j = d[i] ? i : j;
+                uj = d[i] ? u[i] : uj;
             }
-            if (dj) {
+            if (j >= 0) {
                 const double zz = nb_inverse_cdf_direct(par, ex, uj, lo_tab).y;
 #pragma unroll
-                for (int i = 0; i < N; ++i) z[i] = j == i ? zz : z[i];
+                for (int i = 0; i < N; ++i) {
+                    z[i] = j == i ? zz : z[i];
+                    d[i] = j == i ? false : d[i];
+                }
             }
+            bool more = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) more |= d[i];
+            if (!__builtin_amdgcn_ballot_w64(more)) break;
         }
     }
 }
@@ -1835,11 +1843,14 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
                 for (int j = 0; j < 4; ++j) {
                     w4[j] = w4_[j];
                     u4[j] = fma((double)w4[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
-                    if (up && t < L) {
-                        u4[j] = j < ns ? up[j] : 0.5;
+                    if (ABL(512)) u4[j] = 0.37 + 1e-3 * s + 0.04 * j, w4[j] = fptm::guide_word(u4[j]);
+                }
+                if (up) {  // (tests: wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        u4[j] = (t < L && j < ns) ? up[j] : 0.5;
                         w4[j] = fptm::guide_word(u4[j]);
                     }
-                    if (ABL(512)) u4[j] = 0.37 + 1e-3 * s + 0.04 * j, w4[j] = fptm::guide_word(u4[j]);
                 }
                 if (t < L) {
                     if (ABL(1024)) {
