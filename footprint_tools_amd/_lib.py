@@ -228,9 +228,14 @@ class Context(object):
         self._dm_lists = {}
         self._dm_next = 0
         self._lock = threading.RLock()
+        self._dev_pool, self._dev_pool_bytes = {}, 0  # free list of scan.DeviceArray
 
     def close(self):
         if self.h:
+            for ptrs in self._dev_pool.values():
+                for p in ptrs:
+                    self.L.fpt_dev_free(self.h, p)
+            self._dev_pool, self._dev_pool_bytes = {}, 0
             self.L.fpt_ctx_destroy(self.h)
             self.h = None
 

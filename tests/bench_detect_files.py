@@ -56,7 +56,16 @@ for mode in ("device", "per-interval"):
     ff = fa if mode == "device" else type("F", (), {"fetch": lambda self, c, s, e: fa.fetch(c, s, e)})()
     ds = detect.deviation_stats(sub, rf, ff, bm, dm, fdr_shuffle_n=50, seed=1, batch_size=4096)
     ds.compute(range(min(64, len(sub))))  # warm-up
+    prof = None
+    if os.environ.get("PROFILE") and mode == "device":
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     n = sum(sum(s.shape[0] for s in b["stats"]) for b in ds.batch_iter())
     dt = time.perf_counter() - t0
+    if prof:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(22)
     print("%-12s readers: %d intervals, %d bases in %.2f s -> %.3g bases/s" % (mode, len(sub), n, dt, n / dt))
