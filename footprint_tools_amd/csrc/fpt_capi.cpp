@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-constexpr int kSlots = 13;
+constexpr int kSlots = 14;
 constexpr int kModelDoubles = 24;
 
 }  // namespace
@@ -78,6 +78,7 @@ struct fpt_ctx {
     uint64_t m2_epoch[FPT_MAX_DISPERSION_MODELS] = {};
     uint64_t m2_ws_gen = 0;
     bool m2_extended = false;  // the last scan call launched k_nb_memo2: its misses become bounds at the next call
+    bool posterior_direct = false;  // FPT_POSTERIOR_TABLES=0: every log-pmf evaluated in the kernel (tests compare the two)
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
@@ -200,6 +201,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     fpt_ctx *c = new fpt_ctx();
     if (const char *e = getenv("FPT_SCAN_LEAN")) c->use_lean = atoi(e) != 0;
     if (const char *e = getenv("FPT_MEMO2_KEEP")) c->memo2_cold = atoi(e) == 0;
+    if (const char *e = getenv("FPT_POSTERIOR_TABLES")) c->posterior_direct = atoi(e) == 0;
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
@@ -1004,6 +1006,13 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     pl.ll_on_out = d->ll_on_out;
     pl.ll_off_out = d->ll_off_out;
     pl.status_out = d->status_out;
+    // tables of the unoccupied log-pmf and of lgam(k + 1), rebuilt by every call (slot 13)
+    void *d_tab = nullptr;
+    if (!c->posterior_direct) {
+        if (int rc = ws_get(c, 13, fptk::posterior_table_bytes(d->n_datasets), &d_tab)) return rc;
+        pl.off_table = (double *)d_tab;
+        pl.lgam_table = pl.off_table + (size_t)d->n_datasets * 256 * 256;
+    }
     HIP_TRY(fptk::launch_posterior(c->stream, pl));
     return launch_ok("k_posterior");
 }

@@ -110,7 +110,9 @@ struct posterior_launch {
     double *post_out;                   // (total_bases, n_datasets)
     double *prior_out, *delta_out, *ll_on_out, *ll_off_out;
     int32_t *status_out;
+    double *off_table, *lgam_table;     // workspace of posterior_table_bytes(): filled by the launch (or both nullptr)
 };
+size_t posterior_table_bytes(int n_datasets);  // off_table: n_datasets x 256 x 256 doubles, then lgam_table: 4096
 size_t posterior_lds_bytes(int n_datasets, int nt);
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl);
 

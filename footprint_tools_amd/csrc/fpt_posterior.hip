@@ -41,7 +41,45 @@ struct post_args {
     double *post_out;                   // (total_bases, D)
     double *prior_out, *delta_out, *ll_on_out, *ll_off_out;  // optional: (D, total) / (total) / (D, total) x 2
     int32_t *status_out;                // optional, per interval: 1 = a dispersion fit divided by zero
+    // tables made by k_posterior_tables before the launch (or nullptr): the unoccupied log-pmf of every
+    // integer (exp, k) pair below kTabExp x kTabObs per dataset, and lgam(k + 1) for k < kTabLgam
+    const double *off_table;
+    const double *lgam_table;
 };
+
+// The unoccupied likelihood is the NB log-pmf at the expected count itself, an integer (the scan's
+// exp track is a sum of two rounded values), so per dataset it is a function of the integer pair
+// (exp, k): a table entry made by the very expression the kernel evaluates holds the same bits.
+// lgam(k + 1) is a function of k alone.  Three of the five lgam evaluations, a log, a log1p and
+// two piecewise fits per dataset-base become two gathers (L2-resident: 512 KB per dataset).
+// A dispersion fit that divides by zero leaves kTabDirect in its row: the kernel evaluates those
+// itself and reports them.
+constexpr int kTabExp = 256, kTabObs = 256, kTabLgam = 4096;
+constexpr long long kTabDirectBits = 0x7ff8000000abcdefll;  // a NaN no arithmetic produces
+
+__device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, double lg_r, double r, double p, int32_t k) {
+#pragma clang fp contract(off)
+    return ((lg_kr - lg_k1) - lg_r) + r * log(p) + (double)k * fptm::log1p_fn(-p);
+}
+
+__global__ void __launch_bounds__(256) k_posterior_tables(const double *__restrict__ models, int n_datasets,
+                                                          double *__restrict__ off_table, double *__restrict__ lgam_table) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == (unsigned)n_datasets) {  // the extra row of workgroups: lgam(k + 1)
+        if (i < kTabLgam) lgam_table[i] = fptm::lgam((double)(i + 1));
+        return;
+    }
+    if (i >= kTabExp * kTabObs) return;
+    const double *mu9 = models + (size_t)blockIdx.y * 24, *r15 = mu9 + 9;
+    const int32_t k = i % kTabObs;
+    const double x = (double)(i / kTabObs);
+    bool zd = false;
+    const double r = fptm::fit_r(r15, x, &zd);
+    const double mu = fptm::fit_mu(mu9, x);
+    const double p = r / (r + mu);
+    const double v = nb_logpmf_terms(fptm::lgam((double)k + r), fptm::lgam((double)fptm::wrap_inc(k)), fptm::lgam(r), r, p, k);
+    off_table[(size_t)blockIdx.y * kTabExp * kTabObs + i] = zd ? __longlong_as_double(kTabDirectBits) : v;
+}
 
 // np.max(np.vstack([a, b]), axis=0) of two values: NaN wins (posterior.py:72)
 __device__ __forceinline__ double np_max2(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
@@ -128,22 +166,24 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                 const double o = a.obs[j], e = a.exp[j];
                 const double *mu9 = par + d * 24, *r15 = mu9 + 9;
                 const int32_t k = fptm::c_int(o);
-                const double lg_k1 = fptm::lgam((double)fptm::wrap_inc(k));
-                double lg[2][2];
-                double rr[2], pp[2];
+                const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
+                                         ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
+                // the unoccupied form from the table where (exp, k) is an integer pair inside it
+                const int ei = (int)e;
+                bool need_off = true;
+                if (a.off_table && e >= 0.0 && e < (double)kTabExp && (double)ei == e && (uint32_t)k < (uint32_t)kTabObs) {
+                    v_off = a.off_table[((size_t)d * kTabExp + ei) * kTabObs + k];
+                    need_off = __double_as_longlong(v_off) == kTabDirectBits;
+                }
                 FPT_NOUNROLL
                 for (int s = 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
+                    if (s == 1 && !need_off) break;
                     const double x = s == 0 ? e * delta : e;
-                    rr[s] = fptm::fit_r(r15, x, &zero_div);
+                    const double r = fptm::fit_r(r15, x, &zero_div);
                     const double mu = fptm::fit_mu(mu9, x);
-                    pp[s] = rr[s] / (rr[s] + mu);
-                    lg[s][0] = fptm::lgam((double)k + rr[s]);
-                    lg[s][1] = fptm::lgam(rr[s]);
-                }
-                {
-#pragma clang fp contract(off)
-                    v_on = ((lg[0][0] - lg_k1) - lg[0][1]) + rr[0] * log(pp[0]) + (double)k * fptm::log1p_fn(-pp[0]);
-                    v_off = ((lg[1][0] - lg_k1) - lg[1][1]) + rr[1] * log(pp[1]) + (double)k * fptm::log1p_fn(-pp[1]);
+                    const double pq = r / (r + mu);
+                    const double v = nb_logpmf_terms(fptm::lgam((double)k + r), lg_k1, fptm::lgam(r), r, pq, k);
+                    if (s == 0) v_on = v; else v_off = v;
                 }
             }
             lp_on[tid] = v_on;
@@ -179,6 +219,10 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
 
 namespace fptk {
 
+size_t posterior_table_bytes(int n_datasets) {
+    return ((size_t)n_datasets * kTabExp * kTabObs + kTabLgam) * sizeof(double);
+}
+
 size_t posterior_lds_bytes(int n_datasets, int nt) { return (size_t)(n_datasets * 26 + 4 * nt) * sizeof(double); }
 
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
@@ -203,6 +247,11 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     a.ll_on_out = pl.ll_on_out;
     a.ll_off_out = pl.ll_off_out;
     a.status_out = pl.status_out;
+    a.off_table = pl.off_table;
+    a.lgam_table = pl.lgam_table;
+    if (pl.off_table && pl.lgam_table)
+        hipLaunchKernelGGL(k_posterior_tables, dim3(kTabExp * kTabObs / 256, pl.n_datasets + 1), dim3(256), 0, st, pl.models,
+                           pl.n_datasets, pl.off_table, pl.lgam_table);
     // short intervals (the whole-genome hotspot set averages 162 bases) in 128-lane workgroups,
     // anything longer in 256-lane ones; an interval longer than 8 tiles is spread over gridDim.y
     const int nt = pl.max_len + 2 * pl.hw <= 128 ? 128 : 256;

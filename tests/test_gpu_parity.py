@@ -893,6 +893,19 @@ def test_posterior_batch_fuzz(fpt, orc, seed):
         assert rel_err(pc["delta"][a:b], wp["delta"]) < 1e-12, tag
         assert rel_err(pc["ll_on"][:, a:b], wp["ll_on"]) < P_TOL and rel_err(pc["ll_off"][:, a:b], wp["ll_off"]) < P_TOL, tag
         assert np.allclose(stats[a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True), tag
+    # with every log-pmf evaluated in the kernel (no tables of the unoccupied form and of lgam(k + 1)):
+    # the same bits -- the tables are made by the expressions the kernel evaluates
+    os.environ["FPT_POSTERIOR_TABLES"] = "0"
+    try:
+        ctx2 = fpt.Context(0)
+    finally:
+        del os.environ["FPT_POSTERIOR_TABLES"]
+    stats2, pc2 = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
+                                            interval_off=off, pieces=True, ctx=ctx2)
+    ctx2.close()
+    assert np.array_equal(stats, stats2, equal_nan=True), tag
+    assert np.array_equal(pc["ll_on"], pc2["ll_on"], equal_nan=True) and np.array_equal(pc["ll_off"], pc2["ll_off"], equal_nan=True), tag
+
     # without the optional outputs the records are the same bits
     assert np.array_equal(posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
                                                     interval_off=off), stats, equal_nan=True)
