@@ -22,7 +22,7 @@ for f in glob.glob("$OUT/trace/*/*_kernel_stats.csv"):
 per = collections.defaultdict(list)
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "k_posterior" in row["Kernel_Name"]:
+        if "k_posterior<" in row["Kernel_Name"]:
             per[row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("k_posterior, per dispatch (mean):")
 for k in sorted(per):
