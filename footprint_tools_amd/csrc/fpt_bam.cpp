@@ -17,6 +17,14 @@
 // that are there before it is used (tests/test_ingest_cpu.py runs a corpus of truncated and
 // bit-flipped files through an AddressSanitizer build, `make asan`).
 //
+// Region access (what the reference does per interval, samfile.fetch(chrom, start - 10, end + 10),
+// cutcounts.py:191): when a BAI index lies beside the file (SAM specification section 5.2),
+// fpt_bam_seek_region takes the linear index entry of the 16 kb window that holds the start of the
+// region -- the smallest virtual offset of an alignment overlapping that window --, seeks to that
+// block and fpt_bam_read then hands out alignments until one starts at or beyond the end of the
+// region.  (The bins of the index are skipped: for a coordinate-sorted file the linear index alone
+// bounds the scan from below, and the scan ends at the first alignment past the region.)
+//
 // PARITY UNPINNED for this reader: pysam / htslib are not in the image and the reference ships no
 // alignment fixtures, so it is tested on BAM files written by the tests themselves.
 #include <zlib.h>
@@ -42,7 +50,8 @@ namespace {
 using fptz::bgzf_block;
 using fptz::bgzf_member_size;
 using fptz::kMaxBlock;
-constexpr size_t kChunk = (size_t)32 << 20;  // compressed bytes taken from the file at a time
+constexpr size_t kChunk = (size_t)32 << 20;      // compressed bytes taken from the file at a time
+constexpr size_t kSeekChunk = (size_t)1 << 20;  // ... after a seek to a region (doubling up to kChunk)
 
 }  // namespace
 
@@ -57,6 +66,15 @@ struct fpt_bam {
     std::vector<int64_t> ref_lens;
     std::string error;
     int n_threads = 1;
+    size_t chunk = kChunk;
+    // BAI: per reference the linear index (virtual offset of the first alignment overlapping each
+    // 16 kb window; 0 = none recorded), empty when the file has no index
+    bool have_index = false;
+    std::vector<std::vector<uint64_t>> linear;
+    // region mode (after fpt_bam_seek_region): alignments of region_rid that start before region_end
+    bool in_region = false, region_done = false;
+    int32_t region_rid = -1;
+    int64_t region_end = 0;
 
     // inflate the whole members sitting in `in`; returns false on error (message in `error`)
     bool inflate_chunk() {
@@ -130,11 +148,12 @@ struct fpt_bam {
     bool need(size_t n) {
         while (out.size() - out_pos < n) {
             if (!error.empty()) return false;
-            if (!eof && in_len < kChunk) {
-                if (in.size() < kChunk + kMaxBlock) in.resize(kChunk + kMaxBlock);
-                const size_t got = fread(in.data() + in_len, 1, in.size() - in_len, f);
+            if (!eof && in_len < chunk) {
+                if (in.size() < chunk + kMaxBlock) in.resize(chunk + kMaxBlock);
+                const size_t got = fread(in.data() + in_len, 1, chunk + kMaxBlock - in_len, f);
                 in_len += got;
                 if (got == 0) eof = true;
+                if (chunk < kChunk) chunk = std::min(kChunk, chunk * 2);  // (a region read: start small)
             }
             const size_t before = out.size() - out_pos;
             if (!inflate_chunk()) return false;
@@ -145,6 +164,61 @@ struct fpt_bam {
                 }
             }
         }
+        return true;
+    }
+    // the BAI index beside the file, if there is one (<path>.bai, or <path without .bam>.bai);
+    // a damaged index is an error, a missing one is not
+    bool load_index(const std::string &path) {
+        FILE *g = fopen((path + ".bai").c_str(), "rb");
+        if (!g && path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0)
+            g = fopen((path.substr(0, path.size() - 4) + ".bai").c_str(), "rb");
+        if (!g) return true;
+        std::vector<unsigned char> buf;
+        unsigned char tmp[1 << 16];
+        size_t got;
+        while ((got = fread(tmp, 1, sizeof tmp, g)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+        fclose(g);
+        size_t p = 0;
+        auto rd32 = [&](int32_t *v) {
+            if (buf.size() - p < 4) return false;
+            std::memcpy(v, buf.data() + p, 4);
+            p += 4;
+            return true;
+        };
+        int32_t n_ref = 0;
+        if (buf.size() < 8 || std::memcmp(buf.data(), "BAI\1", 4) != 0) {
+            error = "not a BAI index";
+            return false;
+        }
+        p = 4;
+        if (!rd32(&n_ref) || n_ref < 0 || (size_t)n_ref > buf.size()) {
+            error = "damaged BAI index";
+            return false;
+        }
+        linear.assign((size_t)n_ref, std::vector<uint64_t>());
+        for (int32_t r = 0; r < n_ref; ++r) {
+            int32_t n_bin = 0, n_intv = 0;
+            if (!rd32(&n_bin) || n_bin < 0) {
+                error = "damaged BAI index";
+                return false;
+            }
+            for (int32_t b = 0; b < n_bin; ++b) {  // bins: skipped (bin id, chunk count, 16 bytes per chunk)
+                int32_t bin = 0, n_chunk = 0;
+                if (!rd32(&bin) || !rd32(&n_chunk) || n_chunk < 0 || (uint64_t)n_chunk * 16 > buf.size() - p) {
+                    error = "damaged BAI index";
+                    return false;
+                }
+                p += (size_t)n_chunk * 16;
+            }
+            if (!rd32(&n_intv) || n_intv < 0 || (uint64_t)n_intv * 8 > buf.size() - p) {
+                error = "damaged BAI index";
+                return false;
+            }
+            linear[(size_t)r].resize((size_t)n_intv);
+            if (n_intv) std::memcpy(linear[(size_t)r].data(), buf.data() + p, (size_t)n_intv * 8);
+            p += (size_t)n_intv * 8;
+        }
+        have_index = true;
         return true;
     }
     template <typename T>
@@ -190,7 +264,52 @@ int fpt_bam_open(const char *path, fpt_bam **out) {
         b->out_pos += (size_t)l_name;
         b->ref_lens.push_back(b->get<int32_t>());
     }
+    if (!b->load_index(path)) return bad("damaged BAI index");
     *out = b;
+    return FPT_OK;
+}
+
+int fpt_bam_has_index(fpt_bam *b, int32_t *yes_out) {
+    if (!b || !yes_out) return fpt_internal_fail(FPT_ERR_INVALID, "null argument");
+    *yes_out = b->have_index ? 1 : 0;
+    return FPT_OK;
+}
+
+int fpt_bam_seek_region(fpt_bam *b, int32_t ref_id, int64_t beg, int64_t end) {
+    if (!b) return fpt_internal_fail(FPT_ERR_INVALID, "null argument");
+    if (!b->have_index) return fpt_internal_fail(FPT_ERR_INVALID, "the BAM file has no BAI index beside it");
+    if (ref_id < 0 || ref_id >= (int32_t)b->ref_names.size()) return fpt_internal_fail(FPT_ERR_INVALID, "bad reference index");
+    if (beg < 0) beg = 0;
+    b->in_region = true;
+    b->region_done = true;  // until an offset is found
+    b->region_rid = ref_id;
+    b->region_end = end;
+    b->error.clear();
+    if (end <= beg || (size_t)ref_id >= b->linear.size()) return FPT_OK;
+    // first window at or after the region's start with an entry: alignments overlapping the start
+    // window are at or after its entry; an empty window (0) means none overlap it, the next entry
+    // holds the first alignment after it
+    const std::vector<uint64_t> &lin = b->linear[(size_t)ref_id];
+    uint64_t voff = 0;
+    for (size_t w = (size_t)(beg >> 14); w < lin.size(); ++w)
+        if (lin[w] != 0) {
+            voff = lin[w];
+            break;
+        }
+    if (voff == 0) return FPT_OK;  // nothing at or after the region on this reference
+    if (fseeko(b->f, (off_t)(voff >> 16), SEEK_SET) != 0) return fpt_internal_fail(FPT_ERR_INVALID, "seek failed");
+    b->eof = false;
+    b->in_len = 0;
+    b->out.clear();
+    b->out_pos = 0;
+    b->chunk = kSeekChunk;
+    const size_t within = (size_t)(voff & 0xffff);
+    if (!b->need(within + 1)) {  // the block the offset points into
+        if (b->error.empty()) b->error = "BAI index points beyond the end of the file";
+        return fpt_internal_fail(FPT_ERR_INVALID, "%s", b->error.c_str());
+    }
+    b->out_pos = within;
+    b->region_done = false;
     return FPT_OK;
 }
 
@@ -223,6 +342,7 @@ int fpt_bam_read(fpt_bam *b, int64_t max_reads, int32_t *ref_id, int32_t *ref_st
         return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
     int64_t n = 0;
     while (n < max_reads) {
+        if (b->in_region && b->region_done) break;
         if (!b->need(4)) break;  // end of file (or an error, reported below)
         const int32_t block = b->get<int32_t>();
         if (block < 32 || block > (1 << 28) || !b->need((size_t)block)) {
@@ -231,6 +351,11 @@ int fpt_bam_read(fpt_bam *b, int64_t max_reads, int32_t *ref_id, int32_t *ref_st
         }
         const size_t rec = b->out_pos;
         const int32_t rid = b->get<int32_t>(), pos = b->get<int32_t>();
+        if (b->in_region && (rid != b->region_rid || (int64_t)pos >= b->region_end)) {
+            b->region_done = true;  // sorted by coordinate: nothing of the region follows
+            b->out_pos = rec + (size_t)block;
+            break;
+        }
         const uint8_t l_name = b->get<uint8_t>(), mq = b->get<uint8_t>();
         (void)b->get<uint16_t>();  // bin
         const uint16_t n_cig = b->get<uint16_t>(), fl = b->get<uint16_t>();

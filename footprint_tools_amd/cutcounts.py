@@ -68,13 +68,38 @@ def _bind(L):
     L.fpt_bam_n_refs.argtypes = [vp, C.POINTER(i32)]
     L.fpt_bam_ref.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64)]
     L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.fpt_bam_has_index.argtypes = [vp, C.POINTER(i32)]
+    L.fpt_bam_seek_region.argtypes = [vp, i32, i64, i64]
     L.fpt_cut_counts_dev.argtypes = [vp, C.POINTER(CutCountDesc)]
     return L
 
 
-def read_alignments(filepath, batch=1 << 20):
-    """One sequential pass over a BAM file: (references, ref_id, start, end, flag, mapq) with
-    references = [(name, length), ...] and the rest numpy arrays over all alignments.  Needs no GPU."""
+def merge_regions(regions, gap=1 << 16):
+    """(chrom, start, end) triples -> per chromosome, sorted and merged where less than `gap` bases
+    apart (a seek costs more than reading a few blocks on)."""
+    by = {}
+    for c, a, b in regions:
+        by.setdefault(c, []).append((int(a), int(b)))
+    out = []
+    for c in by:
+        cur = None
+        for a, b in sorted(by[c]):
+            if cur and a <= cur[1] + gap:
+                cur[1] = max(cur[1], b)
+            else:
+                if cur:
+                    out.append((c, cur[0], cur[1]))
+                cur = [a, b]
+        out.append((c, cur[0], cur[1]))
+    return out
+
+
+def read_alignments(filepath, batch=1 << 20, regions=None):
+    """(references, ref_id, start, end, flag, mapq) with references = [(name, length), ...] and the rest
+    numpy arrays over the alignments: of the whole file in one sequential pass, or -- `regions`, a list
+    of (chrom, start, end), and a BAI index beside the file -- of those regions only, through the index
+    (what the reference's samfile.fetch does per interval, cutcounts.py:191).  Without an index
+    `regions` is ignored.  Needs no GPU."""
     L = _bind(_lib.load())
     h = C.c_void_p()
     try:
@@ -91,15 +116,35 @@ def read_alignments(filepath, batch=1 << 20):
             _lib.check(L.fpt_bam_ref(h, i, buf, 1024, C.byref(ln)))
             refs.append((buf.value.decode(), ln.value))
         parts = []
-        while True:
-            rid, st, en = (np.empty(batch, np.int32) for _ in range(3))
-            fl, mq = np.empty(batch, np.uint16), np.empty(batch, np.uint8)
-            got = C.c_int64()
-            _lib.check(L.fpt_bam_read(h, batch, rid.ctypes.data, st.ctypes.data, en.ctypes.data, fl.ctypes.data,
-                                      mq.ctypes.data, C.byref(got)))
-            if got.value == 0:
-                break
-            parts.append([a[:got.value] for a in (rid, st, en, fl, mq)])
+
+        def drain(min_start=None):
+            while True:
+                rid, st, en = (np.empty(batch, np.int32) for _ in range(3))
+                fl, mq = np.empty(batch, np.uint16), np.empty(batch, np.uint8)
+                got = C.c_int64()
+                _lib.check(L.fpt_bam_read(h, batch, rid.ctypes.data, st.ctypes.data, en.ctypes.data, fl.ctypes.data,
+                                          mq.ctypes.data, C.byref(got)))
+                if got.value == 0:
+                    break
+                cols = [a[:got.value].copy() if got.value < batch // 4 else a[:got.value] for a in (rid, st, en, fl, mq)]
+                if min_start is not None:  # an alignment that reaches over from the region before: it came with that one
+                    keep = cols[1] >= min_start
+                    if not keep.all():
+                        cols = [a[keep] for a in cols]
+                parts.append(cols)
+
+        indexed = C.c_int32(0)
+        _lib.check(L.fpt_bam_has_index(h, C.byref(indexed)))
+        if regions is not None and indexed.value:
+            names = {name: i for i, (name, _) in enumerate(refs)}
+            prev = {}  # end of the region read before, per chromosome
+            for c, a, b in merge_regions(regions):
+                if c in names:  # (a chromosome the file does not have: no alignments)
+                    _lib.check(L.fpt_bam_seek_region(h, names[c], max(int(a), 0), int(b)))
+                    drain(prev.get(c))
+                    prev[c] = int(b)
+        else:
+            drain()
         cols = [np.concatenate([p[k] for p in parts]) if parts else np.empty(0, dt)
                 for k, dt in enumerate((np.int32, np.int32, np.int32, np.uint16, np.uint8))]
         return (refs,) + tuple(cols)
@@ -111,7 +156,10 @@ class bamfile(object):
     """Class to access a BAM file (and convert tags to cleavage counts); cutcounts.py:40-109."""
 
     def __init__(self, filepath, min_qual=1, remove_dups=False, remove_qcfail=True, offset=(0, -1),
-                 is_cram=False, fasta_reference_filepath=None, ctx=None):
+                 is_cram=False, fasta_reference_filepath=None, ctx=None, regions=None):
+        """`regions` (not in the reference's signature): (chrom, start, end) triples that bound what
+        will be asked of this object -- with a BAI index beside the file only their alignments are
+        read (each widened by 65,536 bases, far beyond any read length plus padding)."""
         if is_cram:
             raise IOError("Cannot open BAM file: %s (CRAM needs htslib, which this build does not have)" % filepath)
         self.filepath = filepath
@@ -120,7 +168,9 @@ class bamfile(object):
         self.remove_dups = remove_dups
         self.remove_qcfail = remove_qcfail
         self._ctx = ctx
-        self.references, rid, st, en, fl, mq = read_alignments(filepath)
+        if regions is not None:
+            regions = [(c, int(a) - 65536, int(b) + 65536) for c, a, b in regions]
+        self.references, rid, st, en, fl, mq = read_alignments(filepath, regions=regions)
         self._ref_index = {name: i for i, (name, _) in enumerate(self.references)}
         key = (rid.astype(np.int64) << 32) | np.clip(st, 0, None).astype(np.int64)
         if key.size and np.any(key[1:] < key[:-1]):  # not coordinate-sorted: sort once

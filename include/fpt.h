@@ -363,6 +363,16 @@ int fpt_bam_ref(fpt_bam *bam, int32_t i, char *name_out, int32_t cap, int64_t *l
 int fpt_bam_read(fpt_bam *bam, int64_t max_reads, int32_t *ref_id, int32_t *ref_start, int32_t *ref_end,
                  uint16_t *flag, uint8_t *mapq, int64_t *n_out);
 
+/* Region access, what the reference does per interval (samfile.fetch(chrom, start - 10, end + 10),
+ * cutcounts.py:191): with a BAI index beside the file (<path>.bai or <path without .bam>.bai; SAM
+ * specification 5.2) fpt_bam_seek_region positions the reader on the first alignment that can
+ * overlap [beg, end) of reference ref_id (linear index), and fpt_bam_read then hands out the
+ * alignments of that reference that start before `end`, returning 0 alignments after the last.
+ * Alignments that end before `beg` may come along (the index works in 16 kb windows).
+ * fpt_bam_seek_region fails with FPT_ERR_INVALID when the file has no index. */
+int fpt_bam_has_index(fpt_bam *bam, int32_t *yes_out);
+int fpt_bam_seek_region(fpt_bam *bam, int32_t ref_id, int64_t beg, int64_t end);
+
 /* Alignments -> cut counts of a batch of intervals, added into the padded CSR count arrays the
  * fused scan reads (zero them first; several calls accumulate, e.g. one per fpt_bam_read batch).
  * All pointers are device pointers.  Intervals are given by ascending start_key =

@@ -139,6 +139,50 @@ def main(tmp):
     case("l_name_past.bam", bam_bytes([record(l_name=255)]), expect_reads=1)
     case("no_cigar.bam", bam_bytes([record(n_cig=0, cig=())]), expect_reads=1)
 
+    # ---- region access through a BAI index: good index, then bit flips and cuts in it
+    L.fpt_bam_seek_region.argtypes = [vp, i32, i64, i64]
+    sreads = sorted(reads, key=lambda r: (r["ref"], r["pos"]))
+    ibam = os.path.join(tmp, "idx.bam")
+    write_bam(ibam, refs, sreads, block_bytes=2500, index=True)
+
+    def region(path, ref_id, a, b):
+        h = vp()
+        rc = L.fpt_bam_open(path.encode(), C.byref(h))
+        if rc:
+            return rc, 0
+        n = 0
+        if L.fpt_bam_seek_region(h, ref_id, a, b) == 0:
+            while True:
+                arr = [np.empty(300, np.int32) for _ in range(3)]
+                fl, mq = np.empty(300, np.uint16), np.empty(300, np.uint8)
+                got = i64()
+                if L.fpt_bam_read(h, 300, arr[0].ctypes.data, arr[1].ctypes.data, arr[2].ctypes.data, fl.ctypes.data,
+                                  mq.ctypes.data, C.byref(got)) or got.value == 0:
+                    break
+                n += got.value
+        L.fpt_bam_close(h)
+        return 0, n
+
+    for ref_id, a, b in ((0, 0, 40000), (1, 16384, 20000), (0, 39000, 90000), (1, 100, 101)):
+        span = {"36M": 36, "20M2D16M": 38, "5S31M": 31}
+        want = sum(1 for r in sreads if r["ref"] == ref_id and r["pos"] < b and r["pos"] + span[r["cigar"]] > a)
+        rc, n = region(ibam, ref_id, a, b)
+        assert rc == 0 and n >= want, (ref_id, a, b, n, want)
+    braw = open(ibam + ".bai", "rb").read()
+    import shutil
+    dbam = os.path.join(tmp, "idx_damaged.bam")
+    shutil.copy(ibam, dbam)
+    for k in range(60):
+        bb = bytearray(braw)
+        bb[int(rs.randint(0, len(braw)))] ^= 1 << int(rs.randint(0, 8))
+        with open(dbam + ".bai", "wb") as f:
+            f.write(bytes(bb))
+        region(dbam, int(rs.randint(0, 2)), int(rs.randint(0, 30000)), int(rs.randint(30000, 60000)))  # error or not
+    for cut in (3, 9, 30, len(braw) // 2, len(braw) - 3):
+        with open(dbam + ".bai", "wb") as f:
+            f.write(braw[:cut])
+        region(dbam, 0, 0, 1000)
+
     # ---- statistics tracks: region access with and without a tabix index, then damaged files
     lines = [b"#header"]
     tpos = np.sort(rs.choice(60000, 9000, replace=False))

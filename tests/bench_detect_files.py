@@ -23,7 +23,7 @@ pos = np.sort(rs.randint(0, glen - 100, n_reads))
 flags = rs.choice([0, 16], n_reads)
 t0 = time.perf_counter()
 write_bam(os.path.join(tmp, "r.bam"), refs, [dict(ref=0, pos=int(p), cigar="36M", flag=int(f), mapq=30) for p, f in zip(pos, flags)],
-          block_bytes=60000)
+          block_bytes=60000, index=True)
 seq = "".join(rs.choice(list("ACGT"), glen))
 with open(os.path.join(tmp, "g.fa"), "w") as f:
     f.write(">chr1\n" + "\n".join(seq[a:a + 60] for a in range(0, glen, 60)) + "\n")
@@ -50,6 +50,12 @@ ivs = [Interval("chr1", int(s), int(s + l)) for s, l in zip(starts, lens)]
 t0 = time.perf_counter()
 bf, fa = cutcounts.bamfile(os.path.join(tmp, "r.bam")), FastaFile(os.path.join(tmp, "g.fa"))
 print("BAM read: %.2f s" % (time.perf_counter() - t0))
+# the alignments of a tenth of the intervals only, through the BAI index
+t0 = time.perf_counter()
+sub10 = ivs[:len(ivs) // 10]
+bf10 = cutcounts.bamfile(os.path.join(tmp, "r.bam"), regions=[(iv.chrom, iv.start, iv.end) for iv in sub10])
+print("BAM read through the index, regions of %d intervals: %.2f s (%d of %d alignments)"
+      % (len(sub10), time.perf_counter() - t0, bf10.n_reads, bf.n_reads))
 for mode in ("device", "per-interval"):
     sub = ivs if mode == "device" else ivs[:1000]
     rf = bf if mode == "device" else type("R", (), {"__getitem__": lambda self, iv: bf[iv]})()

@@ -60,6 +60,78 @@ def test_bam_reader_roundtrip(tmp_path):
         read_alignments(str(tmp_path / "missing.bam"))
 
 
+def test_bam_region_access_through_the_index(tmp_path):
+    """With a BAI index beside the file, `regions` reads what samfile.fetch(chrom, start, end) iterates
+    (cutcounts.py:191) -- every alignment overlapping a region, none twice -- and not the rest of the
+    file; without an index the whole file is read; a damaged index is an error."""
+    import ctypes as C
+    from footprint_tools_amd import _lib
+    from footprint_tools_amd.cutcounts import _bind, merge_regions, read_alignments
+    rs = np.random.RandomState(5)
+    refs = [("chr1", 400000), ("chr2", 300000), ("chrEmpty", 1000)]
+    reads = []
+    for k in range(30000):
+        ref = int(rs.choice([0, 1], p=[0.6, 0.4]))
+        cig = str(rs.choice(["36M", "20M2D16M", "10M30000N26M", "5S31M"], p=[0.7, 0.1, 0.02, 0.18]))
+        reads.append(dict(ref=ref, pos=int(rs.randint(0, refs[ref][1] - 40000)), cigar=cig,
+                          flag=int(rs.choice([0, 16])), mapq=30))
+    reads.sort(key=lambda r: (r["ref"], r["pos"]))
+    path = str(tmp_path / "r.bam")
+    write_bam(path, refs, reads, block_bytes=4000, index=True)
+    st_all = np.array([r["pos"] for r in reads])
+    en_all = np.array([r["pos"] + _ref_span(r["cigar"]) for r in reads])
+    ref_all = np.array([r["ref"] for r in reads])
+    regions = [("chr1", 1000, 3000), ("chr1", 20000, 20500), ("chr1", 150000, 260000), ("chr1", 262000, 262100),
+               ("chr2", 16384, 32768), ("chr2", 290000, 299999), ("chrEmpty", 0, 1000), ("chrNone", 5, 10)]
+    got_refs, rid, st, en, fl, mq = read_alignments(path, regions=regions, batch=513)
+    assert got_refs == refs
+    merged = merge_regions(regions)
+    assert ("chr1", 150000, 262100) in merged  # closer than the merge gap
+    want = np.zeros(len(reads), bool)
+    for c, a, b in merged:
+        if c in ("chr1", "chr2"):
+            want |= (ref_all == (0 if c == "chr1" else 1)) & (st_all < b) & (en_all > a)
+    key_got = sorted(zip(rid.tolist(), st.tolist(), en.tolist()))
+    key_all = sorted(zip(ref_all[want].tolist(), st_all[want].tolist(), en_all[want].tolist()))
+    # everything that overlaps a region is there, once ...
+    import collections
+    cg, cw = collections.Counter(key_got), collections.Counter(key_all)
+    assert all(cg[k] >= v for k, v in cw.items())
+    full = collections.Counter(zip(ref_all.tolist(), st_all.tolist(), en_all.tolist()))
+    assert all(v <= full[k] for k, v in cg.items())  # ... nothing more often than the file has it
+    # ... and what comes along besides (alignments of the start window that end before the region) is little
+    assert len(key_got) < 0.8 * len(reads) and len(key_got) - len(key_all) < 0.1 * len(reads)
+    # seek_region / read at the C ABI: a region beyond the last alignment, and an empty one
+    L = _bind(_lib.load())
+    h = C.c_void_p()
+    _lib.check(L.fpt_bam_open(path.encode(), C.byref(h)))
+    yes = C.c_int32()
+    _lib.check(L.fpt_bam_has_index(h, C.byref(yes)))
+    assert yes.value == 1
+    bufs = [np.empty(100, dt) for dt in (np.int32, np.int32, np.int32, np.uint16, np.uint8)]
+    got = C.c_int64()
+    for ref_id, a, b in ((0, 399000, 400000), (2, 0, 1000), (1, 500, 500)):
+        _lib.check(L.fpt_bam_seek_region(h, ref_id, a, b))
+        _lib.check(L.fpt_bam_read(h, 100, *[x.ctypes.data for x in bufs], C.byref(got)))
+        assert got.value == 0
+    assert L.fpt_bam_seek_region(h, 7, 0, 10) != 0
+    L.fpt_bam_close(h)
+    # no index: regions are ignored, the whole file comes back
+    plain = str(tmp_path / "plain.bam")
+    write_bam(plain, refs, reads[:2000], block_bytes=4000)
+    assert read_alignments(plain, regions=[("chr1", 0, 10)])[1].size == 2000
+    h = C.c_void_p()
+    _lib.check(L.fpt_bam_open(plain.encode(), C.byref(h)))
+    assert L.fpt_bam_seek_region(h, 0, 0, 10) != 0 and b"index" in L.fpt_last_error()
+    L.fpt_bam_close(h)
+    # a damaged index
+    bai = open(path + ".bai", "rb").read()
+    for damaged in (bai[:len(bai) // 2], b"BAX\1" + bai[4:], bai[:8] + b"\xff\xff\xff\x7f" + bai[12:]):
+        open(plain + ".bai", "wb").write(damaged)
+        with pytest.raises(IOError):
+            read_alignments(plain)
+
+
 class _Iv(object):
     def __init__(self, c, s, e):
         self.chrom, self.start, self.end = c, s, e
