@@ -51,7 +51,7 @@ using fptz::bgzf_block;
 using fptz::bgzf_member_size;
 using fptz::kMaxBlock;
 constexpr size_t kChunk = (size_t)32 << 20;      // compressed bytes taken from the file at a time
-constexpr size_t kSeekChunk = (size_t)1 << 20;  // ... after a seek to a region (doubling up to kChunk)
+constexpr size_t kSeekChunk = (size_t)128 << 10;  // ... after a seek to a region (doubling up to kChunk): a short region is a block or two
 
 }  // namespace
 
@@ -66,7 +66,7 @@ struct fpt_bam {
     std::vector<int64_t> ref_lens;
     std::string error;
     int n_threads = 1;
-    size_t chunk = kChunk;
+    size_t chunk = kSeekChunk / 4;  // (the header first: a region read must not inflate 32 MB to see it)
     // BAI: per reference the linear index (virtual offset of the first alignment overlapping each
     // 16 kb window; 0 = none recorded), empty when the file has no index
     bool have_index = false;
