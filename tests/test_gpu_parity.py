@@ -687,7 +687,7 @@ def test_heavy_tailed_workload(fpt, orc):
                 d_o3.ptr + 3 * t8, interval_len=L)
     _, redone3, miss3 = ctx.scan_stats()
     got3 = d_o3.download(np.float64, (3 + S) * total).reshape(3 + S, total)
-    if _lean_on():
+    if _lean_on() and os.environ.get("FPT_MEMO2_KEEP", "1") != "0":  # (the diagnostic switch empties it at every call)
         assert redone3 < redone // 4, (redone, redone3)
     for k in range(3):
         assert np.array_equal(got[k], got3[k], equal_nan=True), k
