@@ -250,12 +250,20 @@ int fpt_ctx_destroy(fpt_ctx *c) {
 
 int fpt_ctx_set_stream(fpt_ctx *c, void *hip_stream) {
     if (int rc = check_ctx(c)) return rc;
+    if (c->stream != (hipStream_t)hip_stream) {
+        c->m2_dm_id = -1;  // the kept second-level table was filled in the order of the old stream
+        c->m2_extended = false;
+    }
     c->stream = (hipStream_t)hip_stream;  // NULL = the device's default stream, as handed over
     return FPT_OK;
 }
 
 int fpt_ctx_use_own_stream(fpt_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
+    if (c->stream != c->own_stream) {
+        c->m2_dm_id = -1;
+        c->m2_extended = false;
+    }
     c->stream = c->own_stream;
     return FPT_OK;
 }
