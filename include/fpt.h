@@ -195,7 +195,7 @@ int fpt_set_memo_dims(fpt_ctx *ctx, int memo_exp, int memo_obs);
  * call that first meets a range computes it between its two passes (and sends the tiles that
  * needed it through the general kernel), later calls look it up in the first pass.  It is emptied
  * when a model of the batch changes (fpt_set_dispersion with other values), when the batch uses
- * other model slots, and by this call (measurements of the cold path; FPT_MEMO2_KEEP=0 in the
+ * other model slots, when the context is given another stream, and by this call (measurements of the cold path; FPT_MEMO2_KEEP=0 in the
  * environment of fpt_ctx_create empties it at every call).  No reference counterpart: the reference
  * evaluates scipy's nbinom.cdf per base (modeling/dispersion.pyx:311-314). */
 int fpt_drop_kept_tables(fpt_ctx *ctx);
