@@ -303,7 +303,10 @@ class Context(object):
     def set_stream(self, hip_stream):
         """Run on a caller-owned hipStream_t (integer handle).  0 is the device's default (null)
         stream -- what `torch.cuda.current_stream().cuda_stream` is on the default stream -- and
-        work is then ordered with it; None goes back to the context's own non-blocking stream."""
+        work is then ordered with it; None goes back to the context's own non-blocking stream.
+        (The stream in use is drained first: buffers on scan.DeviceArray's free list are handed out
+        again on the assumption that one stream orders everything.)"""
+        self.synchronize()
         if hip_stream is None:
             check(self.L.fpt_ctx_use_own_stream(self.h))
         else:
