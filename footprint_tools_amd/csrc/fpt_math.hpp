@@ -493,16 +493,15 @@ FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndt
 // instructions).  Here, for t = |a| < 26,
 //     Phi(-t) = exp(-t^2/2) * g(t),   g(t) = Phi(-t) exp(t^2/2)   (half the scaled complementary
 //                                                                   error function, smooth, ~1/t)
-// with g a degree-14 polynomial in 1/(t+5) (shifted to the centre of its range) and exp
-// by the usual reduction to |r| <= ln2/2 and a degree-8 polynomial: ~40 instructions, no
-// division, no branch.  Coefficients: tools/fit_ndtr_fast.py (Chebyshev series of the functions in
+// with g a degree-14 polynomial in 1/(t+5) (shifted to the centre of its range) and exp as
+// 2^n 2^f, 2^f a degree-8 polynomial on |f| <= 1/2: ~39 instructions, no division, no branch.  Coefficients: tools/fit_ndtr_fast.py (Chebyshev series of the functions in
 // 60-digit arithmetic, truncated); measured against 60-digit values: relative error <= 4.5e-12
 // over |a| < 26, against the contract of 1e-6 (degrees 17 / 10 give 2.5e-13 for six more
 // instructions per evaluation; the scan evaluates this five times per base).  |a| >= 26 (where the
 // reference's exp(-a^2) leaves the normal range and its value degrades, ndtr.c:49 / expx2.c),
 // infinities and NaN take ndtr() above, unchanged.
 constexpr double kNdtrFastLimit = 26.0;
-// g as a polynomial in v = 1/(t+5) - kNdtrR0 (highest power first) and exp(r) on |r| <= ln2/2
+// g as a polynomial in v = 1/(t+5) - kNdtrR0 (highest power first) and 2^f on |f| <= 1/2
 #define FPT_NDTR_G_N 14
 #define FPT_NDTR_E_N 8
 #define FPT_NDTR_G_LIST                                                                                    \
@@ -512,12 +511,11 @@ constexpr double kNdtrFastLimit = 26.0;
         7.06038084514002662e+02, 1.18661330011759532e+02, 1.63755034072666597e+01,                         \
         1.88100183566173196e+00, 1.03451588219912849e-01
 #define FPT_NDTR_E_LIST                                                                                    \
-    2.48844616385603601e-05, 1.99158691913895353e-04, 1.38888017451240203e-03, 8.33326609318958168e-03,   \
-        4.16666670405859349e-02, 1.66666668910743637e-01, 4.99999999994385103e-01,                         \
-        9.99999999979780840e-01, 1.00000000000001354e+00
+    1.32596462502704512e-06, 1.53100811431381520e-05, 1.54034337462241957e-04, 1.33334505603844656e-03,   \
+        9.61812919394216745e-03, 5.55041094121545286e-02, 2.40226506956402991e-01,                         \
+        6.93147180545930497e-01, 1.00000000000001354e+00
 constexpr double kNdtrR0 = 0.11612903225806452;          // centre of 1/(t+5) over t in [0, 26]
 constexpr double kNdtrNegHalfLog2e = -0.7213475204444817;  // -0.5 * log2(e)
-constexpr double kNdtrLn2Hi = 0.6931471803691238, kNdtrLn2Lo = 1.9082149292705877e-10;
 FPT_HD double ndtr_fast(double a) {
     const double kG[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST};
     const double kE[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
@@ -531,10 +529,11 @@ FPT_HD double ndtr_fast(double a) {
 #endif
     const double g = horner<FPT_NDTR_G_N>(r - kNdtrR0, kG);
     const double t2 = t * t;
-    const double n = rint(t2 * kNdtrNegHalfLog2e);
-    double rr = fma(n, -kNdtrLn2Hi, -0.5 * t2);  // ln2 in two parts: the first has 32 significant bits
-    rr = fma(n, -kNdtrLn2Lo, rr);
-    const double e = horner<FPT_NDTR_E_N>(rr, kE);
+    // exp(-t^2/2) = 2^q, q = t^2 (-log2(e) / 2) = n + f: f = q - n is exact, and the rounding of q (1e-13
+    // absolute at t = 26) is far below the polynomial's error -- no reduction by ln 2 in two parts
+    const double q = t2 * kNdtrNegHalfLog2e;
+    const double n = rint(q);
+    const double e = horner<FPT_NDTR_E_N>(q - n, kE);
     const double y = ldexp(e * g, (int)n);
     return a > 0.0 ? 1.0 - y : y;
 }

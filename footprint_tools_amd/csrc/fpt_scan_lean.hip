@@ -55,7 +55,7 @@ constexpr u32 kCountMax = 6553;  // 10 of them fit 16 bits
 struct lean_coef {
     double g[FPT_NDTR_G_N + 1];  // FPT_NDTR_G_LIST divided by its first entry (monic form)
     double e[FPT_NDTR_E_N + 1];  // FPT_NDTR_E_LIST times that entry
-    double neg_r0, neg_half_log2e, neg_ln2_hi, neg_ln2_lo;
+    double neg_r0, neg_half_log2e;
     double c99, band, limit;
 };
 
@@ -169,11 +169,9 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
     double r = __builtin_amdgcn_rcp(d);  // 2^-24 (measured 4.6e-8); one Newton step: 2.2e-15
     r = fma(fma(-d, r, 1.0), r, r);
     const double g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient
-    const double t2 = t * t;
-    const double n = rint(mul_vs(t2, c->neg_half_log2e));
-    double rr = fma_svv(c->neg_ln2_hi, n, -0.5 * t2);
-    rr = fma_svv(c->neg_ln2_lo, n, rr);
-    const double e = horner_e_s(rr, c->e);                      // e * that coefficient
+    const double q = mul_vs(t * t, c->neg_half_log2e);           // exp(-t^2/2) = 2^q = 2^n 2^(q - n)
+    const double n = rint(q);
+    const double e = horner_e_s(q - n, c->e);                   // e * that coefficient
     const double y = ldexp(e * g, (int)n);
     return a > 0.0 ? 1.0 - y : y;
 }
@@ -753,8 +751,6 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     for (int i = 0; i <= FPT_NDTR_E_N; ++i) a.c.e[i] = e[i] * g[0];
     a.c.neg_r0 = -fptm::kNdtrR0;
     a.c.neg_half_log2e = fptm::kNdtrNegHalfLog2e;
-    a.c.neg_ln2_hi = -fptm::kNdtrLn2Hi;
-    a.c.neg_ln2_lo = -fptm::kNdtrLn2Lo;
     a.c.c99 = (double)(kW - 2);
     a.c.band = 1e-13;
     a.c.limit = fptm::kNdtrFastLimit;

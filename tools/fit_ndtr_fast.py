@@ -4,7 +4,7 @@
     Phi(-t) = exp(-t^2/2) * g(t),   g(t) = Phi(-t) exp(t^2/2),   t in [0, 26]
 
 g is approximated by a polynomial of degree N in v = 1/(t+K) - r0 (r0 = centre of 1/(t+K) over the
-range), exp(r) by a polynomial of degree NE on |r| <= ln2/2: truncated Chebyshev series of the
+range), exp(-t^2/2) as 2^n 2^f with 2^f a polynomial of degree NE on |f| <= 1/2: truncated Chebyshev series of the
 functions evaluated with mpmath at 60 digits, converted to the monomial basis in exact arithmetic.
 Prints the macro bodies and the measured relative error against 60-digit values.
 
@@ -53,8 +53,10 @@ alpha, beta = 2 / (whi - wlo), -(whi + wlo) / (whi - wlo)  # u = alpha / (t + K)
 mono_u = cheb2mono(cheb_fit(lambda u: g(alpha / (u - beta) - K), N, 64))
 r0 = -beta / alpha
 gv = [float(mono_u[j] * alpha ** j) for j in range(N + 1)]  # polynomial in v = 1/(t+K) - r0
-h = mp.log(2) / 2
-me = cheb2mono(cheb_fit(lambda u: mp.exp(h * u), NE, 40))
+# exp(-t^2/2) = 2^q, q = t^2 * (-log2(e)/2) = n + f with n = rint(q): 2^f on |f| <= 1/2 (f = q - n is exact,
+# and the rounding of q -- 1e-13 absolute at t = 26 -- is far below the fit's error)
+h = mp.mpf(1) / 2
+me = cheb2mono(cheb_fit(lambda u: mp.power(2, h * u), NE, 40))
 ev = [float(me[i] / h ** i) for i in range(NE + 1)]
 
 print("kNdtrR0 = %.17g   (K = %g)" % (float(r0), K))
@@ -68,8 +70,9 @@ v = 1.0 / (ts + K) - float(r0)
 p = np.zeros_like(v)
 for c in gv[::-1]:
     p = p * v + c
-n = np.rint(ts * ts * (-0.5 * 1.4426950408889634))
-rr = (-0.5 * ts * ts + n * -0.6931471803691238) + n * -1.9082149292705877e-10
+qq = (ts * ts) * (-0.5 * 1.4426950408889634)
+n = np.rint(qq)
+rr = qq - n
 q = np.zeros_like(rr)
 for c in ev[::-1]:
     q = q * rr + c
