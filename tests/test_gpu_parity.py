@@ -1903,7 +1903,8 @@ def test_fdr_fuzz(fpt, orc, seed):
     hw = int(rs.choice([0, 1, 3, 3, 10, 40]))
     times = int(rs.choice([1, 2, 3, 8, 13]))
     n_iv = int(rs.randint(1, 7))
-    lens = rs.choice([1, 2, 7, 64, 65, 300, 511, 512, 1000, 4096, 4097, 6000], n_iv)
+    lens = rs.choice([1, 2, 7, 64, 65, 100, 128, 129, 160, 192, 193, 250, 256, 257, 300, 384, 385, 511, 512, 1000, 4096,
+                      4097, 6000], n_iv)  # (every workgroup size, single-round and two-round instances, both buffer kinds)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     scale = float(rs.choice([0.3, 3.0, 12.0, 60.0]))
     exp = np.round(rs.gamma(2.0, scale, off[-1]))
