@@ -1,0 +1,70 @@
+"""Diagnostic (GPU box): one seed of test_fused_scan_fuzz, with where and how much the window
+p-values differ from the oracle.  Usage: python tests/diag_fuzz_seed.py SEED"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.conftest import golden
+from oracle import oracle as orc
+from footprint_tools_amd.scan import FootprintScanner
+
+seed = int(sys.argv[1])
+rs = np.random.RandomState(1000 + seed)
+lat = golden("nb_lattice.npz")
+table = golden("kmer_probs.npz")["table"]
+hw = int(rs.choice([1, 2, 3, 5, 5, 8]))
+shw = int(rs.choice([0, 1, 7, 31, 32, 50, 50, 64, 65, 120]))
+clip = float(rs.choice([0.0, 0.005, 0.01, 0.01, 0.02, 0.05, 0.2]))
+if shw and int((2 * shw + 1) * clip) * 2 >= 2 * shw + 1:
+    clip = 0.01
+n_sc = int(rs.randint(0, 4))
+scales = tuple(int(x) for x in rs.choice([0, 1, 3, 3, 5, 10, 33, 70], n_sc, replace=False))
+dm = str(rs.choice(["A", "B", "C"]))
+mode = str(rs.choice(["direct", "memo", "auto"]))
+pad = hw + shw
+n_iv = int(rs.randint(3, 14))
+lens = rs.choice([1, 2, 5, 17, 63, 64, 65, 200, 500, 700, 1024, 1025, 1500, 2300], n_iv)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+n_c = int(off[-1] + n_iv * (2 * pad + 1))
+kind = str(rs.choice(["dense", "sparse", "runs", "float", "huge", "neg"]))
+print("hw", hw, "shw", shw, "clip", clip, "scales", scales, "dm", dm, "mode", mode, "kind", kind, "lens", lens.tolist())
+if kind == "dense":
+    cp, cm = rs.randint(0, 20, n_c).astype(float), rs.randint(0, 20, n_c).astype(float)
+elif kind == "sparse":
+    cp, cm = rs.poisson(0.05, n_c).astype(float), rs.poisson(0.3, n_c).astype(float)
+elif kind == "runs":
+    cp = np.repeat(rs.randint(0, 4, n_c // 37 + 1), 37)[:n_c].astype(float)
+    cm = np.repeat(rs.randint(0, 2, n_c // 150 + 1), 150)[:n_c].astype(float)
+elif kind == "float":
+    cp, cm = rs.gamma(1.5, 2.0, n_c), rs.gamma(0.5, 3.0, n_c)
+elif kind == "huge":
+    cp, cm = rs.randint(0, 20, n_c).astype(float), rs.randint(0, 5, n_c).astype(float)
+    cp[rs.randint(0, n_c, 5)] = 2.0 ** rs.randint(20, 26, 5)
+else:
+    cp, cm = rs.randint(-2, 6, n_c).astype(float), rs.randint(0, 6, n_c).astype(float)
+sq = rs.choice(np.frombuffer(b"ACGTACGTACGTacgtN", np.uint8), int(off[-1] + n_iv * (2 * pad + 7)))
+
+
+class DM(object):
+    mu_params, r_params = lat["mu_" + dm], lat["r_" + dm]
+
+
+sc = FootprintScanner(table, DM, hw, shw, clip, scales, nb_mode=mode)
+out = sc.scan(cp, cm, sq, interval_off=off)
+for i, L in enumerate(lens):
+    a, b = off[i] + i * (2 * pad + 1), off[i + 1] + (i + 1) * (2 * pad + 1)
+    sa, sb = off[i] + i * (2 * pad + 7), off[i + 1] + (i + 1) * (2 * pad + 7)
+    e, o, p, wp = orc.detect_batch(cp[a:b], cm[a:b], sq[sa:sb], 1, int(L), hw, shw, clip, table, lat["mu_" + dm],
+                                   lat["r_" + dm], np.array(scales, np.int32))
+    sl = slice(off[i], off[i + 1])
+    with np.errstate(all="ignore"):
+        rp = np.abs(out["pval"][sl] - p) / np.abs(p)
+    for s_i, hs in enumerate(scales):
+        with np.errstate(all="ignore"):
+            r = np.abs(out["winp"][s_i, sl] - wp[s_i]) / np.abs(wp[s_i])
+        r[~np.isfinite(r)] = 0
+        j = int(np.argmax(r))
+        if r[j] > 1e-9:
+            lo, hi = max(0, j - hs), min(int(L), j + hs + 1)
+            print("interval %d (L=%d) scale %d: worst rel err %.3g at base %d: device %.17g oracle %.17g; p there: dev %s"
+                  % (i, L, hs, r[j], j, out["winp"][s_i, sl][j], wp[s_i][j], out["pval"][sl][lo:hi]))
+            print("   oracle p:", p[lo:hi], " exp", e[lo:hi], " obs", o[lo:hi], " max rel err of p in the window %.3g" % np.nanmax(rp[lo:hi]))
