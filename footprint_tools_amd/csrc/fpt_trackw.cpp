@@ -1,0 +1,305 @@
+// fpt_trackw.cpp -- writer of bgzip-compressed, tabix-indexed statistics tracks (host only).
+//
+// `ftd detect` writes bedGraph text (cli/utils.py:119-144); the posterior caller reads such tracks
+// back per interval through pysam.TabixFile (cli/post.py:52-87), which needs them bgzip-compressed
+// and indexed -- in the reference's workflow by the external `bgzip` and `tabix -p bed`.  Neither
+// tool is in this image, so the library makes both files itself: the text is cut every kBlock
+// bytes of the uncompressed stream into BGZF members (SAM/BAM specification 4.1; lines may straddle
+// members), a group of members is deflated on a team of threads, and the tabix index (the TBI layout
+// of the tabix manual: binning index + linear index of 16 kb windows, BED preset, itself a BGZF
+// file) is accumulated on the way -- in positions of the uncompressed stream, turned into virtual
+// offsets at the end, when every member's place in the file is known.  Consecutive lines of one bin
+// merge into one chunk, so a per-base track of a whole genome keeps a few chunks per 16 kb.
+//
+// PARITY UNPINNED (no htslib here): tested by reading the files back with this library's own
+// reader, by comparing the index with the one tests/tbiwriter.py makes of the same text, and by
+// decompressing with Python's gzip module.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fpt.h"
+
+int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
+
+namespace {
+
+constexpr size_t kBlock = 0xff00;       // uncompressed bytes per member (what bgzip uses)
+constexpr size_t kGroup = 256;          // members deflated together
+constexpr int kMetaChar = '#';
+
+// one BGZF member holding data[0..n): header with the BC subfield, raw deflate, CRC32, ISIZE
+bool bgzf_member(const unsigned char *data, size_t n, std::vector<unsigned char> &out) {
+    out.resize(18 + compressBound((uLong)n) + 8 + 64);
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = const_cast<unsigned char *>(data);
+    zs.avail_in = (uInt)n;
+    zs.next_out = out.data() + 18;
+    zs.avail_out = (uInt)(out.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    const size_t total = 18 + clen + 8;
+    if (total > 0x10000) return false;  // (cannot happen: 0xff00 bytes grow by at most a few dozen)
+    const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0,
+                                    (unsigned char)((total - 1) & 0xff), (unsigned char)((total - 1) >> 8)};
+    std::memcpy(out.data(), head, 18);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isize = (uint32_t)n;
+    std::memcpy(out.data() + 18 + clen, &crc, 4);
+    std::memcpy(out.data() + 18 + clen + 4, &isize, 4);
+    out.resize(total);
+    return true;
+}
+
+int reg2bin(int64_t beg, int64_t end) {  // the binning scheme of the SAM specification 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+struct chunk {
+    uint64_t u0, u1;  // positions in the uncompressed stream: [start of the first line, end of the last)
+};
+struct ref_index {
+    std::string name;
+    std::map<uint32_t, std::vector<chunk>> bins;
+    std::vector<uint64_t> linear;  // per 16 kb window: start of the first line overlapping it, or ~0
+};
+
+}  // namespace
+
+struct fpt_track_writer {
+    FILE *f = nullptr;
+    std::string path, error;
+    int n_threads = 1;
+    std::vector<unsigned char> pending;  // text not yet cut into members (less than one group)
+    std::string carry;                   // an unfinished line at the end of the last write call
+    uint64_t upos = 0;                   // bytes of the uncompressed stream handed over so far
+    uint64_t cpos = 0;                   // bytes of the compressed file written so far
+    std::vector<uint64_t> member_at;     // compressed offset of every member
+    std::vector<ref_index> refs;
+    int cur_ref = -1;
+    int64_t last_beg = -1;
+
+    bool flush_members(bool all) {
+        // whole members of kBlock bytes (all of `pending` at the end), a group at a time
+        size_t done = 0;
+        while (pending.size() - done >= (all ? 1 : kBlock)) {
+            const size_t avail = pending.size() - done;
+            const size_t n_mem = std::min(kGroup, all ? (avail + kBlock - 1) / kBlock : avail / kBlock);
+            std::vector<std::vector<unsigned char>> outs(n_mem);
+            std::atomic<size_t> next(0);
+            std::atomic<int> bad(0);
+            auto work = [&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= n_mem) return;
+                    const size_t a = done + i * kBlock, len = std::min(kBlock, pending.size() - a);
+                    if (!bgzf_member(pending.data() + a, len, outs[i])) bad.store(1);
+                }
+            };
+            const int nt = (int)std::min<size_t>((size_t)n_threads, n_mem);
+            if (nt <= 1) {
+                work();
+            } else {
+                std::vector<std::thread> team;
+                for (int t = 0; t < nt; ++t) team.emplace_back(work);
+                for (std::thread &t : team) t.join();
+            }
+            if (bad.load()) {
+                error = "deflate failed";
+                return false;
+            }
+            for (size_t i = 0; i < n_mem; ++i) {
+                member_at.push_back(cpos);
+                if (fwrite(outs[i].data(), 1, outs[i].size(), f) != outs[i].size()) {
+                    error = "write failed";
+                    return false;
+                }
+                cpos += outs[i].size();
+            }
+            done += std::min(avail, n_mem * kBlock);
+        }
+        pending.erase(pending.begin(), pending.begin() + (long)done);
+        return true;
+    }
+
+    // one whole line (without its newline) that starts at position `at` of the uncompressed stream
+    bool index_line(const char *s, size_t n, uint64_t at) {
+        if (n == 0 || s[0] == kMetaChar) return true;
+        const char *e = s + n;
+        const char *t1 = (const char *)std::memchr(s, '\t', n);
+        if (!t1) return bad_line();
+        const char *t2 = (const char *)std::memchr(t1 + 1, '\t', (size_t)(e - t1 - 1));
+        if (!t2) return bad_line();
+        const char *t3 = (const char *)std::memchr(t2 + 1, '\t', (size_t)(e - t2 - 1));
+        if (!t3) t3 = e;
+        int64_t beg = 0, end = 0;
+        if (std::from_chars(t1 + 1, t2, beg).ptr != t2 || std::from_chars(t2 + 1, t3, end).ptr != t3 || beg < 0 ||
+            end <= beg || end > ((int64_t)1 << 29))
+            return bad_line();
+        const size_t ln = (size_t)(t1 - s);
+        if (cur_ref < 0 || refs[(size_t)cur_ref].name.size() != ln || std::memcmp(refs[(size_t)cur_ref].name.data(), s, ln)) {
+            for (const ref_index &r : refs)
+                if (r.name.size() == ln && !std::memcmp(r.name.data(), s, ln)) {
+                    error = "the lines of chromosome " + r.name + " are not contiguous";
+                    return false;
+                }
+            refs.emplace_back();
+            refs.back().name.assign(s, ln);
+            cur_ref = (int)refs.size() - 1;
+            last_beg = -1;
+        }
+        if (beg < last_beg) {
+            error = "the lines are not sorted by position";
+            return false;
+        }
+        last_beg = beg;
+        ref_index &r = refs[(size_t)cur_ref];
+        const uint64_t next_line = at + n + 1;
+        std::vector<chunk> &cs = r.bins[(uint32_t)reg2bin(beg, end)];
+        if (!cs.empty() && cs.back().u1 == at) cs.back().u1 = next_line;
+        else cs.push_back(chunk{at, next_line});
+        const size_t w1 = (size_t)((end - 1) >> 14);
+        if (r.linear.size() <= w1) r.linear.resize(w1 + 1, ~(uint64_t)0);
+        for (size_t w = (size_t)(beg >> 14); w <= w1; ++w)
+            if (r.linear[w] == ~(uint64_t)0) r.linear[w] = at;
+        return true;
+    }
+    bool bad_line() {
+        error = "a line is not <chrom> TAB <start> TAB <end> [TAB ...] with 0 <= start < end <= 2^29";
+        return false;
+    }
+
+    // virtual offset of a position of the uncompressed stream (members are kBlock bytes each)
+    uint64_t voff(uint64_t u, uint64_t eof_at) const {
+        const uint64_t k = u / kBlock;
+        if (k >= member_at.size()) return eof_at << 16;  // the end of the data: the end-of-file member
+        return (member_at[(size_t)k] << 16) | (u % kBlock);
+    }
+};
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int fpt_track_writer_open(const char *path, fpt_track_writer **out) {
+    if (!path || !out) return fpt_internal_fail(FPT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fpt_internal_fail(FPT_ERR_INVALID, "cannot create %s", path);
+    fpt_track_writer *w = new fpt_track_writer();
+    w->f = f;
+    w->path = path;
+    unsigned hc = std::thread::hardware_concurrency();
+    w->n_threads = (int)(hc == 0 ? 1 : (hc > 64 ? 64 : hc));
+    if (const char *e = getenv("FPT_TRACK_THREADS")) w->n_threads = atoi(e) > 0 ? atoi(e) : 1;
+    *out = w;
+    return FPT_OK;
+}
+
+int fpt_track_writer_write(fpt_track_writer *w, const char *text, int64_t n_bytes) {
+    if (!w || n_bytes < 0 || (n_bytes > 0 && !text)) return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
+    if (!w->error.empty()) return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+    // index the whole lines (an unfinished last line waits for the next call)
+    const char *p = text, *e = text + n_bytes;
+    uint64_t at = w->upos - w->carry.size();
+    while (p < e) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(e - p));
+        if (!nl) {
+            w->carry.append(p, (size_t)(e - p));
+            break;
+        }
+        bool ok;
+        if (!w->carry.empty()) {
+            w->carry.append(p, (size_t)(nl - p));
+            ok = w->index_line(w->carry.data(), w->carry.size(), at);
+            at += w->carry.size() + 1;
+            w->carry.clear();
+        } else {
+            ok = w->index_line(p, (size_t)(nl - p), at);
+            at += (uint64_t)(nl - p) + 1;
+        }
+        if (!ok) return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+        p = nl + 1;
+    }
+    w->pending.insert(w->pending.end(), (const unsigned char *)text, (const unsigned char *)text + n_bytes);
+    w->upos += (uint64_t)n_bytes;
+    if (w->pending.size() >= kGroup * kBlock && !w->flush_members(false))
+        return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+    return FPT_OK;
+}
+
+int fpt_track_writer_close(fpt_track_writer *w) {
+    if (!w) return FPT_OK;
+    int rc = FPT_OK;
+    std::string msg = w->error;
+    if (msg.empty() && !w->carry.empty()) msg = "the text does not end with a newline";
+    if (msg.empty() && !w->flush_members(true)) msg = w->error;
+    const uint64_t eof_at = w->cpos;
+    std::vector<unsigned char> eof;
+    if (msg.empty() && (!bgzf_member(nullptr, 0, eof) || fwrite(eof.data(), 1, eof.size(), w->f) != eof.size()))
+        msg = "write failed";
+    if (w->f && fclose(w->f) != 0 && msg.empty()) msg = "write failed";
+    if (msg.empty()) {
+        // the tabix index: header, names, then per reference the bins and the linear index
+        std::vector<unsigned char> idx;
+        auto put32 = [&](int32_t v) { idx.insert(idx.end(), (unsigned char *)&v, (unsigned char *)&v + 4); };
+        auto put64 = [&](uint64_t v) { idx.insert(idx.end(), (unsigned char *)&v, (unsigned char *)&v + 8); };
+        idx.insert(idx.end(), {'T', 'B', 'I', 1});
+        std::string names;
+        for (const ref_index &r : w->refs) names += r.name + '\0';
+        put32((int32_t)w->refs.size());
+        put32(0x10000);  // zero-based half-open coordinates (the BED preset)
+        put32(1), put32(2), put32(3), put32(kMetaChar), put32(0), put32((int32_t)names.size());
+        idx.insert(idx.end(), names.begin(), names.end());
+        for (const ref_index &r : w->refs) {
+            put32((int32_t)r.bins.size());
+            for (const auto &b : r.bins) {
+                put32((int32_t)b.first);
+                put32((int32_t)b.second.size());
+                for (const chunk &c : b.second) put64(w->voff(c.u0, eof_at)), put64(w->voff(c.u1, eof_at));
+            }
+            put32((int32_t)r.linear.size());
+            uint64_t prev = 0;  // (htslib: a window without a line takes the offset of the window before)
+            for (uint64_t u : r.linear) {
+                if (u != ~(uint64_t)0) prev = w->voff(u, eof_at);
+                put64(prev);
+            }
+        }
+        FILE *g = fopen((w->path + ".tbi").c_str(), "wb");
+        if (!g) {
+            msg = "cannot create the index";
+        } else {
+            std::vector<unsigned char> mem;
+            bool ok = true;
+            for (size_t a = 0; a < idx.size() && ok; a += kBlock)
+                ok = bgzf_member(idx.data() + a, std::min(kBlock, idx.size() - a), mem) &&
+                     fwrite(mem.data(), 1, mem.size(), g) == mem.size();
+            ok = ok && fwrite(eof.data(), 1, eof.size(), g) == eof.size();
+            if (fclose(g) != 0 || !ok) msg = "writing the index failed";
+        }
+    }
+    if (!msg.empty()) rc = fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), msg.c_str());
+    delete w;
+    return rc;
+}
+
+#pragma GCC visibility pop
+}

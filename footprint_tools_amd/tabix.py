@@ -26,7 +26,56 @@ def _bind(L):
     L.fpt_track_ref.argtypes = [vp, i32, C.c_char_p, i32]
     L.fpt_track_fetch.argtypes = [vp, i64, vp, vp, vp, vp, i32, vp, vp, vp]
     L.fpt_track_fetch_rows.argtypes = [vp, C.c_char_p, i64, i64, i32, vp, i64, vp, vp, C.POINTER(i64)]
+    L.fpt_track_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fpt_track_writer_write.argtypes = [vp, C.c_char_p, i64]
+    L.fpt_track_writer_close.argtypes = [vp]
     return L
+
+
+class TrackWriter(object):
+    """bedGraph text -> `filename` (bgzip-compressed) + `filename`.tbi: what `bgzip` and `tabix -p bed`
+    make of `ftd detect`'s output in the reference's workflow, so that a track written here can be
+    read back by `TabixFile` (and by pysam / tabix).  A file-like object for the writers of
+    detect.py (`write_stats_to_output(..., file=TrackWriter(path))`): `write` takes str or bytes in
+    pieces of any size; lines must be sorted by position within a chromosome, chromosomes
+    contiguous.  `close` finishes both files (and raises on the first error met)."""
+
+    def __init__(self, filename):
+        self.filename = filename
+        self.L = _bind(_lib.load())
+        h = C.c_void_p()
+        try:
+            _lib.check(self.L.fpt_track_writer_open(str(filename).encode(), C.byref(h)))
+        except ValueError as e:
+            raise IOError(str(e))
+        self.h = h
+
+    def write(self, text):
+        if self.h is None:
+            raise ValueError("write to a closed TrackWriter")
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        _lib.check(self.L.fpt_track_writer_write(self.h, data, len(data)))
+        return len(data)
+
+    def flush(self):
+        pass
+
+    def close(self):
+        if getattr(self, "h", None):
+            h, self.h = self.h, None
+            _lib.check(self.L.fpt_track_writer_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class TabixFile(object):
@@ -75,8 +124,8 @@ class TabixFile(object):
             cap = n.value  # rows wider or denser than one per base: again with room
 
     def fetch(self, chrom, start, end, parser=None):
-        """rows as tuples of strings, like pysam's asTuple parser"""
-        pos, vals = self.fetch_columns(chrom, start, end)
+        """rows as tuples of strings, like pysam's asTuple parser: (chrom, start, end, column 3, ...)"""
+        pos, vals = self.fetch_columns(chrom, start, end, cols=np.arange(2, 8))
         for p, row in zip(pos, vals):
             yield (chrom, repr(int(p))) + tuple(repr(int(v)) if k == 0 else repr(float(v)) for k, v in enumerate(row))
 

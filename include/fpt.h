@@ -427,6 +427,19 @@ int fpt_track_fetch(fpt_track *t, int64_t n_intervals, const char *const *chroms
 int fpt_track_fetch_rows(fpt_track *t, const char *chrom, int64_t start, int64_t end, int32_t n_cols,
                          const int32_t *cols, int64_t cap, int64_t *pos_out, double *vals_out, int64_t *n_out);
 
+/* The other direction: bedGraph text (position-sorted lines <chrom> TAB <start> TAB <end> TAB ...,
+ * what fpt_format_stats / write_stats_to_output produce, cli/utils.py:119-144; '#' lines are
+ * header) written as a bgzip-compressed file `path` and its tabix index `path`.tbi (BED preset) --
+ * what the reference's workflow gets from the external `bgzip` and `tabix -p bed` before
+ * cli/post.py reads the track back (cli/post.py:52-55).  Text arrives in pieces of any size (a
+ * line may be split between two calls); members are deflated on a team of threads
+ * (FPT_TRACK_THREADS).  fpt_track_writer_close writes the end-of-file member and the index, frees
+ * the writer and reports the first error (unsorted lines, a malformed line, a failed write). */
+typedef struct fpt_track_writer fpt_track_writer;
+int fpt_track_writer_open(const char *path, fpt_track_writer **out);
+int fpt_track_writer_write(fpt_track_writer *w, const char *text, int64_t n_bytes);
+int fpt_track_writer_close(fpt_track_writer *w);
+
 /* ---- the one collective of the sharded job (BASELINE.json north_star: "a
  * single RCCL all-gather over xGMI at the end to reassemble the per-base statistics track").
  * Intervals shard across GPUs with no communication during the scan (one process and one

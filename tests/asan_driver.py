@@ -226,6 +226,38 @@ def main(tmp):
             f.write(bytes(bb))
         track_rows(dp, "chr1", 0, 60000)
 
+    # ---- the track writer: text in pieces -> bgzip + tabix files, read back through the reader above; bad text
+    L.fpt_track_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fpt_track_writer_write.argtypes = [vp, C.c_char_p, i64]
+    L.fpt_track_writer_close.argtypes = [vp]
+    for threads in ("1", "6"):
+        os.environ["FPT_TRACK_THREADS"] = threads
+        wp = os.path.join(tmp, "written%s.gz" % threads)
+        h = vp()
+        assert L.fpt_track_writer_open(wp.encode(), C.byref(h)) == 0
+        cuts = sorted(set([0, len(ttext)] + rs.randint(0, len(ttext), 25).tolist()))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            assert L.fpt_track_writer_write(h, ttext[a:b], b - a) == 0, L.fpt_last_error()
+        assert L.fpt_track_writer_close(h) == 0, L.fpt_last_error()
+        import gzip
+        assert gzip.open(wp, "rb").read() == ttext
+        for a, b in ((0, 60000), (16384, 40000), (59990, 70000)):
+            assert track_rows(wp, "chr1", a, b) == (0, 0, int(((tpos >= a) & (tpos < b)).sum())), (threads, a, b)
+    big = b"".join(b"chrB\t%d\t%d\t1.0\n" % (k, k + 1) for k in range(0, 3000000, 3))  # several groups of members
+    h = vp()
+    assert L.fpt_track_writer_open(os.path.join(tmp, "big.gz").encode(), C.byref(h)) == 0
+    for a in range(0, len(big), 7000001):
+        assert L.fpt_track_writer_write(h, big[a:a + 7000001], len(big[a:a + 7000001])) == 0
+    assert L.fpt_track_writer_close(h) == 0
+    assert track_rows(os.path.join(tmp, "big.gz"), "chrB", 2999000, 3000000) == (0, 0, 333)
+    for badtext in (b"chr1\t5\t6\nchr1\t1\t2\n", b"chr1\t5\n", b"chr1\t-4\t6\n", b"chr1\t5\t99999999999999999999\n",
+                    b"\t\t\t\n", b"chr1\t5\t6", b"a\t1\t2\nb\t1\t2\na\t5\t6\n"):
+        h = vp()
+        assert L.fpt_track_writer_open(os.path.join(tmp, "badw.gz").encode(), C.byref(h)) == 0
+        rc1 = L.fpt_track_writer_write(h, badtext, len(badtext))
+        rc2 = L.fpt_track_writer_close(h)
+        assert rc1 != 0 or rc2 != 0, badtext
+
     # ---- text formatter: against Python's own formatting, serial and threaded, tight buffers
     for threads, n in (("1", 300), ("5", 40000)):
         os.environ["FPT_TEXT_THREADS"] = threads

@@ -370,3 +370,81 @@ def test_track_reader_damage(tmp_path):
     tb = TabixFile(path)
     with pytest.raises((IOError, ValueError)):
         tb.fetch_columns("chr1", 0, 30000)
+
+
+def test_track_writer_round_trip(tmp_path, monkeypatch):
+    """TrackWriter: bedGraph text in -> bgzip + tabix files out.  The data decompresses to the text
+    (Python's gzip reads BGZF), the index equals the one tests/tbiwriter.py makes of the same text cut
+    at the same member size, the library's reader serves regions through it, and unsorted or malformed
+    lines are errors."""
+    import gzip
+    from footprint_tools_amd.tabix import TabixFile, TrackWriter
+    from .tbiwriter import write_bgzf_with_tbi
+    rs = np.random.RandomState(11)
+    lines = [b"#chrom\tstart\tend\texp\tobs\tlp\tlwp\tfdr"]
+    truth = {}
+    for chrom, n, span in (("chr1", 60000, 400000), ("chr2", 9000, 70000), ("chrX", 3, 100)):
+        pos = np.sort(rs.choice(span, n, replace=False))
+        vals = rs.rand(n, 5) * 9
+        truth[chrom] = (pos, vals)
+        for p_, v in zip(pos, vals):
+            lines.append(("%s\t%d\t%d\t%.4f\t%.4f\t%.4f\t%.4f\t%.4f" % ((chrom, p_, p_ + 1) + tuple(v))).encode())
+    text = b"\n".join(lines) + b"\n"
+    for threads in ("1", "5"):
+        monkeypatch.setenv("FPT_TRACK_THREADS", threads)
+        path = str(tmp_path / ("t%s.bed.gz" % threads))
+        with TrackWriter(path) as w:
+            cuts = sorted(set([0, len(text)] + rs.randint(0, len(text), 40).tolist()))  # pieces that split lines
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                w.write(text[a:b])
+        assert gzip.open(path, "rb").read() == text
+        # the same text through the test helper at the writer's member size: identical index
+        ref = str(tmp_path / "ref.bed.gz")
+        write_bgzf_with_tbi(ref, text, block_bytes=0xff00)
+        got_idx, want_idx = gzip.open(path + ".tbi", "rb").read(), gzip.open(ref + ".tbi", "rb").read()
+        if open(path, "rb").read() == open(ref, "rb").read():  # (same zlib, same members: then the offsets agree too)
+            assert got_idx == want_idx
+        assert got_idx[:4] == b"TBI\x01" and len(got_idx) == len(want_idx)
+        tb = TabixFile(path)
+        assert tb.has_tbi and tb.contigs == ["chr1", "chr2", "chrX"]
+        for chrom, a, b in (("chr1", 0, 400000), ("chr1", 16384, 16484), ("chr1", 123456, 200001), ("chr2", 69000, 70000),
+                            ("chrX", 0, 100), ("chr2", 0, 1)):
+            pos, vals = truth[chrom]
+            sel = (pos >= a) & (pos < b)
+            rows = list(tb.fetch(chrom, a, b))
+            assert len(rows) == int(sel.sum())
+            assert [int(r[1]) for r in rows] == pos[sel].tolist()
+            assert np.allclose([float(r[3]) for r in rows], vals[sel, 0], atol=5e-5)
+        tb.close()
+    # errors: unsorted positions, a chromosome that comes back, a malformed line, no final newline
+    for bad in (b"chr1\t5\t6\t1\nchr1\t2\t3\t1\n", b"chr1\t5\t6\nchr2\t1\t2\nchr1\t9\t10\n", b"chr1\tx\t6\n", b"chr1\t5\n",
+                b"chr1\t5\t6\t1"):
+        w = TrackWriter(str(tmp_path / "bad.gz"))
+        with pytest.raises(ValueError):
+            w.write(bad)
+            w.close()
+    with pytest.raises(IOError):
+        TrackWriter(str(tmp_path / "no_such_dir" / "x.gz"))
+
+
+def test_detect_writer_into_an_indexed_track(tmp_path):
+    """write_stats_to_output (cli/utils.py:119-144) with a TrackWriter for the file: the records of a
+    run of intervals become a bgzip + tabix track that the posterior caller's reader serves back --
+    the reference's detect -> bgzip -> tabix -> post chain without the external tools."""
+    from footprint_tools_amd import detect
+    from footprint_tools_amd.tabix import TabixFile, TrackWriter
+    rs = np.random.RandomState(2)
+    ivs = [_Iv("chr1", 1000, 1800), _Iv("chr1", 5000, 5050), _Iv("chr3", 10, 700)]
+    stats = [np.round(rs.rand(iv.end - iv.start, 5) * 7, 4) for iv in ivs]
+    path = str(tmp_path / "stats.bed.gz")
+    with TrackWriter(path) as w:
+        for iv, st in zip(ivs, stats):
+            detect.write_stats_to_output(iv, st, file=w)
+    tb = TabixFile(path)
+    assert tb.has_tbi and tb.contigs == ["chr1", "chr3"]
+    out, present, off = tb.fetch_batch([iv.chrom for iv in ivs], [iv.start for iv in ivs], [iv.end for iv in ivs], [3, 4, 7])
+    assert present.all()
+    for k, c in enumerate((0, 1, 4)):  # exp, obs, fdr columns of the records
+        assert np.allclose(out[k], np.concatenate([st[:, c] for st in stats]), atol=5e-5)
+    rows = list(tb.fetch("chr1", 1798, 5002))
+    assert [r[1] for r in rows] == ["1798", "1799", "5000", "5001"] and rows[0][2] == "1799" and len(rows[0]) == 8
