@@ -90,6 +90,21 @@ def main():
           % (len(intervals), n_bases, n_calls, hits))
     print("dispersion model JSON: %d bytes; bedGraph: %d lines" % (len(model_json), bedgraph.getvalue().count("\n")))
 
+    # 3. the statistics as a bgzip-compressed, tabix-indexed track (what `bgzip` + `tabix -p bed` make of
+    #    the bedGraph in the reference's workflow), read back by region the way the posterior caller does
+    import os
+    import tempfile
+    from footprint_tools_amd.tabix import TabixFile, TrackWriter
+    path = os.path.join(tempfile.mkdtemp(), "stats.bed.gz")
+    with TrackWriter(path) as w:
+        w.write(bedgraph.getvalue())
+    tb = TabixFile(path)
+    iv = intervals[len(intervals) // 2]
+    rows = list(tb.fetch(iv.chrom, iv.start, iv.end))
+    print("track %s (%d bytes + %d of index): %d rows of %s:%d-%d read back through the index"
+          % (os.path.basename(path), os.path.getsize(path), os.path.getsize(path + ".tbi"), len(rows), iv.chrom,
+             iv.start, iv.end))
+
 
 if __name__ == "__main__":
     main()
