@@ -97,6 +97,8 @@ struct fpt_track_writer {
     std::vector<ref_index> refs;
     int cur_ref = -1;
     int64_t last_beg = -1;
+    int64_t last_bin = -1;                // the bin of the line before and its chunk list (most lines stay in it)
+    std::vector<chunk> *last_chunks = nullptr;
 
     bool flush_members(bool all) {
         // whole members of kBlock bytes (all of `pending` at the end), a group at a time
@@ -166,6 +168,7 @@ struct fpt_track_writer {
             refs.back().name.assign(s, ln);
             cur_ref = (int)refs.size() - 1;
             last_beg = -1;
+            last_bin = -1;
         }
         if (beg < last_beg) {
             error = "the lines are not sorted by position";
@@ -174,7 +177,12 @@ struct fpt_track_writer {
         last_beg = beg;
         ref_index &r = refs[(size_t)cur_ref];
         const uint64_t next_line = at + n + 1;
-        std::vector<chunk> &cs = r.bins[(uint32_t)reg2bin(beg, end)];
+        const int bin = reg2bin(beg, end);
+        if (bin != last_bin) {  // (a map lookup per line is most of what a line costs)
+            last_chunks = &r.bins[(uint32_t)bin];
+            last_bin = bin;
+        }
+        std::vector<chunk> &cs = *last_chunks;
         if (!cs.empty() && cs.back().u1 == at) cs.back().u1 = next_line;
         else cs.push_back(chunk{at, next_line});
         const size_t w1 = (size_t)((end - 1) >> 14);
