@@ -351,3 +351,28 @@ def test_dispersion_model_json_roundtrip(tmp_path):
     assert np.array_equal(back.r_params, dm.r_params) and np.array_equal(back.h, dm.h)
     enc = dispersion.base64encode(np.array([[1.5, 2.5]]))
     assert enc[0] == "float64" and tuple(enc[2]) == (1, 2) and np.array_equal(dispersion.base64decode(enc), [[1.5, 2.5]])
+
+
+def test_interval_file_and_duck_type(tmp_path):
+    """cli/detect.py:50,118: a headerless tab-separated interval file -> genomic_interval objects with
+    the attributes the path uses (chrom, start, end, widen -> copy, len)."""
+    import gzip
+    from footprint_tools_amd.intervals import genomic_interval, read_intervals
+    text = "# a comment\nchr1\t100\t250\nchr1\t900\t1000\tpeak7\t55\t-\n\nchrX\t5\t6\textra\n"
+    p = tmp_path / "iv.bed"
+    p.write_text(text)
+    ivs = read_intervals(str(p))
+    assert [(i.chrom, i.start, i.end, i.strand) for i in ivs] == [("chr1", 100, 250, None), ("chr1", 900, 1000, "-"),
+                                                                 ("chrX", 5, 6, None)]
+    assert len(ivs[0]) == 150 and ivs[1].name == "peak7" and str(ivs[2]) == "chrX\t5\t6"
+    w = ivs[0].widen(56)
+    assert (w.start, w.end) == (44, 306) and (ivs[0].start, ivs[0].end) == (100, 250) and w is not ivs[0]
+    assert genomic_interval("chr1", 100, 250) == ivs[0] and len({ivs[0], genomic_interval("chr1", 100, 250)}) == 1
+    with gzip.open(str(tmp_path / "iv.bed.gz"), "wt") as f:
+        f.write(text)
+    assert read_intervals(str(tmp_path / "iv.bed.gz")) == ivs
+    for bad in ("chr1\t5\n", "chr1\tx\t9\n", "chr1\t9\t5\n"):
+        q = tmp_path / "bad.bed"
+        q.write_text(bad)
+        with pytest.raises(ValueError):
+            read_intervals(str(q))
