@@ -1506,31 +1506,67 @@ __device__ __forceinline__ double ndtr_threshold(double P) {
     return from_ordered_bits(hi);
 }
 
-// The same threshold when a y with ndtr(y) == P is at hand (the observed window's own y): the upper
-// end of P's plateau is a gallop and a bisection away from it -- about five evaluations of ndtr
-// where the search from ndtri(P) needs ten and the ndtri.
+// The same threshold when a y with ndtr(y) == P is at hand (the observed window's own y).  The upper
+// end of P's plateau is where the search has to go, and how far that is depends on y: the plateau is
+// about ulp(P) / (phi(y) ulp(y)) values of y wide -- 1 for y < 0, tens to 10^12 in the upper tail
+// (windows that are not depleted, p next to 1: most windows of most data), 2^40 next to 0.  A gallop
+// from y by powers of two and a bisection are 2 log2(width) evaluations of ndtr
+// (tools/micro/thr_evals.hip: 88 in the wavefront of the largest y when the windows sit at y ~ 6,
+// 47 when the gallop starts from the estimated width).  For y > 0 the search therefore starts where
+// the plateau must end: ndtr(a) = base + t(a) rounded once (base 0.5 or 1: the central and the tail
+// branch of ndtr.c), t resolves a far finer than the sum does, the sum first rounds above P at
+// t* ~ (P - base) + ulp(P)/2, and Newton's iteration on t (central branch: dt/da = phi(a); tail:
+// on ln(-t), whose slope is the hazard sqrt(2/pi) / erfce, nearly constant over a plateau however
+// wide) lands within a few values of the end in two to four steps.  The gallop and the bisection from
+// there -- on ndtr itself, as before -- make it four to six evaluations in every wavefront, whatever
+// the windows look like.  ndtr is not monotone to the last bit, so "the" end of a plateau is one of a
+// few neighbouring values whichever way it is searched: this search and the plain one differ by a
+// value or two of y in 0.3 % of the cases around y = 0 and in none in the tail.
 __device__ __forceinline__ double ndtr_threshold_from(double y, double P) {
-    // The plateau is about ulp(P) / (phi(y) ulp(y)) values of y wide -- 1 for y < 0, tens in the upper
-    // tail, 2^40 next to 0, where y has small ulps and P = 0.5 + ... large ones -- and its upper end
-    // is up to that far from y: the gallop starts at a quarter of the estimate, not at 1 (measured
-    // on sorted standard-normal y, tools/micro/thr_evals.hip: the wavefront that holds y = 0 made
-    // 14.6 evaluations on average, the others 5-8).
     long long lo = ordered_bits(y), hi, step = 1;  // ndtr(lo) <= P
-    {
-        const double up = __longlong_as_double(__double_as_longlong(P) + 1) - P;  // ulp(P), P in (0, 1)
-        const double ay = fabs(y);
-        const double uy = ay > 0.0 ? __longlong_as_double(__double_as_longlong(ay) + 1) - ay : 4.9406564584124654e-324;
-        const double w = up * 2.5066282746310002 * exp(0.5 * y * y) / uy;  // plateau width in ulps of y
-        if (w >= 8.0) step = 1ll << min(ilogb(w) - 2, 60);
-    }
-    for (;;) {
-        const long long c = lo + step;
-        if (fptm::ndtr(from_ordered_bits(c)) > P) {
-            hi = c;
-            break;
+    long long k = lo + 1;
+    if (y > 0.0) {
+        const bool central = fptm::ndtr_is_central(y);
+        const double up = __longlong_as_double(__double_as_longlong(P) + 1) - P;  // ulp(P), P in [0.5, 1)
+        double a = y;
+        for (int it = 0; it < 6; ++it) {
+            if (fptm::ndtr_is_central(a) != central || !(a < 40.0)) break;
+            double base, ec = 1.0;
+            const double t = fptm::ndtr_addend_pos(a, base, &ec);
+            const double ts = (P - base) + 0.5 * up;
+            const double d = central ? (ts - t) / (exp(-0.5 * a * a) * 0.3989422804014327)
+                                     : log(t / ts) * ec * 1.2533141373155003;
+            const double an = a + d;
+            const double ua = __longlong_as_double(__double_as_longlong(a) + 1) - a;
+            if (!(an > y)) break;
+            a = an;
+            if (fabs(d) <= 4.0 * ua) break;
         }
-        lo = c;
-        step <<= 1;
+        if (a > y && a < 40.0) k = ordered_bits(a);
+    }
+    if (k > lo + 1 && fptm::ndtr(from_ordered_bits(k)) > P) {  // at or beyond the end: down to it
+        hi = k;
+        for (;;) {
+            const long long c = hi - step;
+            if (c <= lo) break;  // (lo itself is on the plateau)
+            if (!(fptm::ndtr(from_ordered_bits(c)) > P)) {
+                lo = c;
+                break;
+            }
+            hi = c;
+            step <<= 1;
+        }
+    } else {  // on the plateau: up from here
+        if (k > lo + 1) lo = k;
+        for (;;) {
+            const long long c = lo + step;
+            if (fptm::ndtr(from_ordered_bits(c)) > P) {
+                hi = c;
+                break;
+            }
+            lo = c;
+            step <<= 1;
+        }
     }
     while (hi - lo > 1) {
         const long long mid = lo + ((hi - lo) >> 1);

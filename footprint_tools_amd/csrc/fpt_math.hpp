@@ -464,10 +464,15 @@ FPT_HD double erfc_fn(double a) {
 // the cheap central branch for all of them and the tail branch only where it is needed
 FPT_HD bool ndtr_is_central(double a) { return fabs(a * kSqrtH) < 1.0; }
 FPT_HD double ndtr_central(double a) { return 0.5 + 0.5 * erf_small(a * kSqrtH); }
-FPT_HD double ndtr_tail(double a) {
+// the tail branch before its last step: y = Phi(-|a|); ndtr is y for a < 0 and 1 - y for a > 0.
+// *ec = erfce(|a| / sqrt 2), the scaled complementary error function y is made of: the hazard
+// phi(a) / y = sqrt(2 / pi) / ec follows from it without another exp.
+FPT_HD double ndtr_tail_y(double a, double *ec = nullptr) {
     double x = a * kSqrtH;
     double z = fabs(x);
-    double y = 0.5 * erfce(z);
+    const double ece = erfce(z);
+    if (ec) *ec = ece;
+    double y = 0.5 * ece;
 #if defined(__HIP_DEVICE_COMPILE__)
     // exp(-a^2/2) for the tail.  The reference takes sqrt(expx2(a, -1)) (two exps and a square
     // root); away from the underflow of exp(-a^2) the same value to ~1 ulp is one exp of the
@@ -482,10 +487,24 @@ FPT_HD double ndtr_tail(double a) {
         z = expx2(a, -1);
         y = y * sqrt(z);
     }
-    if (x > 0) y = 1.0 - y;
     return y;
 }
+FPT_HD double ndtr_tail(double a) {
+    const double y = ndtr_tail_y(a);
+    return a * kSqrtH > 0 ? 1.0 - y : y;
+}
 FPT_HD double ndtr(double a) { return ndtr_is_central(a) ? ndtr_central(a) : ndtr_tail(a); }
+// ndtr(a) for a > 0 is base + t rounded once, base = 0.5 (central branch) or 1.0 (tail): t, the
+// addend before that last rounding -- it resolves a far finer than the sum does, which is what the
+// threshold search of the empirical-FDR kernel uses (ndtr_threshold_open)
+FPT_HD double ndtr_addend_pos(double a, double &base, double *ec = nullptr) {
+    if (ndtr_is_central(a)) {
+        base = 0.5;
+        return 0.5 * erf_small(a * kSqrtH);
+    }
+    base = 1.0;
+    return -ndtr_tail_y(a, ec);
+}
 
 // One-formula normal cdf for the Stouffer windows of the fused scan (windowing.h:61-66 ends in
 // hcephes_ndtr).  ndtr.c evaluates erf for |a| < sqrt(2) and exp(-a^2/2) erfce for the rest, and a
