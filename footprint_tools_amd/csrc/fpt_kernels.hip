@@ -1471,12 +1471,17 @@ __device__ __forceinline__ double from_ordered_bits(long long k) {
     const long long b = k < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)k) : k;
     return __longlong_as_double(b);
 }
+__device__ __forceinline__ double ndtr_threshold_from(double y, double P);
 __device__ __forceinline__ double ndtr_threshold(double P) {
     if (!(P < 1.0)) return fptm::kInf;  // ndtr never exceeds 1
     if (P < 0.0) return -fptm::kInf;
     const double y0 = P > 0.0 ? fptm::ndtri(P) : -39.0;
     long long lo, hi, step = 1;  // ndtr(lo) <= P < ndtr(hi)
-    if (fptm::ndtr(y0) > P) {
+    const double p0 = fptm::ndtr(y0);
+    // (in the upper tail a plateau is thousands of values wide and ndtri lands on it: the search that
+    // starts from a point of the plateau knows where it ends)
+    if (p0 == P && y0 > 0.0) return ndtr_threshold_from(y0, P);
+    if (p0 > P) {
         hi = ordered_bits(y0);
         for (;;) {
             const long long c = hi - step;
