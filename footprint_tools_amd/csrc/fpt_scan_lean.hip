@@ -22,8 +22,11 @@
 //   * the trimmed sum of a smoothing window is S - min - max from per-64-position-tile prefix sums
 //     and prefix / suffix extrema; the one case where smoothing.h:61-69 gives something else
 //     (2nd smallest == 2nd largest: at least 99 of 101 values equal and non-zero) needs a run of
-//     33 equal values, hence 16 equal non-zero values in an aligned row of 16 lanes -- two ballots
-//     and a few scalar instructions per tile, and such a tile goes to the general kernel;
+//     33 equal non-zero values -- two ballots and a dozen scalar instructions per tile for the runs
+//     inside a 64-position tile, three words of LDS per tile for those across two -- and such a tile
+//     goes to the general kernel.  (Round 2 took any aligned row of 16 equal non-zero values for
+//     the sign: sparse counts, where a single cut makes ten equal window sums, tripped it in 16-47 %
+//     of the tiles, tests/diag_sparse_redo.py; with 33 it is 0.01-0.5 %);
 //   * expected = round(P/Q * t/99): Q is summed in the reference's order, the two divisions are
 //     replaced by one reciprocal with one Newton step, and a base whose product lies within
 //     1e-13 (relative) of a half-integer -- where the rounding of the exact operations could
@@ -197,7 +200,8 @@ struct lean_lds {
     static constexpr int oXPs = oXP + NCR;         //     same for the suffixes
     static constexpr int oXM = oXPs + NCR;
     static constexpr int oXMs = oXM + NCR;
-    static constexpr int nWords = oXMs + NCR;
+    static constexpr int oEG = oXMs + NCR;         // per 64-position tile: first W, last W, run lengths at both ends
+    static constexpr int nWords = oEG + 3 * (NCR / 64) + 4;
     // the prefix sums of z (phase E, NT + 48 doubles) take the place of the six scan arrays, which
     // nobody reads after phase D: 6 * NCR words >= 2 * (NT + 48)
     static constexpr int oZB = oSP;                // in words; 8-byte aligned: see the static_assert
@@ -336,7 +340,7 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
 template <int NT>
 struct lean_mem {
     double *PP, *PM, *Z, *rowtot, *C;
-    u32 *bits0, *bits1, *pk, *psP, *psM, *xP, *xPs, *xM, *xMs;
+    u32 *bits0, *bits1, *pk, *psP, *psM, *xP, *xPs, *xM, *xMs, *edge;
     __device__ __forceinline__ explicit lean_mem(double *smem) {
         typedef lean_lds<NT> LY;
         PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW;
@@ -345,6 +349,7 @@ struct lean_mem {
         bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK;
         psP = words + LY::oSP, psM = words + LY::oSM;
         xP = words + LY::oXP, xPs = words + LY::oXPs, xM = words + LY::oXM, xMs = words + LY::oXMs;
+        edge = words + LY::oEG;
     }
 };
 
@@ -383,14 +388,28 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         m.xM[v] = wave_scan_umax(0xffffu - wm) | (wave_scan_umax(wm) << 16);
         m.xPs[vr] = wave_scan_umax(0xffffu - rp) | (wave_scan_umax(rp) << 16);
         m.xMs[vr] = wave_scan_umax(0xffffu - rm) | (wave_scan_umax(rm) << 16);
-        // a row of 16 equal non-zero window sums (lanes 0..14 equal their right neighbour)?
-        const u32 d = W ^ (u32)__builtin_amdgcn_update_dpp(0, (int)W, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
-        constexpr unsigned long long kLast = 0x8000800080008000ull, kFirst = 0x0001000100010001ull;
-        unsigned long long rP = (__ballot((d & 0xffffu) == 0) & __ballot(wp != 0)) | kLast;
-        unsigned long long rM = (__ballot((d >> 16) == 0) & __ballot(wm != 0)) | kLast;
-        rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8;
-        rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8;
-        bad |= ((rP | rM) & kFirst) != 0;
+        // 33 equal non-zero window sums in a row?  (The only way to the one case where smoothing.h:61-69
+        // is not S - min - max: see the header.)  Inside the tile: 32 lanes in a row that equal their
+        // right neighbour.  Across two tiles: the runs at the tile's two ends go to LDS with the first
+        // and the last value, phase C adds up what meets at a boundary.
+        const u32 d = W ^ (u32)__builtin_amdgcn_update_dpp(0, (int)W, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        constexpr unsigned long long kNotLast = 0x7fffffffffffffffull;  // lane 63 has no right neighbour here
+        const unsigned long long eP = __ballot((d & 0xffffu) == 0 && wp != 0) & kNotLast;
+        const unsigned long long eM = __ballot((d >> 16) == 0 && wm != 0) & kNotLast;
+        unsigned long long rP = eP, rM = eM;
+        rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8; rP &= rP >> 16;
+        rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8; rM &= rM >> 16;
+        bad |= (rP | rM) != 0;
+        {
+            const u32 leadP = (u32)__builtin_ctzll(~eP) + 1u, trailP = (u32)__builtin_clzll(~(eP << 1)) + 1u;
+            const u32 leadM = (u32)__builtin_ctzll(~eM) + 1u, trailM = (u32)__builtin_clzll(~(eM << 1)) + 1u;
+            u32 *eg = m.edge + 3 * ((i * NT + wave * kWave) >> 6);
+            if (lane == 0) {
+                eg[0] = W;
+                eg[2] = leadP | (leadM << 8) | (trailP << 16) | (trailM << 24);
+            }
+            if (lane == kWave - 1) eg[1] = W;
+        }
         m.PP[v] = tt[i].x;
         m.PM[v] = tt[i].y;
     }
@@ -408,13 +427,20 @@ struct lean_tracks {
 // (exp, obs) table.  Lanes beyond nt return z = 0.
 template <int NT>
 __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_args &a, kcoef *kc, const double2 *memo,
-                                              int dm, int nt, int tid, lean_tracks &tr, double &z) {
+                                              int dm, int nt, int ncs, int tid, lean_tracks &tr, double &z) {
     bool bad = false;
     z = 0.0;
     tr.ex = tr.pv = 0.0;
     tr.k = 0;
     bool miss = false;  // a lane whose (exp, obs) pair lies outside the table but inside the second-level bounds
     u32 miss_e = 0;
+    if (tid + 1 < (ncs >> 6)) {  // a run of equal non-zero window sums across the boundary of tiles tid, tid + 1
+        const u32 *e0 = m.edge + 3 * tid;
+        const u32 last = e0[1], first = e0[3], r0 = e0[2], r1 = e0[5];
+        const bool crossP = ((last ^ first) & 0xffffu) == 0 && (last & 0xffffu) != 0 && ((r0 >> 16) & 0xffu) + (r1 & 0xffu) >= 33u;
+        const bool crossM = ((last ^ first) >> 16) == 0 && (last >> 16) != 0 && (r0 >> 24) + ((r1 >> 8) & 0xffu) >= 33u;
+        bad |= crossP | crossM;
+    }
     if (tid < nt) {
         double e2[2];
 #pragma unroll
@@ -622,7 +648,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
 
     lean_tracks tr;
     double z;
-    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.dm, g.nt, tid, tr, z);
+    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.dm, g.nt, g.ncs, tid, tr, z);
     const lean_owner o = lean_own(g, tid, LEAN_STOP(6));
     lean_store_tracks(a, o, tr);
 
