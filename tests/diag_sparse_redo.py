@@ -38,3 +38,17 @@ for lam in (0.02, 0.1, 0.5, 2.0, "uniform 0..19"):
     tiles, redone, miss = ctx.scan_stats()
     print("counts %s: %.3f ms per %d bases = %.3g bases/s; tiles redone %d of %d (%.2f %%)"
           % (lam, dt * 1e3, total, total / dt, redone, tiles, 100.0 * redone / max(tiles, 1)))
+    # the empirical FDR of the same batch (100 draws per base)
+    d_ef = DeviceArray(ctx, t8)
+
+    def fstep():
+        sc.fdr_dev(n_iv, d_out.ptr, d_out.ptr + 3 * t8, d_ef.ptr, times=100, seed=1, half_win_width=3, interval_len=L,
+                   obs=d_out.ptr + t8)
+    fstep(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fstep()
+    ctx.synchronize()
+    dtf = (time.perf_counter() - t0) / 3
+    print("     FDR with 100 draws: %.2f ms = %.3g bases/s" % (dtf * 1e3, total / dtf))
+    d_ef.free()
