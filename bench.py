@@ -381,7 +381,7 @@ def main():
         tiles, redone, miss = ctx.scan_stats()
         robust = dict(hotspot_per_mille=args.hotspots, tiles=tiles, tiles_redone=redone,
                       largest_pair_outside_first_table=list(miss))
-    heavy = None
+    heavy = sparse = None
     if world == 1 and not ragged and not args.no_heavy and not args.hotspots and args.nb_mode == "memo":
         pm = 20
         sc.synth_hotspots_dev(1, n_iv, L, p_cp, p_cm, pm)
@@ -411,6 +411,22 @@ def main():
                           "an empty table (computes it between the passes, sized on the device by the largest "
                           "pair the first pass missed, and redoes those tiles), the main figures are the calls "
                           "after it")
+
+        # ---- the same job on SPARSE counts (Poisson 0.05 per base and strand: real data away from
+        #      hotspots), which exercise the first pass differently: single cuts make runs of equal window
+        #      sums.  A host-made block of counts is tiled over the resident arrays.
+        blk_iv = min(n_iv, 20000)
+        rs_sp = np.random.RandomState(7)
+        blocks = [rs_sp.poisson(0.05, blk_iv * l).astype(np.float64) for _ in range(2)]
+        for ptr, blk in ((p_cp, blocks[0]), (p_cm, blocks[1])):
+            for a0 in range(0, n_iv, blk_iv):
+                nb_ = min(blk_iv, n_iv - a0) * l
+                _lib.check(ctx.L.fpt_memcpy_h2d(ctx.h, ptr + a0 * l * 8, blk.ctypes.data, nb_ * 8))
+        dts = measure(kh, 1)[0]
+        tiles_s, redone_s, _ = ctx.scan_stats()
+        sparse = dict(workload=cfg["name"] + "+poisson0.05_counts", value=total * kh / dts, unit="bases/s",
+                      ms_per_step=dts / kh * 1e3, steps=kh, tiles=tiles_s, tiles_redone=redone_s,
+                      redone_fraction=redone_s / max(tiles_s, 1), ratio_to_headline=(total * kh / dts) / head)
 
     # ---- config 5, second half: the posterior footprint caller (cli/post.py:98-124) over D datasets
     #      of this rank's interval set, as ONE launch of fpt_posterior_dev.  Each dataset's tracks
@@ -546,6 +562,7 @@ def main():
             "other_nb_mode": other,
             "memo_robustness": robust,
             "heavy_tailed": heavy,
+            "sparse_counts": sparse,
             "posterior": post,
             "parity": parity,
         }
