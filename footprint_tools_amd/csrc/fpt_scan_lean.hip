@@ -394,8 +394,9 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         // and the last value, phase C adds up what meets at a boundary.
         const u32 d = W ^ (u32)__builtin_amdgcn_update_dpp(0, (int)W, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
         constexpr unsigned long long kNotLast = 0x7fffffffffffffffull;  // lane 63 has no right neighbour here
-        const unsigned long long eP = __ballot((d & 0xffffu) == 0 && wp != 0) & kNotLast;
-        const unsigned long long eM = __ballot((d >> 16) == 0 && wm != 0) & kNotLast;
+        // (one compare per ballot, the masks combined on the scalar side)
+        const unsigned long long eP = __ballot((d & 0xffffu) == 0) & __ballot(wp != 0) & kNotLast;
+        const unsigned long long eM = __ballot((d >> 16) == 0) & __ballot(wm != 0) & kNotLast;
         unsigned long long rP = eP, rM = eM;
         rP &= rP >> 1; rP &= rP >> 2; rP &= rP >> 4; rP &= rP >> 8; rP &= rP >> 16;
         rM &= rM >> 1; rM &= rM >> 2; rM &= rM >> 4; rM &= rM >> 8; rM &= rM >> 16;
@@ -403,12 +404,13 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         {
             const u32 leadP = (u32)__builtin_ctzll(~eP) + 1u, trailP = (u32)__builtin_clzll(~(eP << 1)) + 1u;
             const u32 leadM = (u32)__builtin_ctzll(~eM) + 1u, trailM = (u32)__builtin_clzll(~(eM << 1)) + 1u;
-            u32 *eg = m.edge + 3 * ((i * NT + wave * kWave) >> 6);
+            const u32 wlast = (u32)__builtin_amdgcn_readlane((int)W, kWave - 1);
             if (lane == 0) {
+                u32 *eg = m.edge + 3 * ((i * NT + wave * kWave) >> 6);
                 eg[0] = W;
+                eg[1] = wlast;
                 eg[2] = leadP | (leadM << 8) | (trailP << 16) | (trailM << 24);
             }
-            if (lane == kWave - 1) eg[1] = W;
         }
         m.PP[v] = tt[i].x;
         m.PM[v] = tt[i].y;
