@@ -1394,7 +1394,8 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
             m[j] = up[j] ? k[j] < kl : k[j] > a[j];
             any |= m[j];
         }
-        while (any) {
+        // one step of the walk for every draw that moves
+        auto walk_step = [&]() {
             double2 c[N];
 #pragma unroll
             for (int j = 0; j < N; ++j)
@@ -1417,6 +1418,14 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
                 }
                 any |= m[j];
             }
+        };
+        // The first step in straight-line code, the rest -- rare: the guide's brackets are a step wide --
+        // behind a wavefront-wide test: flags carried around a loop live in vector registers as 0 / 1
+        // and are re-tested with three instructions each (~100 per four draws when the loop started
+        // right after the first probe); now that costs only the wavefronts that walk on.
+        if (any) walk_step();
+        if (__builtin_amdgcn_ballot_w64(any)) {
+            while (any) walk_step();
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
