@@ -21,9 +21,9 @@ EXPORTS = [
     "fpt_ctx_set_stream", "fpt_ctx_use_own_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
-    "fpt_dev_zero", "fpt_format_stats", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
+    "fpt_dev_zero", "fpt_format_stats", "fpt_format_stats_batch", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
-    "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_write", "fpt_track_writer_close",
+    "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
     "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
@@ -173,6 +173,8 @@ def load():
         L.fpt_dev_free.argtypes = [vp, vp]
         L.fpt_dev_zero.argtypes = [vp, vp, i64]
         L.fpt_format_stats.argtypes = [C.c_char_p, i64, vp, i64, i32, vp, i64, C.c_char, i32, vp, i64, C.POINTER(i64)]
+        L.fpt_format_stats_batch.argtypes = [i64, vp, i32, vp, vp, vp, vp, i32, C.c_char, i32, vp, i64, C.POINTER(i64)]
+        L.fpt_track_writer_write_stats.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp, i32, i32]
         L.fpt_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.fpt_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.fpt_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -207,6 +209,24 @@ def f64(a):
 
 def ptr(a):
     return None if a is None else a.ctypes.data
+
+
+def batch_text_args(chroms, starts, row_off, table):
+    """arguments of fpt_format_stats_batch / fpt_track_writer_write_stats from a batch's interval
+    names, starts, row offsets and (rows, columns) matrix: (char*[] of the distinct names, ids,
+    starts, offsets, matrix)"""
+    uniq = {}
+    ids = np.fromiter((uniq.setdefault(c, len(uniq)) for c in chroms), dtype=np.int32, count=len(chroms))
+    for c in uniq:
+        if not str(c).isascii():
+            raise ValueError("chromosome name %r is not ASCII" % (c,))
+    names = (C.c_char_p * max(len(uniq), 1))(*[str(c).encode() for c in uniq])
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    off = np.ascontiguousarray(row_off, dtype=np.int64)
+    m = np.ascontiguousarray(table, dtype=np.float64)
+    if m.ndim != 2 or off.size != st.size + 1 or ids.size != st.size or (off.size and (off[0] < 0 or off[-1] > m.shape[0])):
+        raise ValueError("batch of %d intervals: offsets / starts / matrix do not fit together" % st.size)
+    return names, ids, st, off, m
 
 
 class Context(object):

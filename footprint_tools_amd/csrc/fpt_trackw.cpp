@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -26,9 +27,11 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/fpt.h"
+#include "fpt_text_internal.hpp"
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
 
@@ -63,6 +66,48 @@ bool bgzf_member(const unsigned char *data, size_t n, std::vector<unsigned char>
     out.resize(total);
     return true;
 }
+
+// the same member from a deflate state that is kept between members (one per thread of a team:
+// deflateInit2 allocates and clears ~260 KB) and a scratch buffer; `out` gets exactly the member
+struct deflater {
+    z_stream zs;
+    bool live = false;
+    std::vector<unsigned char> scratch;
+    ~deflater() {
+        if (live) deflateEnd(&zs);
+    }
+    bool member(const unsigned char *data, size_t n, std::vector<unsigned char> &out) {
+        if (!live) {
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            live = true;
+            scratch.resize(18 + compressBound((uLong)kBlock) + 8 + 64);
+        } else if (deflateReset(&zs) != Z_OK) {
+            return false;
+        }
+        zs.next_in = const_cast<unsigned char *>(data);
+        zs.avail_in = (uInt)n;
+        zs.next_out = scratch.data() + 18;
+        zs.avail_out = (uInt)(scratch.size() - 18 - 8);
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return false;
+        const size_t clen = zs.total_out, total = 18 + clen + 8;
+        if (total > 0x10000) return false;
+        const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0,
+                                        (unsigned char)((total - 1) & 0xff), (unsigned char)((total - 1) >> 8)};
+        std::memcpy(scratch.data(), head, 18);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isize = (uint32_t)n;
+        std::memcpy(scratch.data() + 18 + clen, &crc, 4);
+        std::memcpy(scratch.data() + 18 + clen + 4, &isize, 4);
+        out.assign(scratch.begin(), scratch.begin() + (long)total);
+        return true;
+    }
+};
+
+// pieces of text that follow each other in the uncompressed stream
+struct segment {
+    const unsigned char *p;
+    size_t n;
+};
 
 int reg2bin(int64_t beg, int64_t end) {  // the binning scheme of the SAM specification 5.3
     --end;
@@ -100,46 +145,87 @@ struct fpt_track_writer {
     int64_t last_bin = -1;                // the bin of the line before and its chunk list (most lines stay in it)
     std::vector<chunk> *last_chunks = nullptr;
 
-    bool flush_members(bool all) {
-        // whole members of kBlock bytes (all of `pending` at the end), a group at a time
-        size_t done = 0;
-        while (pending.size() - done >= (all ? 1 : kBlock)) {
-            const size_t avail = pending.size() - done;
-            const size_t n_mem = std::min(kGroup, all ? (avail + kBlock - 1) / kBlock : avail / kBlock);
-            std::vector<std::vector<unsigned char>> outs(n_mem);
-            std::atomic<size_t> next(0);
-            std::atomic<int> bad(0);
-            auto work = [&]() {
-                for (;;) {
-                    const size_t i = next.fetch_add(1);
-                    if (i >= n_mem) return;
-                    const size_t a = done + i * kBlock, len = std::min(kBlock, pending.size() - a);
-                    if (!bgzf_member(pending.data() + a, len, outs[i])) bad.store(1);
+    bool flush_members(bool all) { return flush_segments({}, all, nullptr); }
+
+    // `pending` followed by `more`, cut into members of kBlock bytes (a last shorter one when `all`),
+    // deflated on a team of threads straight from where the text lies (a member that straddles two
+    // pieces is put together in the thread's own buffer) and written in order; what is left over
+    // becomes the new `pending`.  `meanwhile` runs on the calling thread while the team works
+    // (the index of the same lines); if it returns false nothing is written.
+    template <typename F>
+    bool flush_segments(const std::vector<segment> &more, bool all, F meanwhile) {
+        std::vector<segment> segs;
+        std::vector<size_t> at;  // start of each piece in the joined text
+        size_t total = 0;
+        auto add = [&](const unsigned char *p, size_t n) {
+            if (n == 0) return;
+            segs.push_back(segment{p, n});
+            at.push_back(total);
+            total += n;
+        };
+        add(pending.data(), pending.size());
+        for (const segment &sg : more) add(sg.p, sg.n);
+        const size_t n_mem = all ? (total + kBlock - 1) / kBlock : total / kBlock;
+        const size_t done = std::min(total, n_mem * kBlock);
+        std::vector<std::vector<unsigned char>> outs(n_mem);
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        auto work = [&]() {
+            deflater d;
+            std::vector<unsigned char> joined;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n_mem) return;
+                const size_t a = i * kBlock, len = std::min(kBlock, total - a);
+                size_t k = (size_t)(std::upper_bound(at.begin(), at.end(), a) - at.begin()) - 1;
+                const unsigned char *src = segs[k].p + (a - at[k]);
+                if (a + len > at[k] + segs[k].n) {  // straddles pieces
+                    joined.resize(len);
+                    size_t got = 0;
+                    for (size_t u = a; got < len; ++k) {
+                        const size_t take = std::min(len - got, at[k] + segs[k].n - u);
+                        std::memcpy(joined.data() + got, segs[k].p + (u - at[k]), take);
+                        got += take;
+                        u += take;
+                    }
+                    src = joined.data();
                 }
-            };
-            const int nt = (int)std::min<size_t>((size_t)n_threads, n_mem);
-            if (nt <= 1) {
-                work();
-            } else {
-                std::vector<std::thread> team;
-                for (int t = 0; t < nt; ++t) team.emplace_back(work);
-                for (std::thread &t : team) t.join();
+                if (!d.member(src, len, outs[i])) bad.store(1);
             }
-            if (bad.load()) {
-                error = "deflate failed";
+        };
+        const int nt = (int)std::min<size_t>((size_t)n_threads, n_mem);
+        bool ok = true;
+        if (nt <= 1) {
+            if constexpr (!std::is_same<F, std::nullptr_t>::value) ok = meanwhile();
+            if (ok) work();
+        } else {
+            std::vector<std::thread> team;
+            for (int t = 0; t < nt; ++t) team.emplace_back(work);
+            if constexpr (!std::is_same<F, std::nullptr_t>::value) ok = meanwhile();
+            for (std::thread &t : team) t.join();
+        }
+        if (!ok) return false;
+        if (bad.load()) {
+            error = "deflate failed";
+            return false;
+        }
+        for (size_t i = 0; i < n_mem; ++i) {
+            member_at.push_back(cpos);
+            if (fwrite(outs[i].data(), 1, outs[i].size(), f) != outs[i].size()) {
+                error = "write failed";
                 return false;
             }
-            for (size_t i = 0; i < n_mem; ++i) {
-                member_at.push_back(cpos);
-                if (fwrite(outs[i].data(), 1, outs[i].size(), f) != outs[i].size()) {
-                    error = "write failed";
-                    return false;
-                }
-                cpos += outs[i].size();
-            }
-            done += std::min(avail, n_mem * kBlock);
+            cpos += outs[i].size();
         }
-        pending.erase(pending.begin(), pending.begin() + (long)done);
+        // the tail: the bytes after the last whole member
+        std::vector<unsigned char> rest;
+        rest.reserve(total - done);
+        for (size_t k = 0; k < segs.size(); ++k) {
+            if (at[k] + segs[k].n <= done) continue;
+            const size_t from = done > at[k] ? done - at[k] : 0;
+            rest.insert(rest.end(), segs[k].p + from, segs[k].p + segs[k].n);
+        }
+        pending.swap(rest);
         return true;
     }
 
@@ -154,10 +240,12 @@ struct fpt_track_writer {
         const char *t3 = (const char *)std::memchr(t2 + 1, '\t', (size_t)(e - t2 - 1));
         if (!t3) t3 = e;
         int64_t beg = 0, end = 0;
-        if (std::from_chars(t1 + 1, t2, beg).ptr != t2 || std::from_chars(t2 + 1, t3, end).ptr != t3 || beg < 0 ||
-            end <= beg || end > ((int64_t)1 << 29))
-            return bad_line();
-        const size_t ln = (size_t)(t1 - s);
+        if (std::from_chars(t1 + 1, t2, beg).ptr != t2 || std::from_chars(t2 + 1, t3, end).ptr != t3) return bad_line();
+        return index_known(s, (size_t)(t1 - s), beg, end, at, n);
+    }
+    // ... when its fields are known: chromosome s[0..ln), [beg, end), n bytes without the newline
+    bool index_known(const char *s, size_t ln, int64_t beg, int64_t end, uint64_t at, size_t n) {
+        if (beg < 0 || end <= beg || end > ((int64_t)1 << 29)) return bad_line();
         if (cur_ref < 0 || refs[(size_t)cur_ref].name.size() != ln || std::memcmp(refs[(size_t)cur_ref].name.data(), s, ln)) {
             for (const ref_index &r : refs)
                 if (r.name.size() == ln && !std::memcmp(r.name.data(), s, ln)) {
@@ -216,7 +304,7 @@ int fpt_track_writer_open(const char *path, fpt_track_writer **out) {
     w->f = f;
     w->path = path;
     unsigned hc = std::thread::hardware_concurrency();
-    w->n_threads = (int)(hc == 0 ? 1 : (hc > 64 ? 64 : hc));
+    w->n_threads = (int)(hc == 0 ? 1 : (hc > 256 ? 256 : hc));  // (deflate is ~20 MB/s per thread on this text)
     if (const char *e = getenv("FPT_TRACK_THREADS")) w->n_threads = atoi(e) > 0 ? atoi(e) : 1;
     *out = w;
     return FPT_OK;
@@ -251,6 +339,69 @@ int fpt_track_writer_write(fpt_track_writer *w, const char *text, int64_t n_byte
     w->upos += (uint64_t)n_bytes;
     if (w->pending.size() >= kGroup * kBlock && !w->flush_members(false))
         return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+    return FPT_OK;
+}
+
+int fpt_track_writer_write_stats(fpt_track_writer *w, int64_t n_intervals, const char *const *chrom_names, int32_t n_chroms,
+                                 const int32_t *chrom_id, const int64_t *start, const int64_t *row_off, const double *stats,
+                                 int32_t n_cols, int32_t precision) {
+    if (!w) return fpt_internal_fail(FPT_ERR_INVALID, "null writer");
+    if (!w->error.empty()) return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+    static const bool times = getenv("FPT_TRACK_TIMES") != nullptr;  // diagnostic: where a call spends its time
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<fpt_text_part> parts;
+    if (int rc = fpt_internal_format_batch(n_intervals, chrom_names, n_chroms, chrom_id, start, row_off, stats, n_cols, '\t',
+                                           precision, true, parts))
+        return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    bool lines = w->carry.empty();  // (after half a line of somebody's text: as text)
+    for (const fpt_text_part &pt : parts) lines = lines && pt.line_len.size() == (size_t)(row_off[pt.j1] - row_off[pt.j0]);
+    if (!lines) {
+        for (const fpt_text_part &pt : parts)
+            if (int rc = fpt_track_writer_write(w, pt.data.get(), (int64_t)pt.size)) return rc;
+        return FPT_OK;
+    }
+    // The lines are indexed from what is known about them (position = start + row, length as the
+    // formatter recorded it) while the team deflates the members they fall into.
+    std::vector<segment> segs;
+    size_t total = 0;
+    for (const fpt_text_part &pt : parts) {
+        segs.push_back(segment{(const unsigned char *)pt.data.get(), pt.size});
+        total += pt.size;
+    }
+    std::chrono::steady_clock::time_point t2 = t1;
+    auto index_all = [&]() {
+        struct stamp {
+            std::chrono::steady_clock::time_point &t;
+            ~stamp() { t = std::chrono::steady_clock::now(); }
+        } st{t2};
+        uint64_t at = w->upos;
+        for (const fpt_text_part &pt : parts) {
+            const uint16_t *ll = pt.line_len.data();
+            for (int64_t j = pt.j0; j < pt.j1; ++j) {
+                const char *name = chrom_names[chrom_id[j]];
+                const size_t ln = std::strlen(name);
+                const int64_t n = row_off[j + 1] - row_off[j];
+                for (int64_t i = 0; i < n; ++i) {
+                    const size_t len = *ll++;
+                    if (!w->index_known(name, ln, start[j] + i, start[j] + i + 1, at, len - 1)) return false;
+                    at += len;
+                }
+            }
+        }
+        return true;
+    };
+    const bool ok = w->flush_segments(segs, false, index_all);
+    if (!ok) return fpt_internal_fail(FPT_ERR_INVALID, "%s: %s", w->path.c_str(), w->error.c_str());
+    w->upos += (uint64_t)total;
+    if (times) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        fprintf(stderr, "fpt_track_writer_write_stats: %zu bytes: format %.1f ms, index %.1f ms, deflate + write (index inside) %.1f ms\n",
+                total, ms(t0, t1), ms(t1, t2), ms(t1, t3));
+    }
     return FPT_OK;
 }
 

@@ -151,17 +151,21 @@ class deviation_stats(object):
 
     def compute(self, indices):
         """statistics of intervals `indices` (one GPU batch); list of {"interval", "stats"}"""
+        return self._compute(indices)[0]
+
+    def _compute(self, indices):
+        """(records, the (bases, columns) matrix their `stats` are row blocks of, row offsets)"""
         indices = list(indices)
         ivs = [self.intervals[i] for i in indices]
         if not ivs:
-            return []
+            return [], None, None
         lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         sc = self._scanner()
         if self._device_inputs():  # (strand '-' intervals included: cut_counts_dev mirrors and swaps their counts)
             res, efdr = self._compute_on_device(indices, ivs, lens, off)
             if self.dm:  # the (bases, 5) table came back assembled
-                return [{"interval": iv, "stats": res[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])]
+                return [{"interval": iv, "stats": res[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])], res, off
         else:
             cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
             for L, cp, sq in zip(lens, cps, sqs):
@@ -170,8 +174,8 @@ class deviation_stats(object):
             res = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
             efdr = None
         if not self.dm:
-            return [{"interval": iv, "stats": np.column_stack((res["exp"][a:b], res["obs"][a:b]))}
-                    for iv, a, b in zip(ivs, off[:-1], off[1:])]
+            table = np.column_stack((res["exp"], res["obs"]))
+            return [{"interval": iv, "stats": table[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])], table, off
         if efdr is None:
             efdr = np.empty(off[-1])
             for a, b in self._runs(indices):
@@ -185,7 +189,7 @@ class deviation_stats(object):
             pv[off[j]:off[j + 1]] = wp[off[j]:off[j + 1]] = ef[off[j]:off[j + 1]] = 1.0
         with np.errstate(all="ignore"):  # detect.py:41 np.seterr(all="ignore")
             table = np.column_stack((res["exp"], res["obs"], -np.log(pv), -np.log(wp), ef))
-        return [{"interval": iv, "stats": table[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])]
+        return [{"interval": iv, "stats": table[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])], table, off
 
     def __getitem__(self, index):
         return self.compute([index])[0]
@@ -193,8 +197,11 @@ class deviation_stats(object):
     def batch_iter(self, batch_size=None):
         bs = int(batch_size or self.batch_size)
         for a in range(0, len(self.intervals), bs):
-            recs = self.compute(range(a, min(a + bs, len(self.intervals))))
-            yield {"interval": [r["interval"] for r in recs], "stats": [r["stats"] for r in recs]}
+            recs, table, off = self._compute(range(a, min(a + bs, len(self.intervals))))
+            out = {"interval": [r["interval"] for r in recs], "stats": [r["stats"] for r in recs]}
+            if table is not None:  # the records' rows as one matrix, for write_batch_to_output
+                out["table"], out["row_off"] = table, off
+            yield out
 
 
 # ---- output writers: same text as cli/utils.py:86-210 ---------------------------------------
@@ -252,6 +259,94 @@ def write_stats_to_output(interval, stats, file=sys.stdout, delim="\t", filter_f
             delim.join([str(chrom), str(start + i), str(start + i + 1)] + [fmt.format(v) for v in stats[i, :]])
             + "\n" for i in (range(stats.shape[0]) if rows is None else rows))
     file.write(text)
+
+
+def write_batch_to_output(batch, file=sys.stdout, delim="\t", fmt_string="0.4f"):
+    """`write_stats_to_output` for every interval of a `batch_iter` step, in one call of the
+    library: the step's rows are one matrix (`batch["table"]`, `batch["row_off"]`), formatted on a
+    team of threads -- and compressed there too when `file` is a `tabix.TrackWriter`.  The same
+    bytes as the loop over `zip(batch["interval"], batch["stats"])` (cli/detect.py:399-411)."""
+    ivs = batch["interval"]
+    fixed = _FIXED.match(fmt_string)
+    table = batch.get("table")
+    if (table is None or not fixed or len(delim) != 1 or not delim.isascii()
+            or not all(str(iv.chrom).isascii() for iv in ivs)):
+        for iv, st in zip(ivs, batch["stats"]):
+            write_stats_to_output(iv, st, file=file, delim=delim, fmt_string=fmt_string)
+        return
+    precision = int(fixed.group(1))
+    chroms, starts = [iv.chrom for iv in ivs], [iv.start for iv in ivs]
+    if hasattr(file, "write_stats") and delim == "\t":
+        file.write_stats(chroms, starts, batch["row_off"], table, precision)
+        return
+    names, ids, st, off, m = _lib.batch_text_args(chroms, starts, batch["row_off"], table)
+    L = _lib.load()
+    args = (len(st), names, len(names), ids.ctypes.data, st.ctypes.data, off.ctypes.data, m.ctypes.data, m.shape[1],
+            delim.encode(), precision)
+    used = C.c_int64()
+    buf = np.empty(int(off[-1] - off[0]) * (max(len(str(c)) for c in chroms) + 24 + m.shape[1] * (precision + 8)) + 64
+                   if len(st) else 0, dtype=np.uint8)
+    rc = L.fpt_format_stats_batch(*args, buf.ctypes.data, buf.size, C.byref(used))
+    if rc != 0 and used.value > buf.size:  # long values: the library says how much it needs
+        buf = np.empty(used.value, dtype=np.uint8)
+        rc = L.fpt_format_stats_batch(*args, buf.ctypes.data, buf.size, C.byref(used))
+    _lib.check(rc)
+    view = memoryview(buf)[:used.value]
+    raw = getattr(file, "buffer", None)  # a text file over a binary one: the bytes go underneath (no str copy)
+    if raw is not None and str(getattr(file, "encoding", "")).lower().replace("_", "-") in (
+            "utf-8", "utf8", "ascii", "us-ascii", "latin-1", "iso-8859-1", "iso8859-1", "cp1252"):
+        file.flush()
+        raw.write(view)
+        return
+    try:
+        file.write(str(view, "ascii"))
+    except TypeError:  # a binary file
+        file.write(view)
+
+
+def write_track(ds, filename, batch_size=None, header_columns=None, fmt_string="0.4f"):
+    """A whole `detect` run into a bgzip-compressed, tabix-indexed track: every step of
+    `ds.batch_iter()` through `write_batch_to_output` into a `tabix.TrackWriter`, the writing of one
+    step (threads inside the library, no interpreter lock held) overlapped with the statistics of
+    the next -- the role of the reference's writer thread behind its queue (cli/detect.py:364-411).
+    Intervals must come sorted the way a track is.  Returns the number of bases written."""
+    import queue
+    import threading
+    from .tabix import TrackWriter
+    q, err, n = queue.Queue(maxsize=2), [], 0
+    w = TrackWriter(filename)
+
+    def drain():
+        while True:
+            batch = q.get()
+            if batch is None:
+                return
+            if not err:
+                try:
+                    write_batch_to_output(batch, file=w, fmt_string=fmt_string)
+                except Exception as e:  # noqa: BLE001 -- handed to the caller below
+                    err.append(e)
+
+    t = threading.Thread(target=drain, name="fpt-track-writer", daemon=True)
+    t.start()
+    try:
+        if header_columns is not None:
+            write_output_header(header_columns, file=w, include_name=False)
+        for batch in ds.batch_iter(batch_size):
+            if err:
+                break
+            n += int(batch["row_off"][-1]) if "row_off" in batch else sum(s.shape[0] for s in batch["stats"])
+            q.put(batch)
+    finally:
+        q.put(None)
+        t.join()
+        try:
+            w.close()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    if err:
+        raise err[0]
+    return n
 
 
 def write_segment_batch_to_output(intervals, segments, name=".", file=sys.stdout, delim="\t", fmt_string="0.4f"):

@@ -57,6 +57,16 @@ class TrackWriter(object):
         _lib.check(self.L.fpt_track_writer_write(self.h, data, len(data)))
         return len(data)
 
+    def write_stats(self, chroms, starts, row_off, table, precision=4):
+        """the lines of a whole batch (detect.write_batch_to_output) formatted and compressed inside
+        the library: `table` is the (rows, columns) matrix, interval j owns rows
+        row_off[j]:row_off[j+1] and starts at starts[j] of chroms[j]"""
+        if self.h is None:
+            raise ValueError("write to a closed TrackWriter")
+        names, ids, st, off, m = _lib.batch_text_args(chroms, starts, row_off, table)
+        _lib.check(self.L.fpt_track_writer_write_stats(self.h, len(st), names, len(names), ids.ctypes.data, st.ctypes.data,
+                                                       off.ctypes.data, m.ctypes.data, m.shape[1], int(precision)))
+
     def flush(self):
         pass
 

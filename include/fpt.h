@@ -493,6 +493,22 @@ int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int6
                      const int64_t *rows, int64_t n_sel, char delim, int32_t precision, char *buf, int64_t cap,
                      int64_t *len_out);
 
+/* The same lines for a whole batch of intervals (what one step of detect's batch_iter yields,
+ * cli/detect.py:399-411 writes them interval by interval): `stats` holds the rows of interval j at
+ * [row_off[j], row_off[j+1]) (n_intervals + 1 offsets), its lines start at position start[j] of
+ * chromosome chrom_names[chrom_id[j]].  Intervals are formatted on a team of threads
+ * (FPT_TEXT_THREADS) and joined in order.  *len_out is set to the size of the text also when it
+ * does not fit `cap` (FPT_ERR_INVALID then: come back with a buffer of that size). */
+int fpt_format_stats_batch(int64_t n_intervals, const char *const *chrom_names, int32_t n_chroms,
+                           const int32_t *chrom_id, const int64_t *start, const int64_t *row_off,
+                           const double *stats, int32_t n_cols, char delim, int32_t precision, char *buf,
+                           int64_t cap, int64_t *len_out);
+/* ... and straight into a track writer (TAB-delimited), without the text passing through the host
+ * program: what `detect` followed by bgzip + tabix comes to. */
+int fpt_track_writer_write_stats(fpt_track_writer *w, int64_t n_intervals, const char *const *chrom_names,
+                                 int32_t n_chroms, const int32_t *chrom_id, const int64_t *start,
+                                 const int64_t *row_off, const double *stats, int32_t n_cols, int32_t precision);
+
 /* bytes of device memory set to zero on the context's stream (not synchronised) */
 int fpt_dev_zero(fpt_ctx *ctx, void *dev, int64_t bytes);
 int fpt_memcpy_h2d(fpt_ctx *ctx, void *dev, const void *host, int64_t bytes);

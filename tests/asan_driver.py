@@ -280,6 +280,60 @@ def main(tmp):
         rows[1] = n  # outside the matrix
         assert L.fpt_format_stats(b"c", 0, m.ctypes.data, n, 5, rows.ctypes.data, 3, b" ", 4, buf, 4096, C.byref(out)) != 0
 
+    # ---- a batch of intervals formatted and written in one call: against the text of the per-interval
+    #      formatter, into a buffer (exact, too small) and into a track (after whole lines and after half a
+    #      line of text); values that take the long path; bad ids / offsets
+    L.fpt_format_stats_batch.argtypes = [i64, vp, i32, vp, vp, vp, vp, i32, C.c_char, i32, vp, i64, C.POINTER(i64)]
+    L.fpt_track_writer_write_stats.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp, i32, i32]
+    import gzip
+    for threads in ("1", "7"):
+        os.environ["FPT_TEXT_THREADS"] = os.environ["FPT_TRACK_THREADS"] = threads
+        lens = rs.randint(0, 400, 700)
+        lens[::9] = 0
+        boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        bst = (1000 + np.cumsum(lens + 3) - lens).astype(np.int64)
+        bid = (np.arange(700) >= 400).astype(np.int32)
+        bst[400:] -= bst[400] - 5
+        m = rs.standard_normal((int(boff[-1]), 5)) * 10.0 ** rs.randint(-6, 7, (int(boff[-1]), 5))
+        m[3, 1], m[4, 2], m[6, 0] = 1e300, np.nan, -np.inf
+        names = (C.c_char_p * 2)(b"chr1", b"chr2_alt")
+        want = b"".join((b"chr1", b"chr2_alt")[bid[j]] + b"\t%d\t%d\t" % (bst[j] + i, bst[j] + i + 1)
+                        + "\t".join("{:0.4f}".format(v) for v in m[boff[j] + i]).encode() + b"\n"
+                        for j in range(700) for i in range(lens[j]))
+        for cap in (len(want), len(want) - 1):
+            buf, out = C.create_string_buffer(max(cap, 1)), i64()
+            rc = L.fpt_format_stats_batch(700, names, 2, bid.ctypes.data, bst.ctypes.data, boff.ctypes.data, m.ctypes.data, 5,
+                                          b"\t", 4, buf, cap, C.byref(out))
+            assert out.value == len(want) and (rc == 0 and buf.raw[:cap] == want if cap == len(want) else rc != 0), (threads, rc)
+        for lead in (b"", b"# a header line\n", b"chr1\t1\t2\thalf a li"):
+            wp = os.path.join(tmp, "batch%s.gz" % threads)
+            h = vp()
+            assert L.fpt_track_writer_open(wp.encode(), C.byref(h)) == 0
+            assert L.fpt_track_writer_write(h, lead, len(lead)) == 0
+            rc = L.fpt_track_writer_write_stats(h, 700, names, 2, bid.ctypes.data, bst.ctypes.data, boff.ctypes.data,
+                                                m.ctypes.data, 5, 4)
+            assert rc == 0, L.fpt_last_error()  # (the half line takes the batch's first line for its last columns)
+            assert L.fpt_track_writer_write(h, b"chr3\t7\t8\t1\n", 11) == 0
+            assert L.fpt_track_writer_close(h) == 0, L.fpt_last_error()
+            assert gzip.open(wp, "rb").read() == lead + want + b"chr3\t7\t8\t1\n"
+            a0 = int(bst[450])
+            assert track_rows(wp, "chr2_alt", a0, a0 + 50)[2] == int(sum(((bst[j] + np.arange(lens[j]) >= a0) &
+                                                                        (bst[j] + np.arange(lens[j]) < a0 + 50)).sum()
+                                                                       for j in range(400, 700)))
+        bad_id = bid.copy()
+        bad_id[5] = 2
+        bad_off = boff.copy()
+        bad_off[7] = bad_off[6] - 1
+        out = i64()
+        for ids_, off_ in ((bad_id, boff), (bid, bad_off)):
+            assert L.fpt_format_stats_batch(700, names, 2, ids_.ctypes.data, bst.ctypes.data, off_.ctypes.data, m.ctypes.data,
+                                            5, b"\t", 4, None, 0, C.byref(out)) != 0
+        h = vp()  # unsorted batch: the sticky error of the writer
+        assert L.fpt_track_writer_open(os.path.join(tmp, "badb.gz").encode(), C.byref(h)) == 0
+        rev = bst[:400][::-1].copy()
+        rc = L.fpt_track_writer_write_stats(h, 400, names, 2, bid.ctypes.data, rev.ctypes.data, boff.ctypes.data, m.ctypes.data, 5, 4)
+        assert rc != 0 and L.fpt_track_writer_close(h) != 0
+
     # ---- the CPU checker under the sanitizers: the expected-cleavage path with rounding ties, the
     # NB / window functions and one small whole-path batch
     O = C.CDLL(os.path.join(ROOT, "oracle", "libfpt_oracle_asan.so"))

@@ -60,7 +60,7 @@ for mode in ("device", "per-interval"):
     sub = ivs if mode == "device" else ivs[:1000]
     rf = bf if mode == "device" else type("R", (), {"__getitem__": lambda self, iv: bf[iv]})()
     ff = fa if mode == "device" else type("F", (), {"fetch": lambda self, c, s, e: fa.fetch(c, s, e)})()
-    ds = detect.deviation_stats(sub, rf, ff, bm, dm, fdr_shuffle_n=50, seed=1, batch_size=4096)
+    ds = detect.deviation_stats(sub, rf, ff, bm, dm, fdr_shuffle_n=50, seed=1, batch_size=int(os.environ.get("BATCH", "4096")))
     ds.compute(range(min(64, len(sub))))  # warm-up
     prof = None
     if os.environ.get("PROFILE") and mode == "device":

@@ -448,3 +448,68 @@ def test_detect_writer_into_an_indexed_track(tmp_path):
         assert np.allclose(out[k], np.concatenate([st[:, c] for st in stats]), atol=5e-5)
     rows = list(tb.fetch("chr1", 1798, 5002))
     assert [r[1] for r in rows] == ["1798", "1799", "5000", "5001"] and rows[0][2] == "1799" and len(rows[0]) == 8
+
+
+def test_batch_writer_matches_the_per_interval_writer(tmp_path, monkeypatch):
+    """write_batch_to_output (fpt_format_stats_batch / fpt_track_writer_write_stats: a batch_iter step
+    formatted in one call, on threads) writes the bytes the loop of write_stats_to_output over the
+    step's records does (cli/detect.py:399-411 + cli/utils.py:119-144) -- as text, as bytes, with
+    other formats and delimiters, into a track (file and index), on one thread and on many; empty
+    intervals, a change of chromosome, nan / inf / huge / negative-zero values included."""
+    import io
+    from footprint_tools_amd import detect
+    from footprint_tools_amd.tabix import TrackWriter
+    rs = np.random.RandomState(0)
+    ivs, off, pos = [], [0], 100
+    for j in range(3000):
+        n = int(rs.randint(0, 300)) if j % 50 else 0
+        ivs.append(_Iv("chr1" if j < 2000 else "chrX_random", pos, pos + n))
+        pos = 10 if j == 1999 else pos + n + 5
+        off.append(off[-1] + n)
+    table = rs.lognormal(0, 3, (off[-1], 5))
+    table[5, 2], table[7, 3], table[9, 1], table[11, 0], table[13, 4] = np.nan, np.inf, 3e20, -0.0, -np.inf
+    stats = [table[a:b] for a, b in zip(off[:-1], off[1:])]
+    batch = {"interval": ivs, "stats": stats, "table": table, "row_off": np.array(off)}
+
+    def loop(n=None, **kw):
+        f = io.StringIO()
+        for iv, st in zip(ivs[:n], stats[:n]):
+            detect.write_stats_to_output(iv, st, file=f, **kw)
+        return f.getvalue()
+
+    want = loop()
+    for threads in ("8", "1"):
+        monkeypatch.setenv("FPT_TEXT_THREADS", threads)
+        f = io.StringIO()
+        detect.write_batch_to_output(batch, file=f)
+        assert f.getvalue() == want
+    monkeypatch.delenv("FPT_TEXT_THREADS")
+    fb = io.BytesIO()
+    detect.write_batch_to_output(batch, file=fb)
+    assert fb.getvalue() == want.encode()
+    part = {"interval": ivs[:200], "stats": stats[:200], "table": table, "row_off": np.array(off[:201])}
+    for fmt, delim in (("0.2f", ","), ("0.9f", "\t"), ("0.12f", " "), ("0.3e", "\t")):  # the last: no fixed format, the loop
+        f = io.StringIO()
+        detect.write_batch_to_output(part, file=f, fmt_string=fmt, delim=delim)
+        assert f.getvalue() == loop(200, fmt_string=fmt, delim=delim), fmt
+    f = io.StringIO()  # a batch without its matrix (somebody else's records): the loop
+    detect.write_batch_to_output({"interval": ivs[:20], "stats": stats[:20]}, file=f)
+    assert f.getvalue() == loop(20)
+    f = io.StringIO()
+    detect.write_batch_to_output({"interval": [], "stats": [], "table": np.empty((0, 5)), "row_off": np.array([0])}, file=f)
+    assert f.getvalue() == ""
+    a, b = str(tmp_path / "a.bed.gz"), str(tmp_path / "b.bed.gz")
+    with TrackWriter(a) as w:
+        for iv, st in zip(ivs, stats):
+            detect.write_stats_to_output(iv, st, file=w)
+    with TrackWriter(b) as w:
+        detect.write_batch_to_output(batch, file=w)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(a + ".tbi", "rb").read() == open(b + ".tbi", "rb").read()
+    with pytest.raises(ValueError):  # offsets beyond the matrix
+        detect.write_batch_to_output(dict(batch, row_off=np.array(off) + 1), file=io.StringIO())
+    w = TrackWriter(str(tmp_path / "c.bed.gz"))
+    with pytest.raises(ValueError):  # unsorted: the later interval first
+        w.write_stats(["chr1", "chr1"], [500, 100], [0, 2, 4], table[:4])
+    with pytest.raises(ValueError):  # (and close reports it again)
+        w.close()
