@@ -77,6 +77,30 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """CPUs this process can actually run on: the machine's count cut to the affinity mask and to
+    the control group's quota (a GPU box reports 256 hardware threads under a quota of 16 CPUs;
+    256 OpenMP threads there are 16 cores' worth of work, throttled)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(cfg, table, DM, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm, results identical to the reference on
     the golden vectors) on a bounded sample of the same workload: all host cores, and one core.
@@ -86,7 +110,7 @@ def cpu_baseline(cfg, table, DM, budget_s=12.0):
     from oracle import oracle  # checker / baseline only
     L, scales = cfg["L"], cfg["scales"]
     l = L + 2 * (HW + SHW) + 1
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
 
     def run(n, threads):
         cp = oracle.synth_counts(1, 0, n * l, 0)

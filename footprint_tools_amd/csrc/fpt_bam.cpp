@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "../../include/fpt.h"
+#include "fpt_host_threads.hpp"
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
 
@@ -240,8 +241,7 @@ int fpt_bam_open(const char *path, fpt_bam **out) {
     if (!f) return fpt_internal_fail(FPT_ERR_INVALID, "Cannot open BAM file: %s", path);  // cutcounts.py:103
     fpt_bam *b = new fpt_bam();
     b->f = f;
-    unsigned hc = std::thread::hardware_concurrency();
-    b->n_threads = (int)(hc == 0 ? 1 : (hc > 64 ? 64 : hc));
+    b->n_threads = std::min(fpt_host_cpus(), 64);
     if (const char *e = getenv("FPT_BAM_THREADS")) b->n_threads = atoi(e) > 0 ? atoi(e) : 1;
     auto bad = [&](const char *what) {
         std::string msg = b->error.empty() ? what : b->error;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/fpt.h"
+#include "fpt_host_threads.hpp"
 #include "fpt_text_internal.hpp"
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
@@ -138,8 +139,7 @@ int fpt_format_stats(const char *chrom, int64_t start, const double *stats, int6
     int64_t bad_row = -1;
     // large selections: row blocks on a team of threads, each into its own buffer, joined in order
     // (a line is 30-70 bytes; the text of a million rows is what a `detect` run waits for)
-    unsigned hc = std::thread::hardware_concurrency();
-    int nt = (int)(hc == 0 ? 1 : (hc > 32 ? 32 : hc));
+    int nt = std::min(fpt_host_cpus(), 32);
     if (const char *e = getenv("FPT_TEXT_THREADS")) nt = atoi(e) > 0 ? atoi(e) : 1;
     if (count < 8192 || nt < 2) {
         char *p = format_rows(chrom, lc, start, stats, n_rows, n_cols, rows, 0, count, delim, precision, buf, buf + cap, &bad_row);
@@ -227,8 +227,7 @@ int fpt_internal_format_batch(int64_t n_intervals, const char *const *chrom_name
     const int64_t rows0 = row_off[0], total = row_off[n_intervals] - rows0;
     if (total > 0 && n_cols > 0 && !stats) return fpt_internal_fail(FPT_ERR_INVALID, "null matrix");
     want_lines = want_lines && fpt_internal_line_bound(lc_max, n_cols, precision) < 65536;
-    unsigned hc = std::thread::hardware_concurrency();
-    int nt = (int)(hc == 0 ? 1 : (hc > 64 ? 64 : hc));
+    int nt = std::min(fpt_host_cpus(), 64);
     if (const char *e = getenv("FPT_TEXT_THREADS")) nt = atoi(e) > 0 ? atoi(e) : 1;
     if ((int64_t)nt > total / 4096 + 1) nt = (int)(total / 4096 + 1);
     // interval ranges of about equal row counts

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/fpt.h"
+#include "fpt_host_threads.hpp"
 #include "fpt_bgzf.hpp"
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
@@ -434,8 +435,7 @@ int fpt_track_open(const char *path, fpt_track **out) {
         return fpt_internal_fail(FPT_ERR_INVALID, "Cannot open track file: %s", path);
     }
     t.bgzf = t.file.n >= 2 && t.file.p[0] == 31 && t.file.p[1] == 139;
-    unsigned hc = std::thread::hardware_concurrency();
-    t.n_threads = (int)(hc == 0 ? 1 : (hc > 32 ? 32 : hc));
+    t.n_threads = std::min(fpt_host_cpus(), 32);
     if (const char *e = getenv("FPT_TRACK_THREADS")) t.n_threads = atoi(e) > 0 ? atoi(e) : 1;
     std::string tbi = std::string(path) + ".tbi";
     if (t.bgzf && load_tbi(&t, tbi.c_str())) {

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/fpt.h"
+#include "fpt_host_threads.hpp"
 #include "fpt_text_internal.hpp"
 
 int fpt_internal_fail(int code, const char *fmt, ...);  // fpt_capi.cpp
@@ -76,10 +77,11 @@ struct deflater {
     ~deflater() {
         if (live) deflateEnd(&zs);
     }
+    int level = 6;
     bool member(const unsigned char *data, size_t n, std::vector<unsigned char> &out) {
         if (!live) {
             std::memset(&zs, 0, sizeof zs);
-            if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
             live = true;
             scratch.resize(18 + compressBound((uLong)kBlock) + 8 + 64);
         } else if (deflateReset(&zs) != Z_OK) {
@@ -134,6 +136,7 @@ struct fpt_track_writer {
     FILE *f = nullptr;
     std::string path, error;
     int n_threads = 1;
+    int level = 6;                       // zlib level of the data members (bgzip's default)
     std::vector<unsigned char> pending;  // text not yet cut into members (less than one group)
     std::string carry;                   // an unfinished line at the end of the last write call
     uint64_t upos = 0;                   // bytes of the uncompressed stream handed over so far
@@ -172,6 +175,7 @@ struct fpt_track_writer {
         std::atomic<int> bad(0);
         auto work = [&]() {
             deflater d;
+            d.level = level;
             std::vector<unsigned char> joined;
             for (;;) {
                 const size_t i = next.fetch_add(1);
@@ -303,10 +307,15 @@ int fpt_track_writer_open(const char *path, fpt_track_writer **out) {
     fpt_track_writer *w = new fpt_track_writer();
     w->f = f;
     w->path = path;
-    unsigned hc = std::thread::hardware_concurrency();
-    w->n_threads = (int)(hc == 0 ? 1 : (hc > 256 ? 256 : hc));  // (deflate is ~20 MB/s per thread on this text)
+    w->n_threads = std::min(fpt_host_cpus(), 256);  // (deflate is ~20 MB/s per thread on this text)
     if (const char *e = getenv("FPT_TRACK_THREADS")) w->n_threads = atoi(e) > 0 ? atoi(e) : 1;
     *out = w;
+    return FPT_OK;
+}
+
+int fpt_track_writer_set_level(fpt_track_writer *w, int32_t level) {
+    if (!w || level < 0 || level > 9) return fpt_internal_fail(FPT_ERR_INVALID, "compression level must be 0..9");
+    w->level = level;
     return FPT_OK;
 }
 

@@ -304,17 +304,18 @@ def write_batch_to_output(batch, file=sys.stdout, delim="\t", fmt_string="0.4f")
         file.write(view)
 
 
-def write_track(ds, filename, batch_size=None, header_columns=None, fmt_string="0.4f"):
+def write_track(ds, filename, batch_size=None, header_columns=None, fmt_string="0.4f", level=None):
     """A whole `detect` run into a bgzip-compressed, tabix-indexed track: every step of
     `ds.batch_iter()` through `write_batch_to_output` into a `tabix.TrackWriter`, the writing of one
     step (threads inside the library, no interpreter lock held) overlapped with the statistics of
     the next -- the role of the reference's writer thread behind its queue (cli/detect.py:364-411).
-    Intervals must come sorted the way a track is.  Returns the number of bases written."""
+    Intervals must come sorted the way a track is; `level` is the zlib level of the track (None: 6,
+    bgzip's).  Returns the number of bases written."""
     import queue
     import threading
     from .tabix import TrackWriter
     q, err, n = queue.Queue(maxsize=2), [], 0
-    w = TrackWriter(filename)
+    w = TrackWriter(filename, level=level)
 
     def drain():
         while True:

@@ -1,6 +1,8 @@
 """Host side of the cut-count ingestion (no GPU): the library's BGZF/BAM reader on files written by
 tests/bamwriter.py, and the FASTA reader.  The reader's parity with pysam is unpinned (pysam /
 htslib are not in the image); what is pinned here is the record layout of the BAM specification."""
+import os
+
 import numpy as np
 import pytest
 
@@ -506,6 +508,17 @@ def test_batch_writer_matches_the_per_interval_writer(tmp_path, monkeypatch):
         detect.write_batch_to_output(batch, file=w)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a + ".tbi", "rb").read() == open(b + ".tbi", "rb").read()
+    import gzip
+    from footprint_tools_amd.tabix import TabixFile
+    fast = str(tmp_path / "fast.bed.gz")  # zlib level 1: other bytes, the same text and the same answers
+    with TrackWriter(fast, level=1) as w:
+        detect.write_batch_to_output(batch, file=w)
+    assert gzip.open(fast, "rb").read() == want.encode() and os.path.getsize(fast) > os.path.getsize(a)
+    ta, tf = TabixFile(a), TabixFile(fast)
+    iv = ivs[2501]
+    assert list(ta.fetch(iv.chrom, iv.start, iv.end)) == list(tf.fetch(iv.chrom, iv.start, iv.end)) != []
+    with pytest.raises(ValueError):
+        TrackWriter(str(tmp_path / "lvl.gz"), level=12)
     with pytest.raises(ValueError):  # offsets beyond the matrix
         detect.write_batch_to_output(dict(batch, row_off=np.array(off) + 1), file=io.StringIO())
     w = TrackWriter(str(tmp_path / "c.bed.gz"))
