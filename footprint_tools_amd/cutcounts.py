@@ -215,7 +215,7 @@ class bamfile(object):
         b = int(np.searchsorted(self._index, hi_key, side="right"))
         return max(a, 0) * self._index_step, min(b * self._index_step, self._n_reads)
 
-    def cut_counts_ranges_dev(self, chroms, starts, lengths, counts_plus=None, counts_minus=None, flip=None):
+    def cut_counts_ranges_dev(self, chroms, starts, lengths, counts_plus=None, counts_minus=None, flip=None, rid=None):
         """Counts of the ranges [starts[i], starts[i] + lengths[i]) on chroms[i], written back to
         back (CSR) into two device arrays of sum(lengths) doubles: returns (plus, minus, offsets).
         Existing arrays are accumulated into (several files of one dataset).  flip[i] = True gives
@@ -229,7 +229,8 @@ class bamfile(object):
         total = int(off[-1])
         if counts_plus is None:
             counts_plus, counts_minus = DeviceArray(ctx, max(total, 1) * 8).zero(), DeviceArray(ctx, max(total, 1) * 8).zero()
-        rid = np.array([self._ref_index.get(c, -1) for c in chroms], dtype=np.int64)
+        if rid is None:  # (callers that hold the intervals as columns pass the file's reference ids)
+            rid = np.array([self._ref_index.get(c, -1) for c in chroms], dtype=np.int64)
         known = rid >= 0  # a chromosome the file does not have: all zeros, like an empty fetch
         key = (rid << 32) | np.clip(starts, 0, None)
         # ranges starting before 0 keep their true length: shift by the clipped part
@@ -273,6 +274,12 @@ class bamfile(object):
         (`prediction.compute` fetches [start - pad - 1, end + pad), modeling/predict.pyx:132-134):
         (counts_plus, counts_minus) DeviceArrays in FootprintScanner.scan_dev's CSR layout.
         Intervals on strand '-' get the reference's mirrored and swapped arrays."""
+        if hasattr(intervals, "cid"):  # intervals.interval_columns
+            cols = intervals
+            flip = cols.flip
+            cp, cm, _ = self.cut_counts_ranges_dev(None, cols.start - (pad + 1), cols.end - cols.start + (2 * pad + 1),
+                                                   flip=flip if flip.any() else None, rid=cols.lookup(self._ref_index, -1))
+            return cp, cm
         ivs = list(intervals)
         flip = [getattr(iv, "strand", None) == "-" for iv in ivs]
         cp, cm, _ = self.cut_counts_ranges_dev([iv.chrom for iv in ivs], [iv.start - pad - 1 for iv in ivs],

@@ -46,6 +46,7 @@ class deviation_stats(object):
         self._sc = None
         self._ctx = ctx
         self._bases_before = None
+        self._cols = None
 
     def __len__(self):
         return len(self.intervals)
@@ -84,17 +85,23 @@ class deviation_stats(object):
 
     def _runs(self, indices):
         """maximal runs of consecutive indices: one FDR call each keeps the RNG counters global"""
-        runs, start = [], 0
-        for j in range(1, len(indices) + 1):
-            if j == len(indices) or indices[j] != indices[j - 1] + 1:
-                runs.append((start, j))
-                start = j
+        idx = np.asarray(indices, dtype=np.int64)
+        cuts = np.nonzero(np.diff(idx) != 1)[0] + 1
+        bounds = [0] + cuts.tolist() + [int(idx.size)]
+        runs = list(zip(bounds[:-1], bounds[1:]))
         if self._bases_before is None:
             # global base index of an interval = bases of all intervals before it in the full list,
             # so the null draws do not depend on how the list is batched or sharded
-            all_len = np.array([iv.end - iv.start for iv in self.intervals], dtype=np.int64)
-            self._bases_before = np.concatenate([[0], np.cumsum(all_len)])
+            cols = self._columns()
+            self._bases_before = np.concatenate([[0], np.cumsum(cols.end - cols.start)])
         return runs
+
+    def _columns(self):
+        """the interval list as columns (read off the objects once)"""
+        if self._cols is None:
+            from .intervals import interval_columns
+            self._cols = interval_columns.of(self.intervals)
+        return self._cols
 
     def _compute_on_device(self, indices, ivs, lens, off):
         """The batch without leaving the GPU between the steps: cut counts from the alignments on
@@ -107,11 +114,15 @@ class deviation_stats(object):
         total, n_iv = int(off[-1]), len(ivs)
         S = len(sc.scales)
         n_tracks = 3 + S + (1 if self.dm else 0)
-        d_cp, d_cm = self.read_func.cut_counts_dev(ivs, self.padding)
+        from .cutcounts import bamfile
+        from .fasta import FastaFile
+        cols = self._columns().take(indices)  # (this package's readers take the batch as columns)
+        d_cp, d_cm = self.read_func.cut_counts_dev(cols if isinstance(self.read_func, bamfile) else ivs, self.padding)
         bufs = [d_cp, d_cm]
         try:
             if hasattr(self.fasta_func, "fetch_batch_dev"):  # the FASTA bytes live on the device too
-                d_sq, n_sq = self.fasta_func.fetch_batch_dev(ctx, ivs, self.padding)
+                d_sq, n_sq = self.fasta_func.fetch_batch_dev(ctx, cols if isinstance(self.fasta_func, FastaFile) else ivs,
+                                                             self.padding)
             else:
                 sq = self.fasta_func.fetch_batch(ivs, self.padding)
                 d_sq, n_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq), sq.size
@@ -155,17 +166,22 @@ class deviation_stats(object):
 
     def _compute(self, indices):
         """(records, the (bases, columns) matrix their `stats` are row blocks of, row offsets)"""
-        indices = list(indices)
-        ivs = [self.intervals[i] for i in indices]
+        if isinstance(indices, range) and indices.step == 1 and 0 <= indices.start <= indices.stop <= len(self.intervals):
+            ivs = self.intervals[indices.start:indices.stop]
+        else:
+            indices = list(indices)
+            ivs = [self.intervals[i] for i in indices]
         if not ivs:
             return [], None, None
-        lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
+        cols = self._columns().take(indices)
+        lens = cols.end - cols.start
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         sc = self._scanner()
         if self._device_inputs():  # (strand '-' intervals included: cut_counts_dev mirrors and swaps their counts)
             res, efdr = self._compute_on_device(indices, ivs, lens, off)
             if self.dm:  # the (bases, 5) table came back assembled
-                return [{"interval": iv, "stats": res[a:b]} for iv, a, b in zip(ivs, off[:-1], off[1:])], res, off
+                o = off.tolist()
+                return [{"interval": iv, "stats": res[a:b]} for iv, a, b in zip(ivs, o[:-1], o[1:])], res, off
         else:
             cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
             for L, cp, sq in zip(lens, cps, sqs):

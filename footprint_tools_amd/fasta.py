@@ -122,16 +122,22 @@ class FastaFile(object):
         interval list in the scan's layout (fpt_seq_gather_dev)."""
         from . import _lib
         from .scan import DeviceArray
-        ivs = list(intervals)
         fa = self.to_device(ctx)
-        starts = np.array([iv.start for iv in ivs], dtype=np.int64) - (pad + 1 + context)
-        n = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64) + (2 * pad + 1 + 2 * context)
+        if hasattr(intervals, "cid"):  # intervals.interval_columns
+            ivs = intervals
+            starts, n = ivs.start - (pad + 1 + context), ivs.end - ivs.start + (2 * pad + 1 + 2 * context)
+            where = ivs.lookup(self.index, (0, 0, 0, 1))
+        else:
+            ivs = list(intervals)
+            starts = np.array([iv.start for iv in ivs], dtype=np.int64) - (pad + 1 + context)
+            n = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64) + (2 * pad + 1 + 2 * context)
+            where = np.array([self.index.get(iv.chrom, (0, 0, 0, 1)) for iv in ivs], dtype=np.int64).reshape(len(ivs), 4)
         off = np.concatenate([[0], np.cumsum(n)])
         desc = np.empty((len(ivs), 7), dtype=np.int64)
         desc[:, 0], desc[:, 1], desc[:, 2] = starts, n, off[:-1]
-        desc[:, 3:] = np.array([self.index.get(iv.chrom, (0, 0, 0, 1)) for iv in ivs], dtype=np.int64).reshape(len(ivs), 4)
+        desc[:, 3:] = where
         out = DeviceArray(ctx, max(int(off[-1]), 16))
-        if ivs:
+        if len(ivs):
             d_desc = DeviceArray(ctx, desc.nbytes).upload(desc)
             _lib.check(ctx.L.fpt_seq_gather_dev(ctx.h, fa.ptr, self._dev_bytes, d_desc.ptr, len(ivs), out.ptr))
             ctx.synchronize()

@@ -62,3 +62,46 @@ def read_intervals(path):
                 raise ValueError("%s line %d: start / end out of order" % (path, n))
             out.append(iv)
     return out
+
+
+class interval_columns(object):
+    """An interval list as columns (distinct chromosome names, an id per interval, starts, ends,
+    strand '-' flags): read off the objects once, so that a batch is a slice of arrays instead of
+    a dozen passes over Python objects (~2 us per interval and batch otherwise -- more than the
+    statistics of a 160-base interval cost on the device)."""
+
+    def __init__(self, names, cid, start, end, flip):
+        self.names, self.cid, self.start, self.end, self.flip = names, cid, start, end, flip
+
+    @classmethod
+    def of(cls, intervals):
+        import numpy as np
+        n = len(intervals)
+        uniq = {}
+        cid = np.fromiter((uniq.setdefault(iv.chrom, len(uniq)) for iv in intervals), dtype=np.int32, count=n)
+        start = np.fromiter((iv.start for iv in intervals), dtype=np.int64, count=n)
+        end = np.fromiter((iv.end for iv in intervals), dtype=np.int64, count=n)
+        flip = np.fromiter((getattr(iv, "strand", None) == "-" for iv in intervals), dtype=bool, count=n)
+        return cls(list(uniq), cid, start, end, flip)
+
+    def __len__(self):
+        return self.cid.size
+
+    def take(self, indices):
+        """the rows `indices` (a range of step 1 is a slice)"""
+        import numpy as np
+        if isinstance(indices, range) and indices.step == 1:
+            sl = slice(indices.start, indices.stop)
+        else:
+            sl = np.asarray(indices, dtype=np.int64)
+        return interval_columns(self.names, self.cid[sl], self.start[sl], self.end[sl], self.flip[sl])
+
+    def chroms(self):
+        names = self.names
+        return [names[c] for c in self.cid.tolist()]
+
+    def lookup(self, table, missing):
+        """per interval: table[chrom] (rows of an int64 array), `missing` for names it does not have"""
+        import numpy as np
+        rows = np.array([table.get(c, missing) for c in self.names], dtype=np.int64)
+        return rows[self.cid] if len(self.names) else rows.reshape((0,) + np.shape(missing))

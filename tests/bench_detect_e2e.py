@@ -108,3 +108,7 @@ if hasattr(detect, "write_track"):
     t3 = time.perf_counter() - t0
     same = open(path, "rb").read() == open(path3, "rb").read()
     print("write_track (overlap):  %.2f s -> %.3g bases/s (same bytes: %s)" % (t3, n / t3, same))
+    t0 = time.perf_counter()
+    detect.write_track(ds, path3, level=1)
+    t3 = time.perf_counter() - t0
+    print("write_track, level 1:   %.2f s -> %.3g bases/s (%d bytes)" % (t3, n / t3, os.path.getsize(path3)))
