@@ -98,6 +98,8 @@ def main():
     path = os.path.join(tempfile.mkdtemp(), "stats.bed.gz")
     with TrackWriter(path) as w:
         w.write(bedgraph.getvalue())
+    # (a run that only wants the track skips the text: `detect.write_track(ds, path)` formats and
+    #  compresses every batch inside the library while the next one is on the GPU)
     tb = TabixFile(path)
     iv = intervals[len(intervals) // 2]
     rows = list(tb.fetch(iv.chrom, iv.start, iv.end))

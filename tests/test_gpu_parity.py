@@ -1290,6 +1290,31 @@ def test_detect_driver_against_the_reference_driver(fpt, tmp_path):
         for a_, b_ in g["learn_cnts_%d" % i]:  # cli/learn_dm.py:281-287
             want_hist[int(a_), int(b_)] += 1
     assert np.array_equal(ec.histogram(), want_hist)
+    # detect.write_track: the run into a bgzip + tabix track, a step written (on the writer thread, in
+    # the library) while the next is computed -- the text of the per-interval writer loop
+    import gzip
+    import io
+    from footprint_tools_amd.tabix import TabixFile
+    sv, last = [], {}
+    for iv in sorted(ivs, key=lambda v: (v.chrom, v.start)):
+        if iv.start >= last.get(iv.chrom, -1):
+            sv.append(iv)
+            last[iv.chrom] = iv.end
+    assert len(sv) >= 3
+    ds2 = detect.deviation_stats(sv, bf, fa, bm, dm, fdr_shuffle_n=50, seed=7, batch_size=2, **kw)
+    cols = ["exp", "obs", "neglog_pval", "neglog_winpval", "fdr"]
+    track = str(tmp_path / "stats.bed.gz")
+    assert detect.write_track(ds2, track, header_columns=cols) == sum(iv.end - iv.start for iv in sv)
+    text = io.StringIO()
+    detect.write_output_header(cols, file=text, include_name=False)
+    for b in ds2.batch_iter():
+        assert b["table"].shape == (b["row_off"][-1], 5)
+        for iv, st in zip(b["interval"], b["stats"]):
+            detect.write_stats_to_output(iv, st, file=text)
+    assert gzip.open(track, "rb").read().decode() == text.getvalue()
+    tb = TabixFile(track)
+    rows = list(tb.fetch(sv[1].chrom, sv[1].start + 3, sv[1].start + 9))
+    assert [int(r[1]) for r in rows] == list(range(sv[1].start + 3, sv[1].start + 9)) and tb.has_tbi
     bf.close()
     fa.close()
 
