@@ -126,6 +126,9 @@ def cpu_baseline(cfg, table, DM, budget_s=12.0):
     rate = probe_n * L / dt
     n = int(max(probe_n, min(rate * budget_s / L, 200000)))
     dt = run(n, cores)
+    if dt < 0.5 * budget_s and n < 200000:  # the probe was mostly thread start-up: size the sample again
+        n = int(max(n, min(n * budget_s / dt, 200000)))
+        dt = run(n, cores)
     dt1 = run(8, 1)
     n1 = int(max(8, min(8 * 3.0 / dt1, 20000)))  # about 3 s on one core
     dt1 = run(n1, 1)
