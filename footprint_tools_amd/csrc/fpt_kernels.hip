@@ -1357,19 +1357,29 @@ __device__ __forceinline__ uint32_t guide_pair(const uint16_t *base, uint32_t by
 // N first probes, then every round of the walk -- a draw is two or three dependent trips to L2, and
 // a pass spends most of its time waiting for them (measured per phase), so the draws of a
 // Philox block share the trips instead of queueing behind each other.
+// The per-draw flags of the walk (still moving? upwards?) are kept as wavefront masks in scalar
+// registers -- ballots combined with scalar logic, turned back into a lane condition where a select
+// needs one (inverse ballot: free) --: as bools the compiler materialises each as 0 / 1 in a vector
+// register and re-tests it (3-5 vector instructions per flag and use; the kernel is bound by vector
+// issue), and "any lane still moving" is then a scalar compare instead of a vector one.
+typedef unsigned long long lane_mask;
+#define FPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)
+#define FPT_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 template <int N>
 __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *guide, int memo_obs, const double *par,
                                            int ei, const double *exp_ptr, const uint32_t (&w)[N],
                                            const double (&u)[N], double (&z)[N]) {
-    bool d[N];  // still to be evaluated directly
-    int lo_tab = -1;
-#pragma unroll
-    for (int j = 0; j < N; ++j) d[j] = true;
-    if (ei >= 0) {
-        const uint32_t row = (uint32_t)ei * (uint32_t)memo_obs * 16u, gr = (uint32_t)ei * (uint32_t)(kGuide * 2);
+    lane_mask D[N];  // still to be evaluated directly
+    // (a mask is the same for every lane and must not be assigned under a lane's condition: the few
+    // lanes without a table row walk row 0 along with the others and their result is dropped)
+    const lane_mask tabled = FPT_BALLOT(ei >= 0), untabled = FPT_BALLOT(ei < 0);
+    const int lo_tab = ei >= 0 ? memo_obs - 1 : -1;
+    {
+        const uint32_t eiu = ei >= 0 ? (uint32_t)ei : 0u;
+        const uint32_t row = eiu * (uint32_t)memo_obs * 16u, gr = eiu * (uint32_t)(kGuide * 2);
         const int kl = memo_obs - 1;
         int a[N], k[N];
-        bool up[N], m[N];
+        lane_mask UP[N], M[N];
         double2 e[N];
         uint32_t g[N];
         float f[N];
@@ -1387,56 +1397,52 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
         for (int j = 0; j < N; ++j) e[j] = table_entry(memo, row + 16u * (uint32_t)k[j]);
         // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
         // below has to be looked at unless the guide already says it is < u (k == a).
-        bool any = false;
+        lane_mask any = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            up[j] = e[j].x < u[j];
-            m[j] = up[j] ? k[j] < kl : k[j] > a[j];
-            any |= m[j];
+            UP[j] = FPT_BALLOT(e[j].x < u[j]);
+            M[j] = ((UP[j] & FPT_BALLOT(k[j] < kl)) | (~UP[j] & FPT_BALLOT(k[j] > a[j]))) & tabled;
+            any |= M[j];
         }
-        // one step of the walk for every draw that moves
-        auto walk_step = [&]() {
+        // One step of the walk for every draw that moves, the loads together.  A lane rarely needs a
+        // second one (0.4 % of the draws: a guide bracket is mostly a step wide) but a wavefront's
+        // 256 draws do 60 % of the time, so the later steps are taken draw by draw: by the one or two
+        // of the four that still have a lane moving.
+        auto step_of = [&](lane_mask Mj, lane_mask UPj) { return FPT_LANE(Mj) ? (FPT_LANE(UPj) ? 1 : -1) : 0; };
+        auto settle = [&](const double2 &cj, int &kj, double2 &ej, lane_mask &Mj, lane_mask UPj, int aj, double uj) {
+            // up: take the entry, stop at the first one >= u.  down: take it while it is >= u (the
+            // entry below qualifies too), stop at the lane's guide bound.
+            const lane_mask lt = FPT_BALLOT(cj.x < uj), ge = FPT_BALLOT(cj.x >= uj);
+            const lane_mask mv = Mj & (UPj | ge);
+            if (FPT_LANE(mv)) {  // (moves under the lanes' mask: two 64-bit moves instead of four selects)
+                kj += FPT_LANE(UPj) ? 1 : -1;
+                ej = cj;
+            }
+            Mj &= (UPj & lt & FPT_BALLOT(kj < kl)) | (~UPj & ge & FPT_BALLOT(kj > aj));
+        };
+        if (any) {
             double2 c[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                c[j] = table_entry(memo, row + 16u * (uint32_t)(k[j] + (m[j] ? (up[j] ? 1 : -1) : 0)));
-            any = false;
+            for (int j = 0; j < N; ++j) c[j] = table_entry(memo, row + 16u * (uint32_t)(k[j] + step_of(M[j], UP[j])));
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if (m[j]) {
-                    if (up[j]) {  // stop at the first entry >= u
-                        k[j] += 1;
-                        e[j] = c[j];
-                        m[j] = c[j].x < u[j] && k[j] < kl;
-                    } else if (c[j].x >= u[j]) {  // the entry below qualifies too: keep going down
-                        k[j] -= 1;
-                        e[j] = c[j];
-                        m[j] = k[j] > a[j];
-                    } else {
-                        m[j] = false;
-                    }
-                }
-                any |= m[j];
-            }
-        };
-        // The first step in straight-line code, the rest -- rare: the guide's brackets are a step wide --
-        // behind a wavefront-wide test: flags carried around a loop live in vector registers as 0 / 1
-        // and are re-tested with three instructions each (~100 per four draws when the loop started
-        // right after the first probe); now that costs only the wavefronts that walk on.
-        if (any) walk_step();
-        if (__builtin_amdgcn_ballot_w64(any)) {
-            while (any) walk_step();
+            for (int j = 0; j < N; ++j) settle(c[j], k[j], e[j], M[j], UP[j], a[j], u[j]);
         }
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            while (M[j]) {
+                const double2 cj = table_entry(memo, row + 16u * (uint32_t)(k[j] + step_of(M[j], UP[j])));
+                settle(cj, k[j], e[j], M[j], UP[j], a[j], u[j]);
+            }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             z[j] = e[j].y;
-            d[j] = e[j].x < u[j];  // ran off the table; false for NaN rows: those return the NaN entry
+            // ran off the table (not for NaN rows: those return the NaN entry), or has no row
+            D[j] = (FPT_BALLOT(e[j].x < u[j]) & tabled) | untabled;
         }
-        lo_tab = kl;
     }
-    bool any_direct = false;
+    lane_mask any_direct = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) any_direct |= d[j];
+    for (int j = 0; j < N; ++j) any_direct |= D[j];
     if (any_direct) {  // rare: beyond the table or a non-integer expected value
         const double ex = ei >= 0 ? (double)ei : *exp_ptr;
         // one copy of the evaluation (it is ~8,000 instructions): a lane's draws that need it take
@@ -1446,24 +1452,24 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
             double uj = 0.0;
 #pragma unroll
             for (int i = N - 1; i >= 0; --i) {
-                j = d[i] ? i : j;
-                uj = d[i] ? u[i] : uj;
+                j = FPT_LANE(D[i]) ? i : j;
+                uj = FPT_LANE(D[i]) ? u[i] : uj;
             }
-            if (j >= 0) {
-                const double zz = nb_inverse_cdf_direct(par, ex, uj, lo_tab).y;
+            double zz = 0.0;
+            if (j >= 0) zz = nb_inverse_cdf_direct(par, ex, uj, lo_tab).y;
+            any_direct = 0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    z[i] = j == i ? zz : z[i];
-                    d[i] = j == i ? false : d[i];
-                }
+            for (int i = 0; i < N; ++i) {
+                z[i] = j == i ? zz : z[i];
+                D[i] &= ~FPT_BALLOT(j == i);
+                any_direct |= D[i];
             }
-            bool more = false;
-#pragma unroll
-            for (int i = 0; i < N; ++i) more |= d[i];
-            if (!__builtin_amdgcn_ballot_w64(more)) break;
+            if (!any_direct) break;
         }
     }
 }
+#undef FPT_BALLOT
+#undef FPT_LANE
 
 // A null window p-value is ndtr(y), y = -(sum of z) / sqrt(K), and only its RANK among the
 // interval's observed values is needed.  ndtr is monotone, so "observed P < ndtr(y)" is
