@@ -285,7 +285,7 @@ def write_batch_to_output(batch, file=sys.stdout, delim="\t", fmt_string="0.4f")
     ivs = batch["interval"]
     fixed = _FIXED.match(fmt_string)
     table = batch.get("table")
-    if (table is None or not fixed or len(delim) != 1 or not delim.isascii()
+    if (table is None or not fixed or int(fixed.group(1)) > 30 or len(delim) != 1 or not delim.isascii()
             or not all(str(iv.chrom).isascii() for iv in ivs)):
         for iv, st in zip(ivs, batch["stats"]):
             write_stats_to_output(iv, st, file=file, delim=delim, fmt_string=fmt_string)

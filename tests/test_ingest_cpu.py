@@ -490,7 +490,7 @@ def test_batch_writer_matches_the_per_interval_writer(tmp_path, monkeypatch):
     detect.write_batch_to_output(batch, file=fb)
     assert fb.getvalue() == want.encode()
     part = {"interval": ivs[:200], "stats": stats[:200], "table": table, "row_off": np.array(off[:201])}
-    for fmt, delim in (("0.2f", ","), ("0.9f", "\t"), ("0.12f", " "), ("0.3e", "\t")):  # the last: no fixed format, the loop
+    for fmt, delim in (("0.2f", ","), ("0.9f", "\t"), ("0.12f", " "), ("0.3e", "\t"), ("0.40f", "\t")):  # the last two: the loop
         f = io.StringIO()
         detect.write_batch_to_output(part, file=f, fmt_string=fmt, delim=delim)
         assert f.getvalue() == loop(200, fmt_string=fmt, delim=delim), fmt
