@@ -1832,19 +1832,20 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
     // truncation with the guide built on the same function -- 1 % per pass, 5 % more set-up)
     const int nb = np2 < 2048 ? np2 : 2048;
     const double yscale = (double)nb / (2.0 * kYR);
-    for (int b = tid; b <= nb; b += NT) {
-        int l = 0;
-        if (b == nb) {
-            l = rank_one;  // thresholds below +inf
-        } else if (b > 0) {
-            const double edge = (double)b / yscale - kYR;
-            int h = m;
-            while (l < h) {
-                const int mid = (l + h) >> 1;
-                if (skey[mid] <= edge) l = mid + 1; else h = mid;
-            }
-        }
-        rguide[b] = l;
+    // rguide[b] = #{thresholds below 1 whose slice is < b}, with the slice of a threshold found by the
+    // very expression a null window's is below -- it is monotone in x, so the thresholds <= x lie
+    // between rguide[slice(x)] and rguide[slice(x) + 1] whatever the rounding does at a slice's
+    // edge.  Filled from the sorted thresholds: the one at place i writes i to the slices after its
+    // predecessor's up to its own (one or two on average) -- no search (a bisection per slice was
+    // log2(L) dependent LDS reads, a quarter of an interval's set-up time).
+    auto slice_of = [&](double y) {
+        const int b = (y > -kYR) ? (int)((y + kYR) * yscale) : 0;
+        return (b < nb && y < kYR) ? b : nb - 1;
+    };
+    for (int i = tid; i <= rank_one; i += NT) {
+        const int from = i == 0 ? 0 : slice_of(skey[i - 1]) + 1;
+        const int to = i == rank_one ? nb : slice_of(skey[i]);  // (the last entry: every threshold below 1)
+        for (int b = from; b <= to; ++b) rguide[b] = i;
     }
     __syncthreads();
 
@@ -2006,9 +2007,7 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 #pragma clang loop unroll(disable)
             for (int pr = 0; pr < npairs; ++pr) {
                 const double y0 = pr ? x2 : x0, y1 = pr ? x3 : x1;
-                int b0 = (y0 > -kYR) ? (int)((y0 + kYR) * yscale) : 0, b1 = (y1 > -kYR) ? (int)((y1 + kYR) * yscale) : 0;
-                b0 = (b0 < nb && y0 < kYR) ? b0 : nb - 1;
-                b1 = (b1 < nb && y1 < kYR) ? b1 : nb - 1;
+                const int b0 = slice_of(y0), b1 = slice_of(y1);
                 int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
                 // The first two probes go to the two ends of the bracket, then it is bisected: a bracket
                 // of one or two thresholds costs what it did, and a bracket full of EQUAL thresholds -- the
