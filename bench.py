@@ -282,7 +282,7 @@ def main():
         if fdr_times:  # detect.py:132-135; null draws keyed by the GLOBAL base index
             sc.fdr_dev(n_iv, p_out, p_out + 2 * t8, p_track, times=fdr_times, seed=1, half_win_width=scales[0],
                        interval_off_dev=d_off.ptr, base_index0=bases_before, dm_ids_dev=d_dm.ptr if d_dm else None,
-                       obs=p_out + t8)
+                       obs=p_out + t8, interval_off_host=off)
 
     def sync():
         ctx.synchronize()
@@ -476,7 +476,7 @@ def main():
                         dm_ids_dev=d_dm.ptr if d_dm else None)
             sc.fdr_dev(n_iv, p_exp + d_ * row, p_out + 2 * t8, p_fdr + d_ * row, times=fdr_times, seed=1 + d_,
                        half_win_width=scales[0], interval_off_dev=d_off.ptr, base_index0=bases_before,
-                       dm_ids_dev=d_dm.ptr if d_dm else None, obs=p_obs + d_ * row)
+                       dm_ids_dev=d_dm.ptr if d_dm else None, obs=p_obs + d_ * row, interval_off_host=off)
             _lib.check(ctx.L.fpt_memcpy_h2d(ctx.h, p_w + d_ * row, ones.ctypes.data, ones.nbytes))
         ctx.synchronize()
         # dataset d is scored with model d % n_models (the reference has one model per dataset)

@@ -75,6 +75,7 @@ class FdrDesc(C.Structure):
         ("null_uniform", C.c_void_p),
         ("null_winp_out", C.c_void_p),
         ("obs", C.c_void_p),
+        ("interval_off_host", C.c_void_p),
     ]
 
 

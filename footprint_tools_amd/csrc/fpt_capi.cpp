@@ -52,6 +52,10 @@ struct fpt_ctx {
     unsigned long long *d_sum = nullptr;
     bool have_table = false;
     bool have_model[FPT_MAX_DISPERSION_MODELS] = {};
+    int32_t *pin_list = nullptr;  // pinned staging of fpt_fdr_dev's interval lists, and the event behind its last copy
+    size_t pin_list_bytes = 0;
+    hipEvent_t pin_list_copied = nullptr;
+    bool pin_list_busy = false;
     void *ws[kSlots] = {};
     size_t ws_bytes[kSlots] = {};
     uint64_t ws_gen[kSlots] = {};  // counts the (re)allocations of a slot: its contents are gone after one
@@ -240,6 +244,8 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_sum) (void)hipFree(c->d_sum);
+    if (c->pin_list) (void)hipHostFree(c->pin_list);
+    if (c->pin_list_copied) (void)hipEventDestroy(c->pin_list_copied);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
@@ -830,26 +836,51 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         while (cls_len[k] < L) ++k;
         return k;
     };
-    std::vector<int32_t> cls_list[kClasses], longs;
+    // ragged batches: the intervals of every size class (the last: the long ones) listed back to
+    // back in a pinned buffer the context keeps -- counted, then placed: no growing vectors, one
+    // copy to the device that needs no wait
+    int64_t cls_n[kClasses + 1] = {}, cls_at[kClasses + 2] = {};
     if (d->interval_off) {
         if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
-        // interval lengths: the offsets live on the device, so take them back once
-        std::vector<int64_t> off((size_t)d->n_intervals + 1);
-        HIP_TRY(hipMemcpyAsync(off.data(), d->interval_off, off.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // interval lengths: from the caller's host copy of the offsets, else back from the device
+        const int64_t *off = d->interval_off_host;
+        std::vector<int64_t> off_back;
+        if (!off) {
+            off_back.resize((size_t)d->n_intervals + 1);
+            HIP_TRY(hipMemcpyAsync(off_back.data(), d->interval_off, off_back.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            off = off_back.data();
+        }
         lmax = 0;
+        std::vector<uint8_t> cls((size_t)d->n_intervals);
         for (int64_t i = 0; i < d->n_intervals; ++i) {
-            int64_t L = off[i + 1] - off[i];
+            const int64_t L = off[i + 1] - off[i];
             if (L < 0) return fail(FPT_ERR_INVALID, "bad interval offsets");
             if (L > kLongMax)
                 return fail(FPT_ERR_INVALID, "interval of %lld bases: fpt_fdr_dev handles at most %d", (long long)L, kLongMax);
             if (L > lmax) lmax = (int)L;
-            if (L > kLdsMax) {
-                longs.push_back((int32_t)i);
-            } else {
-                cls_list[cls_of((int)L)].push_back((int32_t)i);
-            }
+            const int k = L > kLdsMax ? kClasses : cls_of((int)L);
+            cls[(size_t)i] = (uint8_t)k;
+            cls_n[k] += 1;
         }
+        for (int k = 0; k <= kClasses; ++k) cls_at[k + 1] = cls_at[k] + cls_n[k];
+        const size_t need = (size_t)d->n_intervals * sizeof(int32_t);
+        if (c->pin_list_busy) {  // the copy of the call before has long happened; make sure
+            HIP_TRY(hipEventSynchronize(c->pin_list_copied));
+            c->pin_list_busy = false;
+        }
+        if (c->pin_list_bytes < need) {
+            if (c->pin_list) (void)hipHostFree(c->pin_list);
+            c->pin_list = nullptr;
+            c->pin_list_bytes = 0;
+            const size_t want = need + need / 4;
+            if (hipHostMalloc((void **)&c->pin_list, want, hipHostMallocDefault) != hipSuccess)
+                return fail(FPT_ERR_NOMEM, "no pinned host memory for %zu bytes of interval lists", want);
+            c->pin_list_bytes = want;
+        }
+        int64_t cur[kClasses + 1];
+        for (int k = 0; k <= kClasses; ++k) cur[k] = cls_at[k];
+        for (int64_t i = 0; i < d->n_intervals; ++i) c->pin_list[cur[cls[(size_t)i]]++] = (int32_t)i;
     } else if (lmax <= 0) {
         return fail(FPT_ERR_INVALID, "interval_len must be positive");
     } else if (lmax > kLongMax) {
@@ -909,35 +940,25 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         HIP_TRY(fptk::launch_fdr(c->stream, fl));
         return launch_ok("k_fdr_null");
     }
-    // ragged batch: one interval list per size class on the device
-    size_t n_listed = longs.size();
-    for (int k = 0; k < kClasses; ++k) n_listed += cls_list[k].size();
+    // ragged batch: the lists to the device in one copy (pinned: it is queued, nobody waits)
     void *d_list;
-    if (int rc = ws_get(c, 5, std::max<size_t>(n_listed, 1) * sizeof(int32_t), &d_list)) return rc;
-    int32_t *cursor = (int32_t *)d_list;
-    const int32_t *d_cls[kClasses], *d_long = nullptr;
+    if (int rc = ws_get(c, 5, (size_t)d->n_intervals * sizeof(int32_t), &d_list)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_list, c->pin_list, (size_t)d->n_intervals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (!c->pin_list_copied) HIP_TRY(hipEventCreateWithFlags(&c->pin_list_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->pin_list_copied, c->stream));
+    c->pin_list_busy = true;
+    const int32_t *lists = (const int32_t *)d_list;
     for (int k = 0; k < kClasses; ++k) {
-        d_cls[k] = cursor;
-        if (!cls_list[k].empty())
-            HIP_TRY(hipMemcpyAsync(cursor, cls_list[k].data(), cls_list[k].size() * 4, hipMemcpyHostToDevice, c->stream));
-        cursor += cls_list[k].size();
-    }
-    if (!longs.empty()) {
-        d_long = cursor;
-        HIP_TRY(hipMemcpyAsync(cursor, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the lists are pageable host memory
-    for (int k = 0; k < kClasses; ++k) {
-        if (cls_list[k].empty()) continue;
+        if (cls_n[k] == 0) continue;
         fl.n2_max = cls_n2[k];
         fl.nt = cls_nt[k];
         fl.max_len = cls_len[k];
-        fl.iv_list = d_cls[k];
-        fl.n_list = (int64_t)cls_list[k].size();
+        fl.iv_list = lists + cls_at[k];
+        fl.n_list = cls_n[k];
         HIP_TRY(fptk::launch_fdr(c->stream, fl));
         if (int rc = launch_ok("k_fdr_null")) return rc;
     }
-    if (!longs.empty()) return launch_long(d_long, (int64_t)longs.size());
+    if (cls_n[kClasses]) return launch_long(lists + cls_at[kClasses], cls_n[kClasses]);
     return FPT_OK;
 }
 

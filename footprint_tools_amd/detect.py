@@ -143,7 +143,8 @@ class deviation_stats(object):
                     sc.fdr_dev(b - a, d_out.ptr + int(off[a]) * 8, d_out.ptr + 3 * t8 + int(off[a]) * 8,
                                d_out.ptr + (3 + S) * t8 + int(off[a]) * 8, times=self.fdr_shuffle_n, seed=self.seed,
                                half_win_width=3, interval_off_dev=d_roff.ptr,
-                               base_index0=int(self._bases_before[indices[a]]), obs=d_out.ptr + t8 + int(off[a]) * 8)
+                               base_index0=int(self._bases_before[indices[a]]), obs=d_out.ptr + t8 + int(off[a]) * 8,
+                               interval_off_host=roff)
             if self.dm:
                 # the five record columns (detect.py:142-144, and the fallback rows of :136-140)
                 # assembled on the device: one download of the (bases, 5) matrix

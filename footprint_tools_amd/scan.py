@@ -245,10 +245,11 @@ class FootprintScanner(object):
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
     def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,
                 interval_len=None, interval_off_dev=None, base_index0=0, null_uniform=None, dm_ids_dev=None,
-                null_winp_out=None, obs=None):
+                null_winp_out=None, obs=None, interval_off_host=None):
         """Enqueue the null sampling + ranking on device pointers; does not synchronise.
         obs: the observed counts track (device pointer): ties between null and observed windows
-        are then decided exactly, as in the reference (see fpt_fdr_desc.obs)."""
+        are then decided exactly, as in the reference (see fpt_fdr_desc.obs).  interval_off_host:
+        the offsets once more as a host int64 array (saves their way back from the device)."""
         ctx = self.ctx
         d = _lib.FdrDesc()
         d.n_intervals = int(n_intervals)
@@ -261,10 +262,16 @@ class FootprintScanner(object):
         d.exp, d.winp, d.efdr_out, d.null_uniform = exp, winp, efdr_out, null_uniform
         d.null_winp_out = null_winp_out
         d.obs = obs
-        _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))
+        off_h = None
+        if interval_off_host is not None and interval_off_dev is not None:
+            off_h = np.ascontiguousarray(interval_off_host, dtype=np.int64)
+            if off_h.size != int(n_intervals) + 1:
+                raise ValueError("interval_off_host must hold n_intervals + 1 offsets")
+            d.interval_off_host = off_h.ctypes.data
+        _lib.check(ctx.L.fpt_fdr_dev(ctx.h, C.byref(d)))  # (off_h is read before the call returns)
 
     def fdr(self, exp, winp, times=100, seed=0, half_win_width=3, interval_len=None, interval_off=None,
-            base_index0=0, null_uniform=None, dm_ids=None, return_null=False, obs=None):
+            base_index0=0, null_uniform=None, dm_ids=None, return_null=False, obs=None, host_offsets=True):
         """Empirical FDR of observed window p-values (host arrays in / out).  return_null=True
         also returns the (total_bases, times) null window p-values (detect.py:133).  obs: the
         observed counts the p-values were made from (exact ties, see fdr_dev)."""
@@ -306,7 +313,8 @@ class FootprintScanner(object):
                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
                          base_index0=base_index0, null_uniform=d_u.ptr if d_u else None,
                          dm_ids_dev=d_dm.ptr if d_dm else None, null_winp_out=d_n.ptr if d_n else None,
-                         obs=d_obs.ptr if d_obs else None)
+                         obs=d_obs.ptr if d_obs else None,
+                         interval_off_host=off if host_offsets else None)  # (False: the call fetches them back itself)
             ctx.synchronize()
             ef = d_o.download(np.float64, total)
             if d_n:

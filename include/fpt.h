@@ -245,6 +245,10 @@ typedef struct fpt_fdr_desc {
                                        * Without it observed values are ranked as given, and such ties -- a
                                        * large share of the null for sparse counts -- fall either way by the
                                        * rounding of whatever made `winp`. */
+    const int64_t *interval_off_host; /* optional HOST copy of interval_off (like fpt_scan_desc's): the
+                                       * launches are sized from the interval lengths, and without it the
+                                       * offsets come back from the device first -- a copy and a wait for
+                                       * everything queued on the stream */
 } fpt_fdr_desc;
 
 /* Enqueue the null sampling + ranking on the context's stream (no synchronisation).

@@ -13,6 +13,7 @@ from footprint_tools_amd.scan import DeviceArray, FootprintScanner  # noqa: E402
 
 n_iv = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 NO_OBS = len(sys.argv) > 3 and sys.argv[3] == "noobs"  # the observed windows taken from the p-value track
+NO_HOST_OFF = len(sys.argv) > 3 and sys.argv[3] == "nohostoff"  # the offsets fetched back from the device by the call
 g = np.load("tests/golden/kmer_probs.npz")
 lat = np.load("tests/golden/nb_lattice.npz")
 
@@ -39,7 +40,7 @@ ctx.synchronize()
 for times in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4, 52, 100)):
     def step():
         sc.fdr_dev(n_iv, d_out.ptr, d_out.ptr + 3 * t8, d_out.ptr + 4 * t8, times=times, seed=1, interval_off_dev=d_off.ptr,
-                   obs=None if NO_OBS else d_out.ptr + t8)
+                   obs=None if NO_OBS else d_out.ptr + t8, interval_off_host=None if NO_HOST_OFF else off)
     step()
     ctx.synchronize()
     t0 = time.perf_counter()

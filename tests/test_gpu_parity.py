@@ -1741,6 +1741,9 @@ def test_fdr_long_intervals(fpt, orc):
     winp = rs.uniform(0, 1, off[-1]) ** 2
     winp[off[1] + 17] = np.nan
     ef, nul = sc.fdr(exp, winp, times=times, seed=5, interval_off=off, base_index0=77, return_null=True)
+    # (the interval lists are made from the caller's host copy of the offsets, or from the device's)
+    ef_dev_off = sc.fdr(exp, winp, times=times, seed=5, interval_off=off, base_index0=77, host_offsets=False)
+    assert np.array_equal(ef, ef_dev_off, equal_nan=True)
     for a, b in zip(off[:-1], off[1:]):
         want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[a:b], winp[a:b], 3, times, seed=5, base0=77 + a,
                                 return_null=True)
