@@ -52,6 +52,10 @@ struct fpt_ctx {
     unsigned long long *d_sum = nullptr;
     bool have_table = false;
     bool have_model[FPT_MAX_DISPERSION_MODELS] = {};
+    int32_t *pin_plan = nullptr;  // pinned staging of fpt_scan_dev's per-block class offsets (ragged batches), likewise
+    size_t pin_plan_bytes = 0;
+    hipEvent_t pin_plan_copied = nullptr;
+    bool pin_plan_busy = false;
     int32_t *pin_list = nullptr;  // pinned staging of fpt_fdr_dev's interval lists, and the event behind its last copy
     size_t pin_list_bytes = 0;
     hipEvent_t pin_list_copied = nullptr;
@@ -94,10 +98,8 @@ struct fpt_ctx {
     int64_t seg_n_intervals = -1, seg_total = 0;
     const double *seg_track = nullptr;
     // tile-table cache of the last ragged batch (reused while the offsets and geometry match)
-    std::vector<int64_t> plan_off;
-    int plan_H = -1;
     int64_t plan_tiles = 0;
-    int plan_max_len = 0;  // longest interval of the cached ragged plan
+    int plan_max_len = 0;  // longest interval of the ragged batch in hand
     std::vector<double> beta_host;  // fpt_posterior_dev: source of its asynchronous upload
     int64_t plan_cls_count[fptk::kLeanClasses] = {};  // tiles per workgroup-size class, in table order
     int64_t last_tiles = 0;      // tiles of the most recent memo-mode scan (fpt_scan_stats)
@@ -244,6 +246,8 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_sum) (void)hipFree(c->d_sum);
+    if (c->pin_plan) (void)hipHostFree(c->pin_plan);
+    if (c->pin_plan_copied) (void)hipEventDestroy(c->pin_plan_copied);
     if (c->pin_list) (void)hipHostFree(c->pin_list);
     if (c->pin_list_copied) (void)hipEventDestroy(c->pin_list_copied);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -556,67 +560,79 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             off = off_host.data();
         }
         if (d->n_intervals > 0x7fffffff) return fail(FPT_ERR_INVALID, "too many intervals");
-        const size_t n_off = (size_t)d->n_intervals + 1;
-        const bool cached = c->plan_H == H && c->plan_off.size() == n_off && c->ws[9] != nullptr &&
-                            std::memcmp(c->plan_off.data(), off, n_off * sizeof(int64_t)) == 0;
-        if (!cached) {
-            constexpr int NC = fptk::kLeanClasses;
-            std::vector<int32_t> tiv[NC], tt0[NC], ttl[NC];
-            int max_len = 0;
-            for (int64_t i = 0; i < d->n_intervals; ++i) {
-                int64_t L64 = off[i + 1] - off[i];
-                if (L64 < 0 || L64 > 0x3fffffff) return fail(FPT_ERR_INVALID, "bad interval offsets");
-                int L = (int)L64;
+        // one pass over the lengths: tiles per workgroup-size class (the grid sizes), where every
+        // kPlanBlock intervals start inside each class, and the longest interval; the table itself is
+        // made on the device (k_plan_tiles) -- a few KB are copied, nobody waits, and a job whose
+        // batches all differ pays ~1 ns per interval here
+        constexpr int NC = fptk::kLeanClasses, PB = fptk::kPlanBlock;
+        if (1024 - H <= fptk::kLeanNT[NC - 2]) return fail(FPT_ERR_INVALID, "Stouffer half-width %d too large", H);
+        const int64_t n_blocks = (d->n_intervals + PB - 1) / PB;
+        const size_t stage_bytes = (size_t)std::max<int64_t>(n_blocks, 1) * NC * sizeof(int32_t);
+        if (c->pin_plan_busy) {  // (the copy of the call before has long happened)
+            HIP_TRY(hipEventSynchronize(c->pin_plan_copied));
+            c->pin_plan_busy = false;
+        }
+        if (c->pin_plan_bytes < stage_bytes) {
+            if (c->pin_plan) (void)hipHostFree(c->pin_plan);
+            c->pin_plan = nullptr;
+            c->pin_plan_bytes = 0;
+            const size_t want = stage_bytes + stage_bytes / 4;
+            if (hipHostMalloc((void **)&c->pin_plan, want, hipHostMallocDefault) != hipSuccess)
+                return fail(FPT_ERR_NOMEM, "no pinned host memory for %zu bytes of the tile plan", want);
+            c->pin_plan_bytes = want;
+        }
+        int64_t cls_count[NC] = {};
+        int max_len = 0;
+        bool bad_off = false;
+        for (int64_t blk = 0; blk < n_blocks; ++blk) {
+            int32_t *snap = c->pin_plan + blk * NC;
+            for (int cls = 0; cls < NC; ++cls) snap[cls] = (int32_t)std::min<int64_t>(cls_count[cls], 0x7fffffff);
+            const int64_t i1 = std::min<int64_t>((blk + 1) * PB, d->n_intervals);
+            for (int64_t i = blk * PB; i < i1; ++i) {
+                const int64_t L64 = off[i + 1] - off[i];
+                bad_off |= L64 < 0 || L64 > 0x3fffffff;
+                const int L = (int)L64;
                 max_len = std::max(max_len, L);
-                if (L == 0) continue;
-                if (L <= 1024) {
-                    int cls = lean_class(L);
-                    tiv[cls].push_back((int32_t)i);
-                    tt0[cls].push_back(0);
-                    ttl[cls].push_back(L);
-                } else {
-                    for (int t0 = 0; t0 < L; t0 += split_len) {
-                        int tl = std::min(split_len, L - t0);
-                        int ta = std::max(0, t0 - H), tb = std::min(L, t0 + tl + H);
-                        int n = tb - ta;
-                        int cls = lean_class(n);
-                        tiv[cls].push_back((int32_t)i);
-                        tt0[cls].push_back(t0);
-                        ttl[cls].push_back(tl);
-                    }
+                if (L > 1024 && !bad_off) {  // pieces of split_len bases, all but the last in the top class
+                    const int n_full = (L - 1) / split_len;
+                    cls_count[NC - 1] += n_full;
+                    cls_count[lean_class(L - n_full * split_len + H)] += 1;
+                } else {  // (no branch on the length: the lengths of a real batch are not predictable)
+                    int k = 0;
+                    for (int q = 0; q < NC - 1; ++q) k += fptk::kLeanNT[q] < L ? 1 : 0;
+                    cls_count[k] += L > 0 ? 1 : 0;
                 }
             }
-            std::vector<int32_t> flat;
-            int64_t n_tiles = 0;
-            for (int cls = 0; cls < NC; ++cls) n_tiles += (int64_t)tiv[cls].size();
-            flat.reserve((size_t)n_tiles * 3);
-            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tiv[cls].begin(), tiv[cls].end());
-            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), tt0[cls].begin(), tt0[cls].end());
-            for (int cls = 0; cls < NC; ++cls) flat.insert(flat.end(), ttl[cls].begin(), ttl[cls].end());
-            // the same tiles as 32-byte records for the lean kernel (interval offset and length included:
-            // one scalar load instead of two dependent ones)
-            std::vector<fptk::lean_tile_rec> recs((size_t)n_tiles);
-            for (int64_t t = 0; t < n_tiles; ++t) {
-                const int32_t iv = flat[(size_t)t];
-                recs[(size_t)t] = fptk::lean_tile_rec{off[iv], iv, flat[(size_t)(n_tiles + t)], flat[(size_t)(2 * n_tiles + t)],
-                                                       (int32_t)(off[iv + 1] - off[iv]), {0, 0}};
-            }
-            void *d_new, *d_recs;
-            c->plan_H = -1;  // invalid while the table is being replaced
-            if (int rc = ws_get(c, 9, flat.size() * 4, &d_new)) return rc;
-            if (int rc = ws_get(c, 12, recs.size() * sizeof(fptk::lean_tile_rec), &d_recs)) return rc;
-            if (!flat.empty()) {
-                HIP_TRY(hipMemcpyAsync(d_new, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(fptk::lean_tile_rec), hipMemcpyHostToDevice,
-                                       c->stream));
-            }
-            HIP_TRY(hipStreamSynchronize(c->stream));  // the staging vectors are pageable host memory
-            c->plan_off.assign(off, off + n_off);
-            c->plan_tiles = n_tiles;
-            c->plan_max_len = max_len;
-            for (int cls = 0; cls < NC; ++cls) c->plan_cls_count[cls] = (int64_t)tiv[cls].size();
-            c->plan_H = H;
         }
+        if (bad_off) return fail(FPT_ERR_INVALID, "bad interval offsets");
+        int64_t n_tiles = 0;
+        for (int cls = 0; cls < NC; ++cls) n_tiles += cls_count[cls];
+        if (n_tiles > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many tiles");
+        // block_base: class-major table -> add where each class starts
+        {
+            int64_t at = 0;
+            for (int cls = 0; cls < NC; ++cls) {
+                if (at)
+                    for (int64_t blk = 0; blk < n_blocks; ++blk) c->pin_plan[blk * NC + cls] += (int32_t)at;
+                at += cls_count[cls];
+            }
+        }
+        void *d_flat, *d_recs;
+        if (int rc = ws_get(c, 9, ((size_t)n_tiles * 3 + 16) * 4 + stage_bytes, &d_flat)) return rc;
+        if (int rc = ws_get(c, 12, std::max<size_t>((size_t)n_tiles, 1) * sizeof(fptk::lean_tile_rec), &d_recs)) return rc;
+        int32_t *d_base = (int32_t *)d_flat + (size_t)n_tiles * 3 + 16;
+        if (n_tiles > 0) {
+            HIP_TRY(hipMemcpyAsync(d_base, c->pin_plan, stage_bytes, hipMemcpyHostToDevice, c->stream));
+            if (!c->pin_plan_copied) HIP_TRY(hipEventCreateWithFlags(&c->pin_plan_copied, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->pin_plan_copied, c->stream));
+            c->pin_plan_busy = true;
+            fptk::launch_plan_tiles(c->stream, d->interval_off, d->n_intervals, n_tiles, H, split_len, d_base, (int32_t *)d_flat,
+                                    d_recs);
+            if (int rc = launch_ok("k_plan_tiles")) return rc;
+        }
+        c->plan_tiles = n_tiles;
+        c->plan_max_len = max_len;
+        for (int cls = 0; cls < NC; ++cls) c->plan_cls_count[cls] = cls_count[cls];
         sl.total_bases = off[d->n_intervals];
         sl.interval_off = d->interval_off;
         sl.tile_iv = (const int32_t *)c->ws[9];

@@ -2498,6 +2498,97 @@ void launch_nb_memo2(hipStream_t st, const double *models, int n_models, const i
                        rows, stride, (double2 *)memo2);
 }
 
+// ---- the tile table of a ragged batch, made on the device (fpt_scan_dev).  One lane per interval,
+// kPlanBlock intervals per workgroup: an interval of up to 1,024 bases is one tile, a longer one is
+// cut every split_len bases (each piece read with a halo of H); a tile goes to the workgroup-size
+// class that holds it.  The table is class-major, intervals in their order inside a class: the host
+// has counted the tiles of every class (it needs them for the grid sizes) and, on the way, where each
+// workgroup's intervals start inside every class (`block_base`, kLeanClasses ints per workgroup); the
+// places inside a workgroup come from seven small prefix sums.  (The table used to be made on the
+// host -- 27 growing vectors, 19 MB of pageable copies and a wait: 4.4 ms per call on the
+// whole-genome shape, whose kernels take 1.8, whenever a call's offsets differed from the last one's.
+// One atomic per class and wavefront instead of the prefix sums: 0.44 ms of contention.)
+struct plan_args {
+    const int64_t *off;
+    int64_t n_intervals, n_tiles;
+    int32_t H, split_len;
+    const int32_t *block_base;
+    int32_t *tile_iv, *tile_t0, *tile_tl;
+    lean_tile_rec *recs;
+};
+__host__ __device__ __forceinline__ int plan_class_of(int n) {  // the first class whose lanes hold n positions
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < kLeanClasses - 1; ++i) k += kLeanNT[i] < n ? 1 : 0;
+    return k;
+}
+__global__ void __launch_bounds__(kPlanBlock) k_plan_tiles(const plan_args a) {
+    __shared__ int wave_total[kPlanBlock / 64][kLeanClasses];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kPlanBlock + tid;
+    int L = 0;
+    int64_t o = 0;
+    if (i < a.n_intervals) {
+        o = a.off[i];
+        L = (int)(a.off[i + 1] - o);
+    }
+    // this interval's tiles: n_full pieces of split_len bases (the top class: split_len + H > 768
+    // positions with their halo) and a last -- or only -- one
+    constexpr int kTop = kLeanClasses - 1;
+    int n_full = 0, last_t0 = 0, last_cls = -1;
+    if (L > 1024) {
+        n_full = (L - 1) / a.split_len;
+        last_t0 = n_full * a.split_len;
+        last_cls = plan_class_of(L - last_t0 + a.H);
+    } else if (L > 0) {
+        last_cls = plan_class_of(L);
+    }
+    int mine[kLeanClasses];  // where this lane's tiles of a class start
+#pragma unroll
+    for (int c = 0; c < kLeanClasses; ++c) {
+        const int v = (c == kTop ? n_full : 0) + (last_cls == c ? 1 : 0);
+        const int incl = wave_scan_i32(v);
+        if (lane == 63) wave_total[wave][c] = incl;
+        mine[c] = incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kLeanClasses; ++c) {
+        int before = a.block_base[(int64_t)blockIdx.x * kLeanClasses + c];
+        for (int w = 0; w < wave; ++w) before += wave_total[w][c];
+        mine[c] += before;
+    }
+    auto put = [&](int slot, int t0, int tl) {
+        a.tile_iv[slot] = (int32_t)i;
+        a.tile_t0[slot] = t0;
+        a.tile_tl[slot] = tl;
+        a.recs[slot] = lean_tile_rec{o, (int32_t)i, t0, tl, L, {0, 0}};
+    };
+    for (int p = 0; p < n_full; ++p) put(mine[kTop] + p, p * a.split_len, a.split_len);
+    if (last_cls >= 0) {
+        int slot = mine[0];
+#pragma unroll
+        for (int c = 1; c < kLeanClasses; ++c) slot = last_cls == c ? mine[c] : slot;
+        put(slot + (last_cls == kTop ? n_full : 0), last_t0, L - last_t0);
+    }
+}
+
+void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, int64_t n_tiles, int H, int split_len,
+                       const int32_t *block_base, int32_t *flat, void *recs) {
+    plan_args a;
+    a.off = off;
+    a.n_intervals = n_intervals;
+    a.n_tiles = n_tiles;
+    a.H = H;
+    a.split_len = split_len;
+    a.block_base = block_base;
+    a.tile_iv = flat;
+    a.tile_t0 = flat + n_tiles;
+    a.tile_tl = flat + 2 * n_tiles;
+    a.recs = (lean_tile_rec *)recs;
+    hipLaunchKernelGGL(k_plan_tiles, dim3((unsigned)((n_intervals + kPlanBlock - 1) / kPlanBlock)), dim3(kPlanBlock), 0, st, a);
+}
+
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {
     hipLaunchKernelGGL(k_nb_guide, dim3((memo_exp * kGuide + 255) / 256, n_models), dim3(256), 0, st,
                        (const double2 *)memo, memo_exp, memo_obs, (uint16_t *)guide);

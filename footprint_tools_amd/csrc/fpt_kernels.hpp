@@ -131,6 +131,12 @@ struct segment_launch {
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
 size_t fdr_lds_bytes(int n2, bool dbuf = false);
 void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide);
+// the tile table of a ragged batch (three int32 arrays of n_tiles in `flat`, 32-byte records in `recs`)
+// from the device offsets: class-major, intervals in order.  block_base (device): for every
+// kPlanBlock intervals and class, the table index of the first tile of the block's first interval.
+constexpr int kPlanBlock = 256;
+void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, int64_t n_tiles, int H, int split_len,
+                       const int32_t *block_base, int32_t *flat, void *recs);
 size_t nb_guide_bytes(int n_models, int memo_exp);
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,

@@ -463,6 +463,9 @@ def test_fused_scan_ragged(fpt, orc):
     rs = np.random.RandomState(4)
     lens = np.concatenate([[50, 1, 2000, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 3100],
                            np.clip(rs.lognormal(5.0, 0.6, 40).astype(int), 50, 2000)])
+    # (the tile table is made on the device, 256 intervals per workgroup: several workgroups' worth,
+    # every class and a few long intervals in each)
+    lens = np.concatenate([lens] + [rs.permutation(lens) for _ in range(13)] + [[0, 0, 5000, 1, 0]])
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     pad = hw + shw
     cps, cms, sqs, exp_l, obs_l, p_l, w_l = [], [], [], [], [], [], []
@@ -472,9 +475,11 @@ def test_fused_scan_ragged(fpt, orc):
         cp, cm = orc.synth_counts(9, pos, l, 0), orc.synth_counts(9, pos, l, 1)
         sq = orc.synth_bases(9, pos, l + 6)
         pos += l + 6
+        cps.append(cp); cms.append(cm); sqs.append(sq)
+        if L == 0:  # an empty interval: its padded inputs are there, it has no output
+            continue
         e, o, p, wp = orc.detect_batch(cp, cm, sq, 1, int(L), hw, shw, clip, table, lat["mu_A"], lat["r_A"],
                                        np.array(scales, np.int32))
-        cps.append(cp); cms.append(cm); sqs.append(sq)
         exp_l.append(e); obs_l.append(o); p_l.append(p); w_l.append(wp)
     sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), hw, shw, clip, scales)
     out = sc.scan(np.concatenate(cps), np.concatenate(cms), np.concatenate(sqs), interval_off=off)
