@@ -136,7 +136,9 @@ typedef struct fpt_scan_desc {
     int64_t n_intervals;
     /* uniform batches: every interval has `interval_len` bases and interval_off == NULL.
      * ragged batches: interval_off (DEVICE, n_intervals+1 int64) are offsets into the output
-     * tracks, interval_off_host the same array on the HOST (used to build the tile table). */
+     * tracks, interval_off_host the same array on the HOST (the launches are sized from the interval
+     * lengths; NULL: the offsets come back from the device first, behind a wait for the stream).  The
+     * tile table itself is made on the device in every call: nothing is kept between calls. */
     int32_t interval_len;
     const int64_t *interval_off;
     const int64_t *interval_off_host;
