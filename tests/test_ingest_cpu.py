@@ -318,7 +318,12 @@ def test_track_reader_region_access(tmp_path, form, monkeypatch):
     # batched, on one thread and on a team
     ivs = [(c, int(a), int(a + l)) for c, a, l in zip(rs.choice(["chr1", "chr2", "chrX", "chrM"], 400),
                                                       rs.randint(0, 45000, 400), rs.randint(1, 600, 400))]
-    for nt in ("1", "7"):
+    # ... in any order, and sorted (neighbours are then read in one walk from where the last one stopped:
+    # abutting, overlapping, nested, far apart, a change of chromosome)
+    walk = sorted(ivs) + [("chr2", a, a + 37) for a in range(100, 3000, 37)] + [("chr2", 2990, 3500), ("chr2", 3000, 3010),
+                                                                               ("chr2", 3010, 3010), ("chr2", 20000, 20100),
+                                                                               ("chrX", 5, 90), ("chrX", 90, 300)]
+    for nt, ivs in (("1", ivs), ("7", ivs), ("1", walk), ("5", walk)):
         monkeypatch.setenv("FPT_TRACK_THREADS", nt)
         tb2 = TabixFile(path)
         out, present, off = tb2.fetch_batch([c for c, _, _ in ivs], [a for _, a, _ in ivs], [b for _, _, b in ivs], [3, 4, 7])
