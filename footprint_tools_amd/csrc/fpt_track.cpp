@@ -11,7 +11,9 @@
 //   * a batch of intervals is served by a team of threads, each walking its share of the (sorted or
 //     not) interval list with a cache of the members it inflated last, parsing only the columns
 //     asked for, and scattering the values into the caller's (bases) arrays -- what `_load_data`
-//     does row by row in Python.
+//     does row by row in Python.  Where an interval starts at or a little beyond the row its
+//     predecessor stopped at, the thread reads on from there instead of going through the index
+//     (a sorted interval list is then one walk over the file per thread);
 // Rows are selected by their start column: start <= row start < end (the rows of a `detect` track
 // are one base wide, so this is tabix's overlap rule for them).
 //
