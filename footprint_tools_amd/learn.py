@@ -42,8 +42,18 @@ class expected_counts(object):
                 np.frombuffer(bytes(seq), dtype=np.uint8))
 
     def _upload(self, indices):
-        ivs = [self.intervals[i] for i in indices]
-        lens = np.array([iv.end - iv.start for iv in ivs], dtype=np.int64)
+        from .cutcounts import bamfile
+        from .fasta import FastaFile
+        from .intervals import interval_columns
+        if isinstance(indices, range) and indices.step == 1 and 0 <= indices.start <= indices.stop <= len(self.intervals):
+            ivs = self.intervals[indices.start:indices.stop]
+        else:
+            indices = list(indices)
+            ivs = [self.intervals[i] for i in indices]
+        if getattr(self, "_cols", None) is None:  # the interval list as columns, read off the objects once
+            self._cols = interval_columns.of(self.intervals)
+        cols = self._cols.take(indices)
+        lens = cols.end - cols.start
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         ctx = self._sc.ctx
         if (hasattr(self.read_func, "cut_counts_dev") and hasattr(self.fasta_func, "fetch_batch")
@@ -52,9 +62,16 @@ class expected_counts(object):
             # from the alignments held there, no round trip per interval (see detect.deviation_stats)
             if getattr(self.read_func, "_ctx", None) is None:
                 self.read_func._ctx = ctx
-            d_cp, d_cm = self.read_func.cut_counts_dev(ivs, self.padding)
+            d_cp, d_cm = self.read_func.cut_counts_dev(cols if isinstance(self.read_func, bamfile) else ivs, self.padding)
+            want = int(off[-1]) + len(ivs) * (2 * self.padding + 7)
+            if isinstance(self.fasta_func, FastaFile):  # the FASTA bytes live on the device too
+                d_sq, n_sq = self.fasta_func.fetch_batch_dev(ctx, cols, self.padding)
+                if n_sq != want:
+                    raise ValueError("fasta_func returned sequence of the wrong length")
+                return off, [d_cp, d_cm, d_sq, DeviceArray(ctx, off.nbytes).upload(off),
+                             DeviceArray(ctx, max(2 * int(off[-1]) * 8, 16))]
             sq = self.fasta_func.fetch_batch(ivs, self.padding)
-            if sq.size != int(off[-1]) + len(ivs) * (2 * self.padding + 7):
+            if sq.size != want:
                 raise ValueError("fasta_func returned sequence of the wrong length")
         else:
             cps, cms, sqs = zip(*(self._fetch(iv) for iv in ivs))
@@ -74,8 +91,9 @@ class expected_counts(object):
 
     def compute(self, indices):
         """[column_stack((exp, obs)) for each interval] -- what the reference's dataset yields"""
-        indices = list(indices)
-        if not indices:
+        if not isinstance(indices, range):
+            indices = list(indices)
+        if len(indices) == 0:
             return []
         off, bufs = self._upload(indices)
         try:
