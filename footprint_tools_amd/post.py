@@ -86,3 +86,14 @@ class posterior_stats(object):
 
     def __getitem__(self, index):
         return self.batch([index])[0]
+
+    def batch_iter(self, batch_size=4096):
+        """{"interval": [...], "stats": [...]} per step, like the reference's loader (cli/post.py:160-175),
+        plus the step's rows as one matrix ("table", "row_off") for detect.write_batch_to_output"""
+        for a in range(0, len(self.intervals), int(batch_size)):
+            ivs = self.intervals[a:a + int(batch_size)]
+            obs, exp, fdr, w, off = self.load_batch(ivs)
+            table = posterior.posterior_batch(obs, exp, fdr, w, self.betas, self.disp_models, fdr_cutoff=self.fdr_cutoff,
+                                              half_win_width=3, interval_off=off, ctx=self.ctx)
+            o = off.tolist()
+            yield {"interval": ivs, "stats": [table[x:y] for x, y in zip(o[:-1], o[1:])], "table": table, "row_off": off}

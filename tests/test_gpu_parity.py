@@ -1606,6 +1606,20 @@ def test_posterior_driver_from_tracks(fpt, tmp_path):
     for i in (1, 2, 3):
         assert np.array_equal(recs[i]["stats"], ps2[i]["stats"], equal_nan=True)
     assert recs[3]["stats"].shape == (45, 2) and not recs[3]["stats"].any()
+    # ... and the loader's steps, whose rows write_batch_to_output formats in one call
+    import io
+    from footprint_tools_amd import detect
+    steps = list(ps2.batch_iter(batch_size=3))
+    assert [len(b["interval"]) for b in steps] == [3, 1] and steps[0]["table"].shape == (steps[0]["row_off"][-1], 2)
+    for b, base in zip(steps, (0, 3)):
+        for k, st in enumerate(b["stats"]):
+            assert np.array_equal(st, recs[base + k]["stats"], equal_nan=True)
+    one, loop = io.StringIO(), io.StringIO()
+    for b in steps:
+        detect.write_batch_to_output(b, file=one)
+        for iv, st in zip(b["interval"], b["stats"]):
+            detect.write_stats_to_output(iv, st, file=loop)
+    assert one.getvalue() == loop.getvalue() and one.getvalue().count("\n") == sum(len(r["stats"]) for r in recs)
 
 
 def test_posterior_driver_against_the_reference_driver(fpt, tmp_path):
