@@ -75,4 +75,21 @@ inline bool inflate_block(const unsigned char *src, uint32_t clen, unsigned char
     return ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) == crc;
 }
 
+// the first `want` bytes (or all, if fewer) of what a raw deflate payload inflates to: a look at how
+// a member begins without inflating it (no CRC check: a look, not a read).  Returns the bytes made.
+inline uint32_t inflate_prefix(const unsigned char *src, uint32_t clen, unsigned char *dst, uint32_t want) {
+    if (want == 0) return 0;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return 0;
+    zs.next_in = const_cast<unsigned char *>(src);
+    zs.avail_in = clen;
+    zs.next_out = dst;
+    zs.avail_out = want;
+    const int rc = inflate(&zs, Z_SYNC_FLUSH);
+    const uint32_t got = want - zs.avail_out;
+    inflateEnd(&zs);
+    return (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) ? got : 0;
+}
+
 }  // namespace fptz

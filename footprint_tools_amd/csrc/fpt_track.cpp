@@ -377,6 +377,50 @@ bool build_index(track_file *t, std::string *err) {
     return true;
 }
 
+// From the index's offset for a 16 kb window towards the member that holds `start`: the members after
+// the window's first are looked at -- their header for the size, the first KB of what they inflate to
+// for the first whole line -- and passed over while that line is a row of the chromosome before
+// `start`.  A window of a per-base track is ~14 members; without this a query inflates and walks the
+// half of them that lie before its first row (~1 ms), with it the one or two it needs.  Returns the
+// virtual offset to start reading at (the one given, or the first whole line of a later member).
+inline uint64_t hop_members(const track_file *t, int ref, int64_t start, uint64_t voff) {
+    const std::string &name = t->names[(size_t)ref];
+    size_t off = (size_t)(voff >> 16);
+    uint64_t best = voff;
+    unsigned char head[1024];
+    for (int hops = 0; hops < 64; ++hops) {
+        if (off >= t->file.n) break;
+        fptz::bgzf_block b;
+        const long sz = fptz::bgzf_parse_member(t->file.p + off, t->file.n - off, &b);
+        if (sz <= 0) break;
+        const size_t nxt = off + (size_t)sz;
+        if (nxt >= t->file.n) break;
+        fptz::bgzf_block nb;
+        if (fptz::bgzf_parse_member(t->file.p + nxt, t->file.n - nxt, &nb) <= 0) break;
+        const uint32_t got = fptz::inflate_prefix(t->file.p + nxt + nb.cpos, nb.clen, head, (uint32_t)sizeof head);
+        // the first whole line of the next member: after its first newline (what comes before may be
+        // the tail of a line that began in this member)
+        const unsigned char *nl = got ? (const unsigned char *)memchr(head, '\n', got) : nullptr;
+        if (!nl) break;
+        const char *line = (const char *)nl + 1;
+        const size_t room = (size_t)(head + got - (const unsigned char *)line);
+        const char *le = (const char *)memchr(line, '\n', room);
+        if (!le) break;  // (a line longer than the look: read on from where we are)
+        const size_t len = (size_t)(le - line);
+        const char *f;
+        size_t fl;
+        int64_t beg;
+        if (len == 0 || line[0] == t->meta || !field(line, len, t->col_seq, &f, &fl) || fl != name.size() ||
+            memcmp(f, name.data(), fl) != 0 || !field(line, len, t->col_beg, &f, &fl) || !parse_i64(f, fl, &beg))
+            break;
+        if (t->one_based) beg -= 1;
+        if (beg >= start) break;  // (strictly before: rows that share a start may lie on both sides of a member's edge)
+        off = nxt;
+        best = (uint64_t)nxt << 16 | (uint64_t)(line - (const char *)head);
+    }
+    return best;
+}
+
 // Where a scan stopped: the first row at or beyond its interval's end, read but not used.  A batch
 // of sorted intervals goes on from there instead of through the index -- a 16 kb window of a
 // per-base track is 16,384 rows in ~14 members, and a query that starts in the middle of one inflates
@@ -421,6 +465,7 @@ bool scan_rows(const track_file *t, line_reader &rd, int ref, int64_t start, int
         } else if (voff == ~(uint64_t)0) {  // (an unset window of some writers) from the start of the file
             voff = 0;
         }
+        if (t->bgzf) voff = hop_members(t, ref, start, voff);
         if (!rd.seek(voff)) return !rd.failed;
         seen = own_index;  // our own windows start inside the chromosome; a .tbi offset may precede its first row
     }

@@ -531,3 +531,37 @@ def test_batch_writer_matches_the_per_interval_writer(tmp_path, monkeypatch):
         w.write_stats(["chr1", "chr1"], [500, 100], [0, 2, 4], table[:4])
     with pytest.raises(ValueError):  # (and close reports it again)
         w.close()
+
+
+@pytest.mark.parametrize("tbi", [True, False])
+def test_track_reader_passes_over_members_safely(tmp_path, tbi):
+    """A query goes from the index's 16 kb window towards its first row by looking at how the members in
+    between begin (fpt_track.cpp hop_members): rows that share a start on both sides of a member's edge,
+    members that begin in the middle of a line, a chromosome that ends inside the window, a header line,
+    very long lines -- every query still returns exactly its rows."""
+    from footprint_tools_amd.tabix import TabixFile
+    from .tbiwriter import write_bgzf_with_tbi
+    rs = np.random.RandomState(31)
+    rows = []
+    for pos in range(100, 9000):
+        for _ in range(40 if pos in (5000, 5001, 7777) else 1):  # 40 rows of one start: several members' worth
+            rows.append(("chrA", pos, "%.4f" % rs.rand()))
+    rows.append(("chrA", 9000, "x" * 3000))  # a line longer than the look at a member's beginning
+    rows += [("chrA", pos, "1.0") for pos in range(9001, 9100)]
+    rows += [("chrB", pos, "2.0") for pos in range(0, 3000)]
+    text = b"# a header\n" + b"".join(b"%s\t%d\t%d\t%s\n" % (c.encode(), p, p + 1, v.encode()) for c, p, v in rows)
+    path = str(tmp_path / "dups.bed.gz")
+    write_bgzf_with_tbi(path, text, block_bytes=700, tbi=tbi)
+    tb = TabixFile(path)
+    starts = {}
+    for c, p, _ in rows:
+        starts.setdefault(c, []).append(p)
+    starts = {c: np.array(v) for c, v in starts.items()}
+    for chrom, a, b in [("chrA", 5000, 5001), ("chrA", 5001, 5002), ("chrA", 4999, 5003), ("chrA", 7777, 7778), ("chrA", 8999, 9002),
+                        ("chrA", 9050, 9200), ("chrB", 0, 5), ("chrB", 2990, 4000), ("chrA", 100, 101), ("chrA", 0, 100)] + \
+                       [("chrA", int(x), int(x) + 30) for x in rs.randint(90, 9100, 60)] + \
+                       [("chrB", int(x), int(x) + 30) for x in rs.randint(0, 3000, 20)]:
+        got = [int(r[1]) for r in tb.fetch(chrom, a, b)]
+        want = starts[chrom][(starts[chrom] >= a) & (starts[chrom] < b)].tolist()
+        assert got == want, (chrom, a, b, len(got), len(want))
+    tb.close()
