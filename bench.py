@@ -101,6 +101,50 @@ def usable_cpus():
     return n
 
 
+def traffic_probe(argv_cfg, timeout_s=150):
+    """HBM bytes per step of the scan kernels, read from the PMC counters in THIS invocation: two child
+    runs of this script (2 + 1 steps, nothing but the headline leg) under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` -- separate passes, counters only, as MI355X_MICROARCH.md's HBM section prescribes
+    (both count KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read and is
+    doubled).  Started before this process touches the GPU.  None when rocprofv3 or the counters are not
+    to be had: the line then falls back to profiles/traffic.json (the same measurement, made earlier)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not prof or under_profiler:  # (a run that is itself being profiled does not start profilers)
+        return None
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="fpt_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                                                            "--no-other-mode", "--no-heavy", "--no-posterior",
+                                                            "--no-traffic-probe"]
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True,
+                           cwd=env["TMPDIR"], env=env)
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and ("scan_lean" in row["Kernel_Name"] or "scan_fused" in row["Kernel_Name"]):
+                        per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per:
+                return None
+            # mean over a kernel's dispatches, summed over the scan kernels of a step (prof_run.sh's rule)
+            got[counter] = sum(sum(v) / len(v) for v in per.values())
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    rd, wr = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    return dict(read_bytes=rd, write_bytes=wr, bytes_per_launch=rd + wr)
+
+
 def cpu_baseline(cfg, table, DM, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm, results identical to the reference on
     the golden vectors) on a bounded sample of the same workload: all host cores, and one core.
@@ -164,6 +208,9 @@ def main():
                     help="N=1: skip the extra heavy-tailed measurement (20 per mille hotspots) reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-posterior", action="store_true", help="config 5: skip the posterior-caller leg")
+    ap.add_argument("--no-traffic-probe", action="store_true",
+                    help="N=1: do not read the HBM counters in child runs under rocprofv3 (roofline.traffic then "
+                         "comes from profiles/traffic.json)")
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
     ap.add_argument("--allgather", action="store_true",
@@ -192,6 +239,14 @@ def main():
     base = None
     if world == 1 and not args.no_cpu_baseline and cfg["L"] > 0:
         base = cpu_baseline(cfg, table, DM)
+
+    # ... and so do the two counter passes (children under rocprofv3; this process has no GPU state yet)
+    live_traffic = None
+    if world == 1 and not args.no_traffic_probe and not args.hotspots:
+        probe_argv = ["--config", args.config, "--nb-mode", args.nb_mode]
+        if args.intervals:
+            probe_argv += ["--intervals", str(args.intervals)]
+        live_traffic = traffic_probe(probe_argv)
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
@@ -525,12 +580,23 @@ def main():
             # HBM bytes per launch measured with rocprofv3 --pmc (separate run, committed under
             # profiles/), expressed like `achieved`: bytes per launch / this run's kernel time
             traffic = traffic_bytes = None
+            traffic_source = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tf):
+            if live_traffic:
+                traffic_bytes = live_traffic["bytes_per_launch"]
+                traffic_source = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE over two child runs of this command "
+                                  "(2 + 1 steps each) made by this invocation: %.4g GB read (FETCH_SIZE doubled: gfx950) + "
+                                  "%.4g GB written per step, divided by this run's kernel_ms"
+                                  % (live_traffic["read_bytes"] / 1e9, live_traffic["write_bytes"] / 1e9))
+            elif os.path.exists(tf):
                 rec = json.load(open(tf)).get(cfg["name"])
                 if rec:
                     traffic_bytes = rec["bytes_per_launch"]
-                    traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
+                    traffic_source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this "
+                                      "workload in a separate run (gfx950 corrections applied), divided by "
+                                      "this run's kernel_ms")
+            if traffic_bytes:
+                traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
             achieved_read = total * rd / (k_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
@@ -543,12 +609,10 @@ def main():
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),
                         traffic_bytes_per_launch=traffic_bytes,
-                        # `traffic` is NOT a counter read in this run: it is the HBM bytes per launch that
-                        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measured in a separate run of the same
-                        # command (profiles/traffic.json, summaries under profiles/), over this run's kernel time
-                        traffic_source=("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this "
-                                        "workload in a separate run (gfx950 corrections applied), divided by "
-                                        "this run's kernel_ms") if traffic_bytes else None,
+                        # HBM bytes per launch from the PMC counters -- read by this invocation in two
+                        # child runs under rocprofv3 (traffic_probe), else the same measurement made
+                        # earlier (profiles/traffic.json) -- over this run's kernel time
+                        traffic_source=traffic_source,
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))
         out = {
             "metric": "bases/sec per-nucleotide footprint stats",

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 for stop in ${ABL_STOPS:-1 2 3 4 0}; do
   OUT=gpurun_out/pmc_lean_$stop; rm -rf $OUT; mkdir -p $OUT
-  FPT_ABLATE=$stop rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT -- python3 bench.py --config ${ABL_CFG:-3} --steps 2 --warmup 1 --no-cpu-baseline --no-other-mode --no-heavy > $OUT/log.txt 2>&1
+  FPT_ABLATE=$stop rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT -- python3 bench.py --config ${ABL_CFG:-3} --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy > $OUT/log.txt 2>&1
   python3 - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(float)

@@ -7,7 +7,7 @@ export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 for ab in 0 6 5; do
   OUT=gpurun_out/clock_$ab
   rm -rf $OUT; mkdir -p $OUT
-  FPT_ABLATE=$ab rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --no-heavy > $OUT/log.txt 2>&1
+  FPT_ABLATE=$ab rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy > $OUT/log.txt 2>&1
   python3 - <<PY
 import csv, glob
 for f in glob.glob("$OUT/*/*_counter_collection.csv"):

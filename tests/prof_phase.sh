@@ -7,7 +7,7 @@ export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 OUT=gpurun_out/phase
 mkdir -p $OUT
 for bits in 32 64 128 256 0; do
-  FPT_ABLATE=$bits rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/b$bits -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-mode --nb-mode memo "$@" > $OUT/b$bits.log 2>&1
+  FPT_ABLATE=$bits rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/b$bits -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-probe --no-other-mode --nb-mode memo "$@" > $OUT/b$bits.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
