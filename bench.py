@@ -101,7 +101,7 @@ def usable_cpus():
     return n
 
 
-def traffic_probe(argv_cfg, timeout_s=150):
+def traffic_probe(argv_cfg, timeout_s=100):
     """HBM bytes per step of the scan kernels, read from the PMC counters in THIS invocation: two child
     runs of this script (2 + 1 steps, nothing but the headline leg) under `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` -- separate passes, counters only, as MI355X_MICROARCH.md's HBM section prescribes
