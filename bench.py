@@ -657,6 +657,9 @@ def main():
             "posterior": post,
             "parity": parity,
         }
+        if args.share_gpu and world > 1:  # a smoke test of the launcher path, not a measurement
+            out["invalid"] = ("--share-gpu: %d ranks on one GPU, no communicator, ranks neither synchronised nor "
+                              "their times combined: `value` is rank 0's own time scaled by the rank count" % world)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()
