@@ -95,5 +95,5 @@ class posterior_stats(object):
             obs, exp, fdr, w, off = self.load_batch(ivs)
             table = posterior.posterior_batch(obs, exp, fdr, w, self.betas, self.disp_models, fdr_cutoff=self.fdr_cutoff,
                                               half_win_width=3, interval_off=off, ctx=self.ctx)
-            o = off.tolist()
-            yield {"interval": ivs, "stats": [table[x:y] for x, y in zip(o[:-1], o[1:])], "table": table, "row_off": off}
+            from .detect import _row_blocks
+            yield {"interval": ivs, "stats": _row_blocks(table, off), "table": table, "row_off": off}
