@@ -1636,7 +1636,7 @@ __device__ unsigned long long g_fdr_phase[16];
 // ONE: no interval of the launch is longer than the workgroup -- a lane has one base, and what
 // belongs to the base (table row, Philox counter, addresses) is made once, not in every pass.
 template <int NT, bool GWS, int HSC, bool ONE>
-__global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) {
+__global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
     double *par = GWS ? reinterpret_cast<double *>(a.gws + (size_t)blockIdx.x * a.gws_stride) : smem;  // 24
@@ -2074,6 +2074,9 @@ __global__ void __launch_bounds__(NT, GWS ? 2 : 4) k_fdr_null(const fdr_args a) 
 // bases in one pass and 257..384 in two
 template <int HSC, bool ONE>
 fdr_kernel_t fdr_kernel(int nt) {
+    // (512 lanes: intervals of 385 bases and more, in several rounds -- their buffers let two or three
+    // workgroups live on a CU, and with 256 lanes each those were 8-12 wavefronts)
+    if (!ONE && nt == 512) return k_fdr_null<512, false, HSC, false>;
     return nt == 64 ? k_fdr_null<64, false, HSC, ONE> : nt == 128 ? k_fdr_null<128, false, HSC, ONE>
            : nt == 192 ? k_fdr_null<192, false, HSC, ONE> : k_fdr_null<256, false, HSC, ONE>;
 }
@@ -2654,7 +2657,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     const int nt = fl.nt ? fl.nt : (fl.n2_max <= 64 ? 64 : (fl.n2_max <= 128 ? 128 : 256));
     // (the longest interval of the launch is known to be <= n2_max only; ONE when that says enough
     // or the caller does: max_len)
-    const bool one = (fl.max_len > 0 ? fl.max_len : fl.n2_max) <= nt;
+    const bool one = nt <= 256 && (fl.max_len > 0 ? fl.max_len : fl.n2_max) <= nt;  // (512 lanes: the several-rounds form only)
     fdr_kernel_t kern = fl.hw == 3 ? (one ? fdr_kernel<3, true>(nt) : fdr_kernel<3, false>(nt))
                                    : (one ? fdr_kernel<0, true>(nt) : fdr_kernel<0, false>(nt));
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
