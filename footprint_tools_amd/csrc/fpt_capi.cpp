@@ -846,7 +846,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     constexpr int kClasses = 9;
     static const int cls_len[kClasses] = {64, 128, 192, 256, 384, 512, 1024, 2048, 4096};  // longest interval
     static const int cls_n2[kClasses] = {64, 128, 256, 256, 512, 512, 1024, 2048, 4096};   // LDS buffers
-    static const int cls_nt[kClasses] = {64, 128, 192, 256, 192, 512, 512, 512, 512};      // lanes
+    static const int cls_nt[kClasses] = {64, 128, 192, 256, 192, 256, 512, 512, 512};      // lanes (512: measured slower for the 385..512 class, 2 x 8 wavefronts per CU against 3 x 4)
     auto cls_of = [&](int L) {
         int k = 0;
         while (cls_len[k] < L) ++k;

@@ -2074,8 +2074,8 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
 // bases in one pass and 257..384 in two
 template <int HSC, bool ONE>
 fdr_kernel_t fdr_kernel(int nt) {
-    // (512 lanes: intervals of 385 bases and more, in several rounds -- their buffers let two or three
-    // workgroups live on a CU, and with 256 lanes each those were 8-12 wavefronts)
+    // (512 lanes: intervals of 513 bases and more, in several rounds -- their buffers let two
+    // workgroups live on a CU, and with 256 lanes each those were 8 wavefronts)
     if (!ONE && nt == 512) return k_fdr_null<512, false, HSC, false>;
     return nt == 64 ? k_fdr_null<64, false, HSC, ONE> : nt == 128 ? k_fdr_null<128, false, HSC, ONE>
            : nt == 192 ? k_fdr_null<192, false, HSC, ONE> : k_fdr_null<256, false, HSC, ONE>;
