@@ -1838,10 +1838,10 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // edge.  Filled from the sorted thresholds: the one at place i writes i to the slices after its
     // predecessor's up to its own (one or two on average) -- no search (a bisection per slice was
     // log2(L) dependent LDS reads, a quarter of an interval's set-up time).
-    auto slice_of = [&](double y) {
-        const int b = (y > -kYR) ? (int)((y + kYR) * yscale) : 0;
-        return (b < nb && y < kYR) ? b : nb - 1;
-    };
+    // (one fused multiply-add, two clamps, one conversion: any monotone function of x will do, and a
+    // NaN -- whose rank is not used -- lands in slice 0)
+    const double slice_c0 = kYR * yscale, slice_top = (double)(nb - 1);
+    auto slice_of = [&](double y) { return (int)fmin(fmax(fma(y, yscale, slice_c0), 0.0), slice_top); };
     for (int i = tid; i <= rank_one; i += NT) {
         const int from = i == 0 ? 0 : slice_of(skey[i - 1]) + 1;
         const int to = i == rank_one ? nb : slice_of(skey[i]);  // (the last entry: every threshold below 1)
