@@ -1976,10 +1976,12 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                             sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
                         }
                     }
-                    x0 = isfinite(sm[0]) ? -sm[0] : NAN;
-                    x1 = isfinite(sm[1]) ? -sm[1] : NAN;
-                    x2 = isfinite(sm[2]) ? -sm[2] : NAN;
-                    x3 = isfinite(sm[3]) ? -sm[3] : NAN;
+                    // -sum, or NaN where the sum is not finite: (s - s) is 0 or NaN, and two subtractions
+                    // are half of a class test, a sign flip and two selects
+                    x0 = (sm[0] - sm[0]) - sm[0];
+                    x1 = (sm[1] - sm[1]) - sm[1];
+                    x2 = (sm[2] - sm[2]) - sm[2];
+                    x3 = (sm[3] - sm[3]) - sm[3];
                 }
             } else if (t >= hs && t < L - hs) {
                 const bool le3 = hs <= 64;
