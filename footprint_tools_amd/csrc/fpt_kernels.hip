@@ -2005,10 +2005,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
             }
             // rank = #{thresholds <= y}: bisect inside the guide's bracket, two samples in step
             // (for NaN the result is unused; +inf gets the precomputed rank of 1.0)
-            const int npairs = ns > 2 ? 2 : 1;
-#pragma clang loop unroll(disable)
-            for (int pr = 0; pr < npairs; ++pr) {
-                const double y0 = pr ? x2 : x0, y1 = pr ? x3 : x1;
+            auto rank_pair = [&](const double y0, const double y1, const bool second) {
                 const int b0 = slice_of(y0), b1 = slice_of(y1);
                 int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
                 // The first two probes go to the two ends of the bracket, then it is bisected: a bracket
@@ -2033,8 +2030,11 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                 l0 = y0 == fptm::kInf ? rank_one : l0;
                 l1 = y1 == fptm::kInf ? rank_one : l1;
                 atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
-                if (2 * pr + 1 < ns) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
-            }
+                if (second) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
+            };
+            // (two copies of the search rather than a loop over the pairs: a loop picks its pair with four selects)
+            rank_pair(x0, x1, ns > 1);
+            if (ns > 2) rank_pair(x2, x3, ns > 3);
         }
         FDR_MARK(9)  // a pass: windows + ranks
         if (!alternate) __syncthreads();
