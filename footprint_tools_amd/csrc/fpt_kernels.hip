@@ -2027,8 +2027,8 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                         h1 = g1 ? h1 : m1;
                     }
                 }
-                l0 = y0 == fptm::kInf ? rank_one : l0;
-                l1 = y1 == fptm::kInf ? rank_one : l1;
+                // (an edge position's +inf needs no special case: it falls in the last slice, whose bracket
+                // ends at rank_one -- every threshold below 1 is <= +inf -- and the first probe settles it)
                 atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
                 if (second) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
             };
