@@ -1381,17 +1381,17 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *
         int a[N], k[N];
         lane_mask UP[N], M[N];
         double2 e[N];
-        uint32_t g[N];
-        float f[N];
+        uint32_t g[N], f[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) g[j] = guide_pair(guide, gr + 2u * (uint32_t)fptm::guide_index(w[j], f[j]));
+        for (int j = 0; j < N; ++j) g[j] = guide_pair(guide, gr + 2u * (uint32_t)fptm::guide_index_fixed(w[j], f[j]));
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             a[j] = (int)(g[j] & 0xffffu);  // answer in [a, b]
             const int width = (int)(g[j] >> 16) - a[j];
             // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
             // outermost slot, open towards the end of the table: start at its near end)
-            k[j] = a[j] + (width > 64 ? 0 : (int)(f[j] * (float)width));
+            // (any start inside the bracket gives the same draw: the walk ends at the first entry >= u)
+            k[j] = a[j] + (width > 64 ? 0 : (int)(__umul24(f[j], (uint32_t)width) >> 24));
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) e[j] = table_entry(memo, row + 16u * (uint32_t)k[j]);

@@ -791,6 +791,17 @@ FPT_HD int guide_index(uint32_t w, float &frac) {
     return (int)sub + (low ? 257 : (high ? 514 : 0));
 }
 
+// the same with the position as 24 fixed-point bits (frac = frac24 / 2^24): what the sampler's first
+// probe wants -- frac24 * width >> 24 is one 24-bit multiply and a shift where the float form is two
+// conversions, two multiplications and a truncation
+FPT_HD int guide_index_fixed(uint32_t w, uint32_t &frac24) {
+    const uint32_t top = w >> 24;
+    const bool low = top == 0u, high = top == 255u;
+    const uint32_t sub = (low || high) ? ((w >> 16) & 255u) : top;
+    frac24 = (low || high) ? ((w & 0xffffu) << 8) : (w & 0xffffffu);
+    return (int)sub + (low ? 257 : (high ? 514 : 0));
+}
+
 FPT_HD double guide_edge(int idx) {
     if (idx <= 256) return (double)idx * (1.0 / 256.0);
     if (idx <= 513) return (double)(idx - 257) * (1.0 / 65536.0);
