@@ -102,15 +102,20 @@ def usable_cpus():
 
 
 def traffic_probe(argv_cfg, timeout_s=100):
-    """HBM bytes per step of the scan kernels, read from the PMC counters in THIS invocation: two child
-    runs of this script (2 + 1 steps, nothing but the headline leg) under `rocprofv3 --pmc FETCH_SIZE` and
-    `--pmc WRITE_SIZE` -- separate passes, counters only, as MI355X_MICROARCH.md's HBM section prescribes
-    (both count KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read and is
-    doubled).  Started before this process touches the GPU.  None when rocprofv3 or the counters are not
-    to be had: the line then falls back to profiles/traffic.json (the same measurement, made earlier)."""
+    """HBM bytes per step of the scan kernels and the shader clock they ran at, read from the PMC counters
+    in THIS invocation: three child runs of this script (1 warm-up + 2 steps, nothing but the headline leg)
+    under `rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc GRBM_GUI_ACTIVE` -- separate passes,
+    counters only, as MI355X_MICROARCH.md's HBM section prescribes (both sizes count KiB; on gfx950
+    FETCH_SIZE reports half the bytes of a coalesced streaming read and is doubled; GRBM_GUI_ACTIVE is
+    summed over the 8 XCDs).  The first dispatch of every kernel (the warm-up call: empty second-level
+    table, cold caches) is dropped, the rest averaged.  Started before this process touches the GPU, each
+    child in its own process group (killed as a group on timeout).  None when rocprofv3 or the counters
+    are not to be had: the line then falls back to profiles/traffic.json (the same measurement, made
+    earlier)."""
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -118,31 +123,58 @@ def traffic_probe(argv_cfg, timeout_s=100):
     if not prof or under_profiler:  # (a run that is itself being profiled does not start profilers)
         return None
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-    got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    got, clock = {}, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
         out = tempfile.mkdtemp(prefix="fpt_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         try:
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.abspath(__file__)] + argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                                                             "--no-other-mode", "--no-heavy", "--no-posterior",
-                                                            "--no-traffic-probe"]
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True,
-                           cwd=env["TMPDIR"], env=env)
-            per = {}
+                                                            "--no-traffic-probe", "--no-box-stream"]
+            child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
+                                     start_new_session=True)
+            try:
+                if child.wait(timeout=timeout_s) != 0:
+                    raise subprocess.SubprocessError("rocprofv3 child failed")
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)  # the profiler AND the program under it
+                child.wait()
+                raise
+            per, spans = {}, {}
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and ("scan_lean" in row["Kernel_Name"] or "scan_fused" in row["Kernel_Name"]):
-                        per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] == counter and ("scan_lean" in name or "scan_fused" in name or "scan_wave" in name):
+                        key = (name, int(row.get("Dispatch_Id", 0) or 0))
+                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+                        if "End_Timestamp" in row and "Start_Timestamp" in row:
+                            spans[key] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
             if not per:
                 return None
-            # mean over a kernel's dispatches, summed over the scan kernels of a step (prof_run.sh's rule)
-            got[counter] = sum(sum(v) / len(v) for v in per.values())
+            by_kernel = {}
+            for (name, disp) in sorted(per):
+                by_kernel.setdefault(name, []).append((per[(name, disp)], spans.get((name, disp), 0)))
+            total = cyc = ns = 0.0
+            for name, v in by_kernel.items():
+                v = v[len(v) // 3:] if len(v) >= 3 else v  # drop the warm-up step's dispatch(es)
+                total += sum(x[0] for x in v) / len(v)
+                if "scan_fused" not in name:
+                    cyc += sum(x[0] for x in v)
+                    ns += sum(x[1] for x in v)
+            got[counter] = total
+            if counter == "GRBM_GUI_ACTIVE" and ns > 0:
+                clock = cyc / 8.0 / ns  # GHz: cycles summed over the 8 XCDs / duration of the first-pass kernels
         except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            if counter == "GRBM_GUI_ACTIVE" and "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+                break  # the traffic stands without the clock
             return None
         finally:
             shutil.rmtree(out, ignore_errors=True)
     rd, wr = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
-    return dict(read_bytes=rd, write_bytes=wr, bytes_per_launch=rd + wr)
+    return dict(read_bytes=rd, write_bytes=wr, bytes_per_launch=rd + wr, shader_clock_GHz=clock,
+                raw_counters=dict(FETCH_SIZE_KiB=got.get("FETCH_SIZE"), WRITE_SIZE_KiB=got.get("WRITE_SIZE"),
+                                  GRBM_GUI_ACTIVE=got.get("GRBM_GUI_ACTIVE"),
+                                  corrections="FETCH_SIZE x2 (gfx950 streaming reads), KiB -> bytes"))
 
 
 def cpu_baseline(cfg, table, DM, budget_s=12.0):
@@ -212,6 +244,8 @@ def main():
                     help="N=1: do not read the HBM counters in child runs under rocprofv3 (roofline.traffic then "
                          "comes from profiles/traffic.json)")
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
+    ap.add_argument("--no-box-stream", action="store_true",
+                    help="N=1: do not time the scan's access pattern without arithmetic (roofline.box_stream_GBps)")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
     ap.add_argument("--allgather", action="store_true",
                     help="N=1: run the track all-gather anyway, on a one-rank RCCL communicator")
@@ -296,13 +330,12 @@ def main():
     # ---- resident buffers: inputs generated on the device, outputs written in place
     d_cp, d_cm = DeviceArray(ctx, n_counts * 8), DeviceArray(ctx, n_counts * 8)
     d_sq = DeviceArray(ctx, n_seq)
-    d_out = DeviceArray(ctx, (2 + S) * total * 8)   # exp, obs, winp[S]
+    d_out = DeviceArray(ctx, (3 + S) * total * 8)   # exp, obs, winp[S], p (unless it lives in the gathered track)
     d_gather = DeviceArray(ctx, total_all * 8) if do_gather else None
     # the p-value track of the resident batch: with a gather it is written straight into its
     # slice of the gathered track (the collective runs in place)
     my_off = int(sum(counts[:rank])) * 8
-    d_p = None if do_gather else DeviceArray(ctx, total * 8)
-    p_p = d_gather.ptr + my_off if do_gather else d_p.ptr
+    p_p = d_gather.ptr + my_off if do_gather else d_out.ptr + (2 + S) * total * 8
     p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
     d_off = d_dm = d_efdr = None
     if ragged:
@@ -421,8 +454,8 @@ def main():
         if fdr_times:
             gp = d_pv.download(np.float64, Li, o0 * 8)
         else:
-            src = d_gather if do_gather else d_p
-            gp = src.download(np.float64, Li, (my_off if do_gather else 0) + o0 * 8)
+            src = d_gather if do_gather else d_out
+            gp = src.download(np.float64, Li, (my_off if do_gather else (2 + S) * total * 8) + o0 * 8)
         rel = float(np.nanmax(np.abs(gp - p) / np.maximum(np.abs(p), 1e-300)))
         parity = dict(exp_bit_exact=bool(np.array_equal(ge, e)), p_max_rel_err=rel)
         if S:  # the window p-values of every scale (contract: 1e-6 relative)
@@ -571,6 +604,18 @@ def main():
             post["parity_ok"] = bool(np.allclose(got, want, rtol=1e-6, atol=1e-9, equal_nan=True))
             post["zero_division_flags"] = int(d_st.download(np.int32, n_iv).any())
 
+    # ---- the box beside the kernel: the scan's loads and stores without its arithmetic
+    #      (fpt_stream_pattern_dev: same layout, same workgroup per interval, 3 + S tracks written), timed
+    #      here, after everything that needs the output buffers
+    box = None
+    if world == 1 and not args.no_box_stream:
+        import ctypes
+        ms = ctypes.c_float(0.0)
+        _lib.check(ctx.L.fpt_stream_pattern_dev(ctx.h, n_iv, 0 if ragged else L, d_off.ptr if ragged else None,
+                                                int(lens.max()) if ragged else L, HW + SHW, 3 + S, p_cp, p_cm, p_sq,
+                                                p_out, total, 5, ctypes.byref(ms)))
+        box = float(ms.value)
+
     if rank == 0:
         rd, wr = algorithmic_bytes_per_base(L if not ragged else total / n_iv, S)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None
@@ -606,6 +651,14 @@ def main():
                         kernel=("k_scan_lean<NT> (first pass of the step; tiles outside its case are redone by "
                                 "k_scan_fused<NT,5,50,table=L2,full>)"
                                 if args.nb_mode == "memo" else "k_scan_fused<NT,HW,SHW,table=L2,full>"),
+                        # the same loads and stores with no arithmetic between them, on this box, in this
+                        # invocation (fpt_stream_pattern_dev): what the access pattern reaches here
+                        box_stream_ms=box, box_stream_GBps=(total * (rd + wr) / (box * 1e-3) / 1e9 if box else None),
+                        frac_of_box=(box / k_ms if box else None),
+                        # GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the first-pass kernel in a child run
+                        # under rocprofv3 --pmc (traffic_probe)
+                        shader_clock_GHz=(live_traffic or {}).get("shader_clock_GHz"),
+                        raw_counters=(live_traffic or {}).get("raw_counters"),
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),
                         traffic_bytes_per_launch=traffic_bytes,

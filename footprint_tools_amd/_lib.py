@@ -25,7 +25,7 @@ EXPORTS = [
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
-    "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
+    "fpt_stream_pattern_dev", "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
 
@@ -182,6 +182,8 @@ def load():
         L.fpt_set_memo_dims.argtypes = [vp, i32, i32]
         L.fpt_drop_kept_tables.argtypes = [vp]
         L.fpt_timing_enable.argtypes = [vp, i32]
+        if hasattr(L, "fpt_stream_pattern_dev"):  # (absent from older builds loaded through FPT_LIB_PATH for A/B runs)
+            L.fpt_stream_pattern_dev.argtypes = [vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, C.POINTER(C.c_float)]
         L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]
         _lib = L
     return _lib

@@ -89,6 +89,9 @@ struct fpt_ctx {
     bool posterior_direct = false;  // FPT_POSTERIOR_TABLES=0: every log-pmf evaluated in the kernel (tests compare the two)
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
+    // size classes of a batch's tiles; FPT_SCAN_WAVE = 0 / 4 / 5 / 6: whole intervals of up to 139 / 203 / 267
+    // bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip), read at creation
+    fptk::lean_class_set classes = fptk::make_lean_classes(4);
     bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
@@ -209,6 +212,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     if (const char *e = getenv("FPT_MEMO2_KEEP")) c->memo2_cold = atoi(e) == 0;
     if (const char *e = getenv("FPT_POSTERIOR_TABLES")) c->posterior_direct = atoi(e) == 0;
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
+    if (const char *e = getenv("FPT_SCAN_WAVE")) c->classes = fptk::make_lean_classes(atoi(e));
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     // any failure below releases what was created so far (fpt_ctx_destroy skips null members)
@@ -527,13 +531,15 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         int nt;
         int64_t first, count;
         int tile_len;
+        int wave_rp;  // > 0: the one-wavefront-per-interval kernel (first pass of memo mode only)
     };
+    const fptk::lean_class_set &CS = c->classes;
     std::vector<launch_t> launches, lean_launches;
 
     auto nt_class = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : 1024); };
-    auto lean_class = [](int n) {
+    auto lean_class = [&CS](int n) {
         int k = 0;
-        while (fptk::kLeanNT[k] < n) ++k;
+        while (CS.lmax[k] < n) ++k;
         return k;
     };
 
@@ -546,8 +552,9 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         int tpi = (L + tile_len - 1) / tile_len;
         sl.tiles_per_interval = tpi;
         int nt_needed = tpi == 1 ? L : std::min(L, tile_len + 2 * H);
-        launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len});
-        lean_launches.push_back({fptk::kLeanNT[lean_class(nt_needed)], 0, d->n_intervals * (int64_t)tpi, tile_len});
+        launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len, 0});
+        const int ucls = tpi == 1 ? lean_class(nt_needed) : std::max(lean_class(nt_needed), CS.first_split);
+        lean_launches.push_back({CS.nt[ucls], 0, d->n_intervals * (int64_t)tpi, tile_len, tpi == 1 ? CS.wave_rp[ucls] : 0});
     } else {
         // ragged batch: tile table binned by workgroup size
         std::vector<int64_t> off_host;
@@ -565,7 +572,7 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         // made on the device (k_plan_tiles) -- a few KB are copied, nobody waits, and a job whose
         // batches all differ pays ~1 ns per interval here
         constexpr int NC = fptk::kLeanClasses, PB = fptk::kPlanBlock;
-        if (1024 - H <= fptk::kLeanNT[NC - 2]) return fail(FPT_ERR_INVALID, "Stouffer half-width %d too large", H);
+        if (1024 - H <= CS.lmax[NC - 2]) return fail(FPT_ERR_INVALID, "Stouffer half-width %d too large", H);
         const int64_t n_blocks = (d->n_intervals + PB - 1) / PB;
         const size_t stage_bytes = (size_t)std::max<int64_t>(n_blocks, 1) * NC * sizeof(int32_t);
         if (c->pin_plan_busy) {  // (the copy of the call before has long happened)
@@ -596,10 +603,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
                 if (L > 1024 && !bad_off) {  // pieces of split_len bases, all but the last in the top class
                     const int n_full = (L - 1) / split_len;
                     cls_count[NC - 1] += n_full;
-                    cls_count[lean_class(L - n_full * split_len + H)] += 1;
+                    cls_count[std::max(lean_class(L - n_full * split_len + H), CS.first_split)] += 1;
                 } else {  // (no branch on the length: the lengths of a real batch are not predictable)
                     int k = 0;
-                    for (int q = 0; q < NC - 1; ++q) k += fptk::kLeanNT[q] < L ? 1 : 0;
+                    for (int q = 0; q < NC - 1; ++q) k += CS.lmax[q] < L ? 1 : 0;
                     cls_count[k] += L > 0 ? 1 : 0;
                 }
             }
@@ -626,8 +633,8 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             if (!c->pin_plan_copied) HIP_TRY(hipEventCreateWithFlags(&c->pin_plan_copied, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(c->pin_plan_copied, c->stream));
             c->pin_plan_busy = true;
-            fptk::launch_plan_tiles(c->stream, d->interval_off, d->n_intervals, n_tiles, H, split_len, d_base, (int32_t *)d_flat,
-                                    d_recs);
+            fptk::launch_plan_tiles(c->stream, d->interval_off, d->n_intervals, n_tiles, H, split_len, CS, d_base,
+                                    (int32_t *)d_flat, d_recs);
             if (int rc = launch_ok("k_plan_tiles")) return rc;
         }
         c->plan_tiles = n_tiles;
@@ -643,10 +650,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         for (int cls = 0; cls < fptk::kLeanClasses; ++cls) {
             const int64_t n = c->plan_cls_count[cls];
             if (n > 0) {
-                lean_launches.push_back({fptk::kLeanNT[cls], first, n, split_len});
-                const int nt = nt_class(fptk::kLeanNT[cls]);
+                lean_launches.push_back({CS.nt[cls], first, n, split_len, CS.wave_rp[cls]});
+                const int nt = nt_class(CS.lmax[cls]);
                 if (!launches.empty() && launches.back().nt == nt) launches.back().count += n;
-                else launches.push_back({nt, first, n, split_len});
+                else launches.push_back({nt, first, n, split_len, 0});
             }
             first += n;
         }
@@ -743,17 +750,21 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             // count and cursor of the second pass: a pair of d_flags[10..15] per workgroup size
             s2.redo_cursor = c->d_flags + 10 + 2 * (ln.nt <= 256 ? 0 : (ln.nt <= 512 ? 1 : 2));
             const bool lean = lean_pass;
-            size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt)
-                              : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
+            const int wave_rp = lean ? ln.wave_rp : 0;
+            size_t lds = wave_rp ? fptk::scan_wave_lds_bytes(wave_rp)
+                         : lean  ? fptk::scan_lean_lds_bytes(ln.nt)
+                                 : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)
                 return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
-            if (lean) HIP_TRY(fptk::scan_lean_set_lds(ln.nt));
+            if (wave_rp) {
+            } else if (lean) HIP_TRY(fptk::scan_lean_set_lds(ln.nt));
             else HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, !memo_only && d_redo, lds));
             for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
                 int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
                 s2.tile_first = ln.first + done;
                 s2.redo_cursor_clear = done > 0 ? 1 : 0;  // a second chunk of the same size class reuses the pair
-                if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
+                if (wave_rp) fptk::launch_scan_wave(c->stream, wave_rp, (int)n, s2);
+                else if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
                 else fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
                 if (int rc = launch_ok("k_scan_fused")) return rc;
             }

@@ -2520,11 +2520,13 @@ struct plan_args {
     const int32_t *block_base;
     int32_t *tile_iv, *tile_t0, *tile_tl;
     lean_tile_rec *recs;
+    int32_t lmax[kLeanClasses];
+    int32_t first_split;
 };
-__host__ __device__ __forceinline__ int plan_class_of(int n) {  // the first class whose lanes hold n positions
+__device__ __forceinline__ int plan_class_of(const plan_args &a, int n) {  // the first class that holds n bases
     int k = 0;
 #pragma unroll
-    for (int i = 0; i < kLeanClasses - 1; ++i) k += kLeanNT[i] < n ? 1 : 0;
+    for (int i = 0; i < kLeanClasses - 1; ++i) k += a.lmax[i] < n ? 1 : 0;
     return k;
 }
 __global__ void __launch_bounds__(kPlanBlock) k_plan_tiles(const plan_args a) {
@@ -2544,9 +2546,9 @@ __global__ void __launch_bounds__(kPlanBlock) k_plan_tiles(const plan_args a) {
     if (L > 1024) {
         n_full = (L - 1) / a.split_len;
         last_t0 = n_full * a.split_len;
-        last_cls = plan_class_of(L - last_t0 + a.H);
+        last_cls = max(plan_class_of(a, L - last_t0 + a.H), a.first_split);  // (a piece is no whole interval)
     } else if (L > 0) {
-        last_cls = plan_class_of(L);
+        last_cls = plan_class_of(a, L);
     }
     int mine[kLeanClasses];  // where this lane's tiles of a class start
 #pragma unroll
@@ -2578,9 +2580,32 @@ __global__ void __launch_bounds__(kPlanBlock) k_plan_tiles(const plan_args a) {
     }
 }
 
+lean_class_set make_lean_classes(int wave_rp_max) {
+    lean_class_set c{};
+    for (int i = 0; i < kLeanClasses; ++i) {
+        c.lmax[i] = c.nt[i] = kLeanNT[i];
+        c.wave_rp[i] = 0;
+    }
+    c.first_split = 0;
+    // wave classes: whole intervals of up to 139 (RP 4), 203 (RP 5), 267 (RP 6) bases
+    for (int rp = 4, i = 0; rp <= wave_rp_max && rp <= 6; ++rp, ++i) {
+        c.lmax[i] = scan_wave_max_len(rp);
+        c.wave_rp[i] = rp;
+        c.first_split = i + 1;
+    }
+    for (int i = 0; i < kLeanClasses; ++i) {  // k_scan_lean's size for a class: the smallest that holds it
+        int k = 0;
+        while (kLeanNT[k] < c.lmax[i]) ++k;
+        c.nt[i] = kLeanNT[k];
+    }
+    return c;
+}
+
 void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, int64_t n_tiles, int H, int split_len,
-                       const int32_t *block_base, int32_t *flat, void *recs) {
+                       const lean_class_set &cls, const int32_t *block_base, int32_t *flat, void *recs) {
     plan_args a;
+    for (int i = 0; i < kLeanClasses; ++i) a.lmax[i] = cls.lmax[i];
+    a.first_split = cls.first_split;
     a.off = off;
     a.n_intervals = n_intervals;
     a.n_tiles = n_tiles;

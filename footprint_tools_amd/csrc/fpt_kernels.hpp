@@ -58,6 +58,19 @@ struct lean_tile_rec {  // a tile of a ragged batch, read by the kernel with one
 static_assert(sizeof(lean_tile_rec) == 32, "one s_load_dwordx8");
 constexpr int kLeanClasses = 7;
 constexpr int kLeanNT[kLeanClasses] = {128, 192, 256, 384, 512, 768, 1024};  // its workgroup sizes
+// The tiles of a ragged batch are binned into kLeanClasses classes by the bases (+ halo) they hold.
+// Without the wave kernel the classes are k_scan_lean's workgroup sizes; with it (fpt_scan_wave.hip: one
+// wavefront per whole interval of up to 139 / 203 / 267 bases) the first classes end at those lengths.
+struct lean_class_set {
+    int lmax[kLeanClasses];     // class c holds tiles of (lmax[c-1], lmax[c]] bases incl. halo
+    int nt[kLeanClasses];       // k_scan_lean's workgroup size for the class
+    int wave_rp[kLeanClasses];  // > 0: k_scan_wave<rp> takes the class in the first pass (whole intervals only)
+    int first_split;            // the first class a PIECE of a split interval may go to (never a wave class)
+};
+lean_class_set make_lean_classes(int wave_rp_max);  // 0 (none), 4, 5 or 6
+int scan_wave_max_len(int rp);
+size_t scan_wave_lds_bytes(int rp);
+void launch_scan_wave(hipStream_t st, int rp, int grid, const scan_launch &sl);
 bool scan_lean_applies(const scan_launch &sl);
 bool scan_lean_applies_hw(int hw, int shw, int k_trim);
 size_t scan_lean_lds_bytes(int nt);
@@ -136,7 +149,7 @@ void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_ex
 // kPlanBlock intervals and class, the table index of the first tile of the block's first interval.
 constexpr int kPlanBlock = 256;
 void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, int64_t n_tiles, int H, int split_len,
-                       const int32_t *block_base, int32_t *flat, void *recs);
+                       const lean_class_set &cls, const int32_t *block_base, int32_t *flat, void *recs);
 size_t nb_guide_bytes(int n_models, int memo_exp);
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,

@@ -487,6 +487,20 @@ int fpt_synth_hotspots_dev(fpt_ctx *ctx, uint64_t seed, int64_t pos0_counts, int
  * written to *host_out after synchronising; for size-independent parity checks. */
 int fpt_checksum_dev(fpt_ctx *ctx, const double *dev, int64_t n, uint64_t *host_out);
 
+/* The scan's HBM access pattern and nothing else (measurement; SURVEY.md 8d: "record the box's
+ * measured stream-copy BW beside" the 8 TB/s peak).  Per interval the loads and stores of
+ * fpt_scan_dev -- 2 x (L + 2*pad + 1) doubles and L + 2*pad + 7 sequence bytes in, n_tracks
+ * tracks of L doubles total_bases apart out, one workgroup per interval -- with one add per load
+ * between them.  Same input layout as fpt_scan_dev (interval_len for uniform batches, or
+ * interval_off_dev + max_interval_len for ragged ones); `out` holds n_tracks * total_bases doubles
+ * and is overwritten.  Runs one warm-up launch and `reps` timed ones on the context's stream,
+ * synchronises, and writes the mean milliseconds per launch (HIP events) to *ms_out.
+ * Reference counterpart: none -- the memory side of cli/detect.py:120-130 for a batch. */
+int fpt_stream_pattern_dev(fpt_ctx *ctx, int64_t n_intervals, int32_t interval_len, const int64_t *interval_off_dev,
+                           int32_t max_interval_len, int32_t pad, int32_t n_tracks, const double *counts_plus,
+                           const double *counts_minus, const uint8_t *seq, double *out, int64_t total_bases,
+                           int32_t reps, float *ms_out);
+
 /* device memory helpers for hosts that have no allocator of their own (ctypes callers) */
 int fpt_dev_alloc(fpt_ctx *ctx, int64_t bytes, void **dev_out);
 int fpt_dev_free(fpt_ctx *ctx, void *dev);

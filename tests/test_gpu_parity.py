@@ -1827,6 +1827,9 @@ def test_segment_device(fpt):
     assert sc.segment(np.ones(10), 0.5, 3, True, interval_len=10)["start"].size == 0
 
 
+_huge_fallbacks = []  # (seed, interval, scale, error) of every use of test_fused_scan_fuzz's conditioning allowance
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "12"))))
 def test_fused_scan_fuzz(fpt, orc, seed):
     """random geometry (ragged lengths incl. multi-tile ones), window widths, clip, scales, count
@@ -1887,7 +1890,11 @@ def test_fused_scan_fuzz(fpt, orc, seed):
         assert rel_err(out["pval"][sl], p) < P_TOL, tag
         for s_i, hs in enumerate(scales):
             err = rel_err(out["winp"][s_i, sl], wp[s_i])
-            if err >= P_TOL and kind == "huge":
+            if err >= P_TOL:
+                # the one allowance of the suite, asserted rather than keyed on the case's name: the interval
+                # really holds an observed count of 2^20 or more, and how often it is taken is recorded
+                assert kind == "huge" and float(np.max(cp[a:b])) >= 2.0 ** 20, tag
+                _huge_fallbacks.append((seed, i, s_i, err))
                 # Counts of 2^20 .. 2^26: incbet's exponents amplify the last bits of its libm calls (the
                 # p-values still agree to 3e-8, seed 49), and a window takes z = ndtri(1 - p) of a p next
                 # to 1, which amplifies once more -- the composition is ill-conditioned in any double
@@ -1895,6 +1902,22 @@ def test_fused_scan_fuzz(fpt, orc, seed):
                 # over the DEVICE's p-values (each function inside the contract, p above, windows here).
                 err = rel_err(out["winp"][s_i, sl], orc.window("stouffers_z", out["pval"][sl], hs))
             assert err < P_TOL, tag
+
+
+def test_fused_scan_fuzz_allowance_report():
+    """runs after the fuzz cases (file order): prints how often the ill-conditioned-window allowance was
+    taken -- with the default seeds: never"""
+    print("huge-count window allowance taken %d time(s): %s" % (len(_huge_fallbacks), _huge_fallbacks[:8]))
+    assert len(_huge_fallbacks) <= max(1, int(os.environ.get("FPT_FUZZ_SEEDS", "12")) // 10)
+
+
+_LEAN_LENS = [3, 40, 64, 128, 129, 130, 192, 193, 256, 257, 384, 385, 400, 500, 512, 513, 600, 768, 769,
+              900, 1000, 1024, 1025, 1800]
+# the one-wavefront-per-interval kernel: its size limits (139 / 203 / 267 bases), the lengths at which a
+# row of positions, of base slots, of propensities or of window starts is added or dropped (L + 117,
+# L + 111, L + 6, L + 60, L + 5 crossing a multiple of 64), and a few intervals beyond it
+_WAVE_LENS = [1, 2, 4, 5, 6, 7, 11, 17, 50, 57, 58, 59, 64, 68, 69, 75, 76, 81, 82, 100, 121, 122, 123, 128, 132,
+              133, 139, 140, 141, 145, 146, 186, 187, 196, 197, 203, 204, 209, 210, 250, 251, 260, 261, 267, 268, 300, 700]
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "16"))))
@@ -1905,8 +1928,76 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
     both (exp, obs) tables, N / lower-case bases, every tile class and multi-tile intervals, up to
     seven scales incl. wide ones, several dispersion models -- whatever it keeps and whatever it
     hands to the general kernel must equal the oracle."""
+    _first_pass_fuzz_case(fpt, orc, 7000 + seed, _LEAN_LENS, None)
+
+
+_wave_ctx = {}
+
+
+def _ctx_with_wave(fpt, rp):
+    """a context of its own whose short-interval classes go to k_scan_wave<4..rp> (0: none); the switch is
+    read when a context is made"""
+    if rp not in _wave_ctx:
+        old = os.environ.get("FPT_SCAN_WAVE")
+        os.environ["FPT_SCAN_WAVE"] = str(rp)
+        try:
+            _wave_ctx[rp] = fpt.Context(0)
+        finally:
+            if old is None:
+                del os.environ["FPT_SCAN_WAVE"]
+            else:
+                os.environ["FPT_SCAN_WAVE"] = old
+    return _wave_ctx[rp]
+
+
+@pytest.mark.parametrize("rp", [4, 5, 6, 0])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "12"))))
+def test_wave_kernel_fuzz(fpt, orc, seed, rp):
+    """The same cases on SHORT intervals, where the first pass is one wavefront per interval
+    (fpt_scan_wave.hip, k_scan_wave<4 / 5 / 6>: up to 139 / 203 / 267 bases): every length at which the
+    kernel adds or drops a row, the class limits and one past them, with each set of wave classes
+    switched on (rp = 0: none -- the same batches through k_scan_lean)."""
+    _first_pass_fuzz_case(fpt, orc, 9000 + seed, _WAVE_LENS, _ctx_with_wave(fpt, rp), n_iv_max=40)
+
+
+def test_wave_kernel_uniform_and_models(fpt, orc):
+    """uniform batches (no offset array) of short intervals through the wave kernel, with per-interval
+    dispersion models, one narrow scale / five scales / none"""
     from footprint_tools_amd.scan import FootprintScanner
-    rs = np.random.RandomState(7000 + seed)
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    hw, shw, clip, pad = 5, 50, 0.01, 55
+    models = [_DM(lat["mu_" + k], lat["r_" + k]) for k in "ABC"]
+    for L, scales in ((139, (3,)), (100, (3, 5, 10, 20, 40)), (57, ()), (203, (3,)), (267, (1, 70))):
+        n_iv = 37
+        l = L + 2 * pad + 1
+        cp, cm = orc.synth_counts(5, 0, n_iv * l, 0), orc.synth_counts(5, 0, n_iv * l, 1)
+        sq = orc.synth_bases(5, 0, n_iv * (l + 6))
+        ids = (np.arange(n_iv) % 3).astype(np.int32)
+        sc = FootprintScanner(table, models, hw, shw, clip, scales, nb_mode="memo", ctx=_ctx_with_wave(fpt, 6))
+        out = sc.scan(cp, cm, sq, interval_len=L, dm_ids=ids)
+        for i in range(n_iv):
+            m = models[ids[i]]
+            e, o, p, wp = orc.detect_batch(cp[i * l:(i + 1) * l], cm[i * l:(i + 1) * l], sq[i * (l + 6):(i + 1) * (l + 6)], 1, L,
+                                           hw, shw, clip, table, m.mu_params, m.r_params, np.array(scales, np.int32))
+            sl = slice(i * L, (i + 1) * L)
+            assert np.array_equal(out["exp"][sl], e) and np.array_equal(out["obs"][sl], o), (L, i)
+            assert rel_err(out["pval"][sl], p) < P_TOL, (L, i)
+            for s_i in range(len(scales)):
+                assert rel_err(out["winp"][s_i, sl], wp[s_i]) < P_TOL, (L, i, s_i)
+        # (models B and C have pairs with a non-finite z inside the table: those intervals go to the general
+        # kernel.)  Model A alone on these counts: nothing is handed on
+        sc1 = FootprintScanner(table, models[0], hw, shw, clip, scales, nb_mode="memo", ctx=_ctx_with_wave(fpt, 6))
+        out1 = sc1.scan(cp, cm, sq, interval_len=L)
+        assert sc1.ctx.scan_stats()[1] == 0, L
+        keep = np.repeat(ids == 0, L)
+        assert np.array_equal(out1["exp"][keep], out["exp"][keep]) and np.array_equal(out1["pval"][keep], out["pval"][keep])
+
+
+def _first_pass_fuzz_case(fpt, orc, rs_seed, len_choices, ctx, n_iv_max=20):
+    from footprint_tools_amd.scan import FootprintScanner
+    seed = rs_seed
+    rs = np.random.RandomState(rs_seed)
     lat = golden("nb_lattice.npz")
     table = golden("kmer_probs.npz")["table"]
     hw, shw, clip, pad = 5, 50, 0.01, 55
@@ -1915,9 +2006,8 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
     if rs.rand() < 0.3:
         scales = (3, 5, 10, 20, 40)
     dm = str(rs.choice(["A", "A", "B", "C"]))
-    n_iv = int(rs.randint(4, 20))
-    lens = rs.choice([3, 40, 64, 128, 129, 130, 192, 193, 256, 257, 384, 385, 400, 500, 512, 513, 600, 768, 769,
-                      900, 1000, 1024, 1025, 1800], n_iv)
+    n_iv = int(rs.randint(4, n_iv_max))
+    lens = rs.choice(len_choices, n_iv)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     n_c = int(off[-1] + n_iv * (2 * pad + 1))
     n_s = int(off[-1] + n_iv * (2 * pad + 7))
@@ -1964,7 +2054,7 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
     sq = rs.choice(np.frombuffer(alphabet, np.uint8), n_s)
     if rs.rand() < 0.3:
         sq[rs.randint(0, n_s - 40):][:40] = ord("A")  # homopolymer: P/Q = 1/10 exactly, ties possible
-    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales, nb_mode="memo")
+    sc = FootprintScanner(table, _DM(lat["mu_" + dm], lat["r_" + dm]), hw, shw, clip, scales, nb_mode="memo", ctx=ctx)
     out = sc.scan(cp, cm, sq, interval_off=off)
     tiles, redone, miss = sc.ctx.scan_stats()
     tag = (seed, kind, scales, dm, lens.tolist(), tiles, redone)
