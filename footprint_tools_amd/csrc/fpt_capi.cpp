@@ -89,9 +89,10 @@ struct fpt_ctx {
     bool posterior_direct = false;  // FPT_POSTERIOR_TABLES=0: every log-pmf evaluated in the kernel (tests compare the two)
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
-    // size classes of a batch's tiles; FPT_SCAN_WAVE = 0 / 4 / 5 / 6: whole intervals of up to 139 / 203 / 267
-    // bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip), read at creation
-    fptk::lean_class_set classes = fptk::make_lean_classes(4);
+    // size classes of a batch's tiles; FPT_SCAN_WAVE = 4 / 5 / 6 (read at creation): whole intervals of up to
+    // 139 / 203 / 267 bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip).  Off by
+    // default: measured level with k_scan_lean's 128- and 192-lane classes, not ahead of them
+    fptk::lean_class_set classes = fptk::make_lean_classes(0);
     bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even

@@ -181,12 +181,14 @@ __device__ __forceinline__ void wave_interval(wave_kargs *ka, kcoef *kc, double 
     bad |= (frac_bits | seq_bad) != 0 || cmax > kCountMax;
     wave_sync();
 
-    // ---- B1: the table gathers of every row go out first (one trip to L2 for all of them)
+    if (LEAN_STOP(1)) return;
+    // ---- B1: the propensities.  The table gathers of TWO rows are in flight at a time (eight registers;
+    //      all rows at once held sixteen through the scans and cost a wavefront per SIMD): issued ahead of
+    //      the scans of their rows, written to LDS (positions [40, 40 + PN)) behind them
     double2 tt[RP];
-#pragma unroll
-    for (int i = 0; i < RP; ++i) {
+    auto gather = [&](int i) {
         tt[i] = make_double2(0.0, 0.0);
-        if (i <= prow_last) {
+        if (i == 0 || i <= prow_last) {
             const bool low = lane < 32;
             const u32 sh = (u32)lane & 31u;
             const u32 a0 = low ? (u32)m0[i] : (u32)(m0[i] >> 32), b0 = low ? (u32)(m0[i] >> 32) : (u32)m0[i + 1];
@@ -195,7 +197,16 @@ __device__ __forceinline__ void wave_interval(wave_kargs *ka, kcoef *kc, double 
             const u32 f1 = __builtin_amdgcn_alignbit(b1, a1, sh) & 63u;
             tt[i] = a.table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1])
         }
-    }
+    };
+    auto put = [&](int i) {
+        if (i == 0 || i <= prow_last) {
+            const int idx = i * 64 + lane - LY::kP0;
+            if (idx >= 0 && idx < LY::PN) {
+                PP[idx] = tt[i].x;
+                PM[idx] = tt[i].y;
+            }
+        }
+    };
 
     // ---- B2: 2*hw window sums and their scans, all in registers
     u32 Wk[RP], Ap[RP], Am[RP], pe_p[RP], pe_m[RP], se_p[RP], se_m[RP];
@@ -206,6 +217,10 @@ __device__ __forceinline__ void wave_interval(wave_kargs *ka, kcoef *kc, double 
     for (int i = 0; i < RP; ++i) {
         Wk[i] = Ap[i] = Am[i] = pe_p[i] = pe_m[i] = se_p[i] = se_m[i] = 0;
         Tp[i] = Tm[i] = 0;
+        if ((i & 1) == 0) {
+            gather(i);
+            if (i + 1 < RP) gather(i + 1);
+        }
         if (i < 2 || i < nrow_w) {  // (rows 0 and 1 always hold window sums: nc >= 112)
             const u32 *pw = pk + 8 + i * 64 + lane - kHW;
             u32 W = pw[0];
@@ -247,6 +262,13 @@ __device__ __forceinline__ void wave_interval(wave_kargs *ka, kcoef *kc, double 
             const unsigned long long eM = __ballot((d >> 16) < min(wm, 1u));
             run_bits = max(run_bits, (u32)__builtin_popcountll(eP | eM));
         }
+        if ((i & 1) == 1 || i + 1 == RP) {
+            if (i & 1) put(i - 1);
+            put(i);
+        }
+        // rows are independent, and left alone the scheduler runs them side by side: 20 more registers,
+        // two wavefronts per SIMD fewer.  Other wavefronts fill this one's gaps, not its own next row.
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (run_bits >= 16) {  // (scalar) the exact search: runs inside every tile, then runs across two tiles
         u32 w_first[RP], w_last[RP], w_runs[RP];
@@ -275,19 +297,15 @@ __device__ __forceinline__ void wave_interval(wave_kargs *ka, kcoef *kc, double 
             bad |= crossP | crossM;
         }
     }
-    // the propensities of positions [40, 40 + PN) to LDS (the gathers have had the scans to arrive)
-#pragma unroll
-    for (int i = 0; i < RP; ++i) {
-        if (i <= prow_last) {
-            const int idx = i * 64 + lane - LY::kP0;
-            if (idx >= 0 && idx < LY::PN) {
-                PP[idx] = tt[i].x;
-                PM[idx] = tt[i].y;
-            }
-        }
-    }
     wave_sync();
 
+    if (LEAN_STOP(2)) {  // (keeps the scans alive)
+        u32 x = 0;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) x += Wk[i] + Ap[i] + Am[i] + pe_p[i] + pe_m[i] + se_p[i] + se_m[i] + Tp[i] + Tm[i];
+        if (x == 0x12345678u) a.redo[tile] = 1;
+        return;
+    }
     // ---- C / D per base row: slot u = t + 6 is where the smoothing windows [u, u + 100] of BOTH strands
     //      of base t start ('+' at padded position 56 + t, '-' at 55 + t staged one to the right;
     //      detect.py:121-122); the window ends one row and 36 lanes further on
@@ -449,7 +467,14 @@ __global__ void __launch_bounds__(64) k_scan_wave(const lean_args a) {
     kcoef *kc = &ka->c;
     const int lane = threadIdx.x;
     const int per = ka->tiles_per_wave;
-    const int64_t begin = ka->tile_first + (int64_t)blockIdx.x * per;
+    // Workgroup b runs on XCD b mod 8 (round-robin dispatch; speed only, nothing depends on it): XCD x takes
+    // the x-th eighth of the table, in order, so that intervals that are neighbours in memory -- they share the
+    // 128-byte lines at their ends, inputs and tracks alike -- meet in ONE L2 within microseconds instead of
+    // being written back as partial lines by two of them
+    // (the grid is a multiple of 8 then; slots beyond the table do nothing)
+    const u32 b = blockIdx.x, per_xcd = gridDim.x >> 3;
+    const u32 slot = ka->xcd_map ? (b & 7u) * per_xcd + (b >> 3) : b;
+    const int64_t begin = ka->tile_first + (int64_t)slot * per;
     const int64_t end = min(ka->tile_first + ka->tile_count, begin + per);
     for (int64_t t = begin; t < end; ++t) {
         // (the lane number passes an empty asm too: everything derived from it -- LDS addresses, fetch
@@ -494,7 +519,10 @@ void launch_scan_wave(hipStream_t st, int rp, int n_tiles, const scan_launch &sl
     if (const char *e = getenv("FPT_WAVE_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
     a.tile_count = n_tiles;
     a.tiles_per_wave = tpw;
-    const int grid = (int)((n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave);
+    a.xcd_map = 1;
+    if (const char *e = getenv("FPT_XCD_MAP")) a.xcd_map = atoi(e);
+    int grid = (int)((n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave);
+    if (a.xcd_map) grid = (grid + 7) & ~7;
     hipLaunchKernelGGL(wave_kernel(rp), dim3(grid), dim3(64), scan_wave_lds_bytes(rp), st, a);
 }
 
