@@ -246,7 +246,10 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-box-stream", action="store_true",
                     help="N=1: do not time the scan's access pattern without arithmetic (roofline.box_stream_GBps)")
-    ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the p-value track all-gather")
+    ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the assembly of the p-value track (same as --assembly none)")
+    ap.add_argument("--assembly", default="allgather", choices=["allgather", "gather", "none"],
+                    help="N>1: how the per-base track is re-assembled -- every rank gets it (one RCCL all-gather: BASELINE.json's "
+                         "wording, the default), rank 0 gets it (grouped send / recv to the rank that writes), or not at all")
     ap.add_argument("--allgather", action="store_true",
                     help="N=1: run the track all-gather anyway, on a one-rank RCCL communicator")
     ap.add_argument("--share-gpu", action="store_true",
@@ -297,8 +300,13 @@ def main():
         models = [variant(k) for k in range(n_models)]
     sc = FootprintScanner(table, models, HW, SHW, CLIP, scales, ctx=ctx, nb_mode=args.nb_mode)
     comm = None
-    do_gather = (world > 1 and not args.no_allgather and not args.share_gpu) or (world == 1 and args.allgather)
-    if (world > 1 and not args.share_gpu) or do_gather:
+    if args.no_allgather:
+        args.assembly = "none"
+    # (--share-gpu: ranks on one GPU, which RCCL refuses -- unless FPT_RCCL_LIB binds the test suite's stand-in)
+    can_comm = not args.share_gpu or bool(os.environ.get("FPT_RCCL_LIB"))
+    do_gather = (world > 1 and args.assembly != "none" and can_comm) or (world == 1 and args.allgather)
+    to_root = args.assembly == "gather"  # the track on rank 0 only
+    if (world > 1 and can_comm) or do_gather:
         from footprint_tools_amd.distributed import TrackComm
         comm = TrackComm(ctx, rank, world)  # RCCL, bound by the library; no torch
     ragged = L == 0
@@ -331,10 +339,14 @@ def main():
     d_cp, d_cm = DeviceArray(ctx, n_counts * 8), DeviceArray(ctx, n_counts * 8)
     d_sq = DeviceArray(ctx, n_seq)
     d_out = DeviceArray(ctx, (3 + S) * total * 8)   # exp, obs, winp[S], p (unless it lives in the gathered track)
-    d_gather = DeviceArray(ctx, total_all * 8) if do_gather else None
-    # the p-value track of the resident batch: with a gather it is written straight into its
-    # slice of the gathered track (the collective runs in place)
-    my_off = int(sum(counts[:rank])) * 8
+    # the assembled track, twice (the overlapped leg sends one while the next batch is scanned into the
+    # other); a rank that only sends (gather to rank 0) needs its own slice only.  The p-value track of
+    # the resident batch is written straight into its slice of the assembled track: the collective runs
+    # in place
+    holds_all = do_gather and (not to_root or rank == 0)
+    my_off = int(sum(counts[:rank])) * 8 if holds_all else 0
+    d_gathers = [DeviceArray(ctx, (total_all if holds_all else max(total, 1)) * 8) for _ in range(2)] if do_gather else None
+    d_gather = d_gathers[0] if do_gather else None
     p_p = d_gather.ptr + my_off if do_gather else d_out.ptr + (2 + S) * total * 8
     p_cp, p_cm, p_sq, p_out = d_cp.ptr, d_cm.ptr, d_sq.ptr, d_out.ptr
     d_off = d_dm = d_efdr = None
@@ -362,13 +374,15 @@ def main():
         p_p = d_pv.ptr
         bases_before = int(lens_all[:a_iv].sum())
 
-    def step_once():
+    def step_once(bi=0):
+        """one step; bi: which of the two assembled-track buffers takes this step's track"""
+        shift = d_gathers[bi].ptr - d_gathers[0].ptr if do_gather else 0
         sc.scan_dev(n_iv, p_cp, p_cm, p_sq, exp_out=p_out, obs_out=p_out + t8,
-                    pval_out=p_p, winp_out=p_out + 2 * t8 if S else None,
+                    pval_out=p_p + (0 if fdr_times else shift), winp_out=p_out + 2 * t8 if S else None,
                     interval_len=None if ragged else L, interval_off_dev=d_off.ptr if ragged else None,
                     interval_off_host=off if ragged else None, dm_ids_dev=d_dm.ptr if d_dm else None)
         if fdr_times:  # detect.py:132-135; null draws keyed by the GLOBAL base index
-            sc.fdr_dev(n_iv, p_out, p_out + 2 * t8, p_track, times=fdr_times, seed=1, half_win_width=scales[0],
+            sc.fdr_dev(n_iv, p_out, p_out + 2 * t8, p_track + shift, times=fdr_times, seed=1, half_win_width=scales[0],
                        interval_off_dev=d_off.ptr, base_index0=bases_before, dm_ids_dev=d_dm.ptr if d_dm else None,
                        obs=p_out + t8, interval_off_host=off)
 
@@ -377,10 +391,18 @@ def main():
         if comm is not None:
             comm.barrier()
 
-    def gather_track():
-        """The one collective of the job: every rank ends up with the whole p-value track."""
-        if do_gather:
-            comm.allgather_dev(p_track if fdr_times else p_p, counts, d_gather.ptr)
+    def gather_track(bi=0, overlapped=False):
+        """The one collective of the job: the whole track on every rank (all-gather), or on rank 0 (gather);
+        `overlapped`: on the communicator's own stream, behind this step's scan and beside the next one"""
+        if not do_gather:
+            return
+        shift = d_gathers[bi].ptr - d_gathers[0].ptr
+        send = (p_track if fdr_times else p_p) + shift
+        recv = d_gathers[bi].ptr if holds_all else None
+        if to_root:
+            (comm.gather_dev_async if overlapped else comm.gather_dev)(send, counts, recv, root=0)
+        else:
+            (comm.allgather_dev_async if overlapped else comm.allgather_dev)(send, counts, recv)
 
     cold_tables = [False]  # heavy-tailed leg: empty the kept second-level table before every call
 
@@ -407,7 +429,25 @@ def main():
         seq_ms, main_ms = ctx.timing_read()
         return t2 - t0, main_ms, seq_ms, t1 - t0, t2 - t1
 
+    def measure_overlapped(steps):
+        """every step's track assembled, on the communicator's stream beside the next step's scan: two
+        track buffers in turn, the scan into a buffer waits for the collective that last read it"""
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            comm.wait(back=1)
+            step_once(k % 2)
+            gather_track(k % 2, overlapped=True)
+        comm.synchronize()
+        sync()
+        return time.perf_counter() - t0
+
     dt, kernel_ms, seq_ms, dt_scan, dt_gather = measure(args.steps, args.warmup)
+    dt_asm = measure_overlapped(args.steps) if do_gather else None
+    if do_gather:  # leave the resident batch's track assembled in buffer 0 for the checks below
+        step_once(0)
+        gather_track(0)
+        sync()
     other = None
     if world == 1 and not args.no_other_mode:  # the other evaluation mode, reported beside the headline
         main_mode = sc.nb_mode
@@ -425,6 +465,8 @@ def main():
         dt = comm.max_over_ranks(dt)
         dt_scan = comm.max_over_ranks(dt_scan)
         dt_gather = comm.max_over_ranks(dt_gather)
+        if dt_asm is not None:
+            dt_asm = comm.max_over_ranks(dt_asm)
 
     # ---- parity spot check outside the timed region (oracle = checker only)
     parity = None
@@ -694,12 +736,27 @@ def main():
                                     if ragged else "rank r owns intervals [r*n, (r+1)*n) of the global job"),
                        "allgather_p_track": bool(do_gather),
                        "allgather": ("RCCL (librccl.so bound by libfpt_hip, no torch), %s, once after the %d steps, "
-                                     "inside the timed region" % ("ragged shards: grouped ncclBroadcast" if ragged
-                                                                  else "ncclAllGather", args.steps))
+                                     "inside the timed region" % (("to rank 0: grouped ncclSend / ncclRecv" if to_root else
+                                                                   "ragged shards: grouped ncclBroadcast" if ragged
+                                                                   else "ncclAllGather"), args.steps))
                        if do_gather else None},
             "roofline": roof,
-            "multi_gpu": (dict(scan_s=dt_scan, allgather_s=dt_gather, allgather_bytes_per_rank=total_all * 8,
+            # `value` above: K scans, then ONE assembly of the resident batch's track, inside the timed region
+            # (north_star: "a single RCCL all-gather at the end").  Beside it, separately: the scans alone
+            # (what weak-scaling efficiency of the path itself is computed from), and a job that assembles
+            # EVERY step's track on the communicator's own stream while the next step is scanned
+            "multi_gpu": (dict(assembly=args.assembly if do_gather else "none", steps=args.steps,
+                               scan_s=dt_scan, allgather_s=dt_gather, allgather_bytes_per_rank=total_all * 8,
                                allgather_GBps_per_rank=(total_all * 8 / dt_gather / 1e9 if dt_gather > 0 else None),
+                               assembled_bytes_received=dict(
+                                   allgather_every_rank=(total_all - total) * 8, gather_root=(total_all - counts[0]) * 8),
+                               scan_only=dict(value=total_all * args.steps / dt_scan, unit="bases/s",
+                                              ms_per_step=dt_scan / args.steps * 1e3),
+                               with_assembly=(dict(value=total_all * args.steps / dt_asm, unit="bases/s",
+                                                   ms_per_step=dt_asm / args.steps * 1e3, overlapped=True,
+                                                   note="every step's track assembled (%s) on the communicator's stream beside "
+                                                        "the next step's scan, two track buffers in turn" % args.assembly)
+                                              if dt_asm else None),
                                bases_per_rank=counts)
                           if (world > 1 or do_gather) else None),
             "cpu_baseline": base,
@@ -711,8 +768,9 @@ def main():
             "parity": parity,
         }
         if args.share_gpu and world > 1:  # a smoke test of the launcher path, not a measurement
-            out["invalid"] = ("--share-gpu: %d ranks on one GPU, no communicator, ranks neither synchronised nor "
-                              "their times combined: `value` is rank 0's own time scaled by the rank count" % world)
+            out["invalid"] = ("--share-gpu: %d ranks on ONE GPU (%s): not a scaling measurement" % (
+                world, "collectives through the test suite's librccl stand-in" if comm is not None else
+                "no communicator, ranks neither synchronised nor their times combined"))
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()

@@ -24,7 +24,8 @@ EXPORTS = [
     "fpt_dev_zero", "fpt_format_stats", "fpt_format_stats_batch", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
-    "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track",
+    "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
+    "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize",
     "fpt_stream_pattern_dev", "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
@@ -167,6 +168,12 @@ def load():
         L.fpt_comm_init.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
         L.fpt_comm_destroy.argtypes = [vp]
         L.fpt_allgather_track.argtypes = [vp, vp, vp, vp, vp]
+        if hasattr(L, "fpt_gather_track"):  # (absent from older builds loaded through FPT_LIB_PATH for A/B runs)
+            L.fpt_gather_track.argtypes = [vp, vp, vp, vp, vp, i32]
+            L.fpt_allgather_track_async.argtypes = [vp, vp, vp, vp, vp]
+            L.fpt_gather_track_async.argtypes = [vp, vp, vp, vp, vp, i32]
+            L.fpt_comm_wait.argtypes = [vp, vp, i32]
+            L.fpt_comm_synchronize.argtypes = [vp]
         L.fpt_scan_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32 * 2)]
         L.fpt_synth_hotspots_dev.argtypes = [vp, C.c_uint64, i64, i64, i32, i32, vp, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]

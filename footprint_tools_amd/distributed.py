@@ -3,7 +3,9 @@
 Intervals are independent (every window is confined to its own padded interval), so a job is
 split into contiguous interval ranges balanced by padded bases (`scan.shard_intervals`), every
 rank scans its own range with no communication, and the per-base statistics track is
-re-assembled on every rank with ONE collective at the end: an all-gather over RCCL / xGMI.
+re-assembled with ONE collective per batch: an all-gather over RCCL / xGMI (every rank holds the
+track), or a gather to the rank that writes it (`gather_dev`), on the compute stream or -- the
+`_async` forms -- on the communicator's own stream beside the next batch's scan.
 
 RCCL is bound directly by the library (`fpt_comm_*`, `fpt_allgather_track` in include/fpt.h;
 librccl.so through dlopen) -- no PyTorch, no MPI.  The only thing the host program has to carry
@@ -33,6 +35,13 @@ def shard_track_sizes(lengths, bounds):
     """bases owned by each rank given interval lengths and [(first, last), ...] ranges."""
     lengths = np.asarray(lengths, dtype=np.int64)
     return [int(lengths[a:b].sum()) for a, b in bounds]
+
+
+def shard_offsets(counts):
+    """where each rank's slice starts in the assembled track: world_size + 1 offsets (the last one is the
+    track's length) -- what fpt_allgather_track / fpt_gather_track use for `recv`, and what a caller
+    needs to place its own slice for the in-place forms"""
+    return np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))]).astype(np.int64)
 
 
 def rank_info():
@@ -203,6 +212,33 @@ class TrackComm(object):
             raise ValueError("need one count per rank")
         _lib.check(self.L.fpt_allgather_track(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr))
 
+    def gather_dev(self, send_ptr, counts, recv_ptr, root=0):
+        """The same shards to ONE rank (the writer): recv_ptr is read on `root` only (None elsewhere)."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if counts.size != self.world:
+            raise ValueError("need one count per rank")
+        _lib.check(self.L.fpt_gather_track(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr, int(root)))
+
+    def allgather_dev_async(self, send_ptr, counts, recv_ptr):
+        """allgather_dev on the communicator's own stream, behind what the context's stream holds now:
+        the track of one batch travels while the next is scanned (into another buffer).  `wait` /
+        `synchronize` before the buffers are touched again."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        _lib.check(self.L.fpt_allgather_track_async(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr))
+
+    def gather_dev_async(self, send_ptr, counts, recv_ptr, root=0):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        _lib.check(self.L.fpt_gather_track_async(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr, int(root)))
+
+    def wait(self, back=0):
+        """the context's stream waits for an asynchronous collective: the last one enqueued (back=0), the
+        one before it (1: what a job with two track buffers in turn waits for before its next scan), ..."""
+        _lib.check(self.L.fpt_comm_wait(self.ctx.h, self.h, int(back)))
+
+    def synchronize(self):
+        """the host waits for the last asynchronous collective"""
+        _lib.check(self.L.fpt_comm_synchronize(self.h))
+
     def allgather_host(self, value):
         """one double per rank -> list of all ranks' values (a tiny all-gather; synchronises)"""
         mine = np.array([float(value)])
@@ -272,29 +308,3 @@ def sharded_deviation_stats(intervals, read_func, fasta_func, bm, dm, gather=Non
         full = gather(local, counts)
     off = np.concatenate([[0], np.cumsum(lens)])
     return [{"interval": iv, "stats": full[off[i]:off[i + 1]]} for i, iv in enumerate(ds.intervals)]
-
-
-def allgather_track(local, sizes, group=None):
-    """torch.distributed form of the same collective, for hosts that already run a process group
-    (and for the CPU test of the host logic with the gloo backend): all-gather the ranks' track
-    slices into the whole track.  Ragged slices are padded to the longest one."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    sizes = [int(s) for s in sizes]
-    if len(sizes) != world:
-        raise ValueError("need one slice size per rank")
-    if local.numel() != sizes[rank]:
-        raise ValueError("local slice has %d elements, expected %d" % (local.numel(), sizes[rank]))
-    m = max(sizes)
-    if min(sizes) == m:
-        out = torch.empty(world * m, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
-    padded = torch.zeros(m, dtype=local.dtype, device=local.device)
-    padded[:sizes[rank]] = local
-    buf = torch.empty(world * m, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, padded, group=group)
-    return torch.cat([buf[r * m:r * m + sizes[r]] for r in range(world)])

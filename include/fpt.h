@@ -454,7 +454,8 @@ int fpt_track_writer_close(fpt_track_writer *w);
  * Intervals shard across GPUs with no communication during the scan (one process and one
  * context per GPU); afterwards every rank contributes its slice of a per-base track and receives
  * all slices in rank order.  RCCL is bound directly (librccl.so through dlopen at the first
- * call): rank 0 makes an id with fpt_comm_unique_id, the host program carries the 128 bytes to
+ * call; FPT_RCCL_LIB names another library with the same entry points -- the test suite's stand-in):
+ * rank 0 makes an id with fpt_comm_unique_id, the host program carries the 128 bytes to
  * the other ranks (file, socket, environment), every rank calls fpt_comm_init.
  * Reference counterpart: the worker processes of cli/detect.py:380-411 hand their per-interval
  * statistics to one writer; nothing in the reference exchanges arrays between devices. */
@@ -468,6 +469,22 @@ int fpt_comm_destroy(fpt_comm *comm);
  * inside recv at its own offset).  Equal counts: one ncclAllGather; ragged: one ncclBroadcast per
  * shard inside a group.  Enqueued on the context's stream; does not synchronise. */
 int fpt_allgather_track(fpt_ctx *ctx, fpt_comm *comm, const double *send, const int64_t *counts, double *recv);
+/* The same shards to ONE rank -- the rank that writes the track, as the reference's single writer
+ * thread does (cli/detect.py:396-408): grouped ncclSend / ncclRecv.  `recv` (sum(counts) doubles) is
+ * read on the root only and may be NULL elsewhere; the root's own shard may already lie in place.
+ * 1/world_size of the all-gather's traffic; all of it arrives on the root's links. */
+int fpt_gather_track(fpt_ctx *ctx, fpt_comm *comm, const double *send, const int64_t *counts, double *recv, int root);
+/* Both collectives beside the scan of the NEXT batch: enqueued on the communicator's own stream,
+ * ordered behind everything the context's stream holds at the call (an event), so the track of batch k
+ * travels while batch k + 1 is scanned into another buffer.  fpt_comm_wait makes the context's stream
+ * wait for one of them -- back = 0: the last one enqueued, 1: the one before it, up to 3 (with two
+ * track buffers in turn, wait with back = 1 before scanning into a buffer again: its collective was
+ * the one before the last); fpt_comm_synchronize blocks the host until the last one is done.  Neither
+ * is needed for the plain forms. */
+int fpt_allgather_track_async(fpt_ctx *ctx, fpt_comm *comm, const double *send, const int64_t *counts, double *recv);
+int fpt_gather_track_async(fpt_ctx *ctx, fpt_comm *comm, const double *send, const int64_t *counts, double *recv, int root);
+int fpt_comm_wait(fpt_ctx *ctx, fpt_comm *comm, int back);
+int fpt_comm_synchronize(fpt_comm *comm);
 
 /* Diagnostics of the most recent fpt_scan_dev in memo mode (synchronises): tiles launched, tiles
  * the first pass handed to the general kernel, and the largest (exp, obs) pair that missed the

@@ -1,0 +1,71 @@
+"""Two ranks on ONE GPU through the librccl stand-in (tests/fakerccl): everything of the sharded job
+but RCCL itself with a rank > 0 -- TrackComm's rendezvous, shard offsets, the all-gather and the gather
+to a root in place and out of place, their asynchronous forms, `bench.py --gpus 2`.  Sorts early on
+purpose (after test_aa_): the children are started before this process has touched the GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+FAKE = os.path.join(ROOT, "tests", "fakerccl", "libfakerccl.so")
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(argv, world, extra_env, timeout=900):
+    port = str(_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   FPT_RCCL_LIB=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0", FPT_COMM_TIMEOUT_S="120", **extra_env)
+        procs.append(subprocess.Popen([sys.executable] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o.decode(), e.decode()))
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["ragged", "uniform"])
+def test_two_ranks_one_gpu_collectives(shape):
+    assert os.path.exists(FAKE), "build tests/fakerccl/libfakerccl.so (python -c 'import __graft_entry__ as g; g.build()')"
+    outs = _spawn([os.path.join(ROOT, "tests", "two_rank_worker.py")], 2, {"FPT_TWO_RANK_SHAPE": shape})
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and ("RANK %d OK" % r) in o, "rank %d: rc %d\n%s\n%s" % (r, rc, o[-1500:], e[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assembly", ["allgather", "gather"])
+def test_bench_two_ranks_one_gpu(assembly):
+    """bench.py --gpus 2 end to end (config 4: ONE global ragged list cut in two, the track assembled):
+    rank 0's line carries the multi-GPU block, and its spot check reads the OTHER rank's slice of the
+    assembled track"""
+    outs = _spawn([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--intervals", "20000", "--steps", "3",
+                   "--warmup", "1", "--share-gpu", "--assembly", assembly], 2, {})
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, "rank %d: rc %d\n%s\n%s" % (r, rc, o[-1500:], e[-3000:])
+    lines = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][1].splitlines() if ln.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity"]["exp_bit_exact"] is True and d["parity"]["p_max_rel_err"] < 1e-6
+    assert d["parity"]["gathered_last_rank_p_max_rel_err"] < 1e-6
+    mg = d["multi_gpu"]
+    assert mg["assembly"] == assembly and mg["steps"] == 3
+    assert mg["scan_only"]["value"] > 0 and mg["with_assembly"]["value"] > 0 and mg["with_assembly"]["overlapped"] is True

@@ -20,7 +20,9 @@ import torch.distributed as dist
 sys.path.insert(0, os.environ["FPT_ROOT"])
 from oracle import oracle
 from footprint_tools_amd.scan import shard_intervals
-from footprint_tools_amd.distributed import allgather_track, shard_track_sizes
+from footprint_tools_amd.distributed import shard_offsets, shard_track_sizes
+sys.path.insert(0, os.path.join(os.environ["FPT_ROOT"], "tests"))
+from torch_gather import allgather_track, gather_track   # torch stand-ins of the two collectives (test infrastructure)
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -51,9 +53,18 @@ def run(first, last):
 a, b = bounds[rank]
 local = torch.from_numpy(run(a, b))
 full = allgather_track(local, sizes).numpy()
-if rank == 0:
-    want = run(0, len(lens))
-    assert full.shape == want.shape and np.array_equal(full, want, equal_nan=True), "gathered track differs"
+want = run(0, len(lens))
+assert full.shape == want.shape and np.array_equal(full, want, equal_nan=True), "gathered track differs"
+# the gather to the rank that writes (fpt_gather_track's shape): the whole track on the root only, every
+# slice at shard_offsets(sizes)
+for root in range(world):
+    got = gather_track(local, sizes, root=root)
+    if rank == root:
+        assert np.array_equal(got.numpy(), want, equal_nan=True), "track gathered to rank %d differs" % root
+        off = shard_offsets(sizes)
+        assert int(off[-1]) == want.size and np.array_equal(got.numpy()[off[rank]:off[rank + 1]], local.numpy(), equal_nan=True)
+    else:
+        assert got is None
 
 # the sharded detect driver's host logic (range per rank, row gather, records of ALL intervals in
 # list order on every rank) with a CPU stand-in for the per-rank GPU driver

@@ -1348,6 +1348,31 @@ def test_rccl_track_allgather_one_rank(fpt, orc, tmp_path):
     assert np.array_equal(comm.allgather_rows(m, [33333]), m)
     with pytest.raises(ValueError):
         comm.allgather_dev(d_s.ptr, [1, 2], d_r.ptr)
+    # the gather to the rank that writes (grouped send / recv; on one rank: the root's own shard), out of
+    # place and in place, and both collectives on the communicator's own stream with two buffers in turn
+    d_r.zero()
+    comm.gather_dev(d_s.ptr, [x.size], d_r.ptr, root=0)
+    ctx.synchronize()
+    assert np.array_equal(d_r.download(np.float64, x.size), x)
+    comm.gather_dev(d_s.ptr, [x.size], d_s.ptr, root=0)  # in place
+    ctx.synchronize()
+    assert np.array_equal(d_s.download(np.float64, x.size), x)
+    with pytest.raises(ValueError):
+        comm.gather_dev(d_s.ptr, [x.size], d_r.ptr, root=1)
+    bufs = [DeviceArray(ctx, x.nbytes).zero(), DeviceArray(ctx, x.nbytes).zero()]
+    for k in range(6):
+        comm.wait(back=1)  # the collective that last read this buffer (none for k < 2)
+        y = x + k
+        src = DeviceArray(ctx, x.nbytes).upload(y)   # (an upload on the compute stream: the collective is ordered behind it)
+        if k % 2:
+            comm.gather_dev_async(src.ptr, [x.size], bufs[k % 2].ptr, root=0)
+        else:
+            comm.allgather_dev_async(src.ptr, [x.size], bufs[k % 2].ptr)
+        comm.synchronize()
+        src.free()
+    assert np.array_equal(bufs[0].download(np.float64, x.size), x + 4) and np.array_equal(bufs[1].download(np.float64, x.size), x + 5)
+    comm.wait(back=0)
+    ctx.synchronize()
     comm.close()
     os.environ["FPT_COMM_RAGGED"] = "1"  # the grouped-broadcast form that ragged shards take (read when the communicator is made)
     try:
