@@ -611,13 +611,13 @@ def main():
         ctx.synchronize()
         # dataset d is scored with model d % n_models (the reference has one model per dataset)
         ds_models = [models[d_ % n_models] for d_ in range(D)] if n_models > 1 else [DM] * D
-        slot = ctx.dispersion_slots([(m.mu_params, m.r_params) for m in ds_models])
+        packed = post_mod.pack_models(ds_models)  # handed over with every call (any number of datasets)
         betas = np.array([[2.0 + 0.5 * d_, 8.0 - 0.5 * d_] for d_ in range(D)])
 
         def post_step():
-            post_mod.posterior_dev(ctx, n_iv, total, D, slot, betas, p_obs, p_exp, p_fdr, p_w, d_post.ptr,
+            post_mod.posterior_dev(ctx, n_iv, total, D, 0, betas, p_obs, p_exp, p_fdr, p_w, d_post.ptr,
                                    interval_off_dev=d_off.ptr, max_interval_len=int(lens.max()), fdr_cutoff=0.05,
-                                   half_win_width=3, status_out=d_st.ptr)
+                                   half_win_width=3, status_out=d_st.ptr, models=packed)
         post_step()
         ctx.synchronize()
         kp = max(3, args.steps // 2)
@@ -630,9 +630,16 @@ def main():
             dtp = comm.max_over_ranks(dtp)
         post = dict(n_datasets=D, launches=kp, ms_per_launch=dtp * 1e3, value=total_all / dtp, unit="bases/s",
                     dataset_bases_per_s=total_all * D / dtp,
-                    bound="fp64 vector ALU: 5 lgam + 2 log + 2 log1p + exp + log1p per dataset-base, 40 B of HBM "
+                    bound="fp64 vector ALU: 2 lgam + log + log1p + two piecewise fits (the occupied form; the unoccupied one "
+                          "and lgam(k + 1) from tables made inside the call) + exp + log1p per dataset-base, 48 B of HBM "
                           "traffic per dataset-base (DESIGN.md, posterior kernel)",
-                    hbm_GBps=total * D * 40.0 / dtp / 1e9)
+                    hbm_GBps=total * D * 48.0 / dtp / 1e9,
+                    # an operation count, not a counter: lgam ~45 flops x 2, log / log1p / exp / log1p ~25 each, the
+                    # fits and p ~15, 2 x 7 window additions, the priors ~30 per dataset -- against the 78.6 TFLOP/s
+                    # of the vector fp64 pipes (the kernel is bound by their instruction issue, divergent branches
+                    # of lgam included, not by flops)
+                    flops_per_dataset_base=270,
+                    fp64_TFLOPs=total_all * D * 270.0 / dtp / 1e12, frac_of_fp64_vector_peak=total_all * D * 270.0 / dtp / 78.6e12)
         if rank == 0:  # one interval against the checker's restatement of cli/post.py:109-122
             from oracle import oracle
             iv = n_iv - 1

@@ -12,7 +12,7 @@ FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
 NB_CDF, NB_LOGPMF, NB_PMF = range(3)
 NB_AUTO, NB_DIRECT, NB_MEMO, NB_NONE = range(4)
-FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8, ndtr_window=9)
+FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8, ndtr_window=9, ndtr_window_tab=10)
 MAX_SCALES = 8
 MAX_DM = 64
 
@@ -104,6 +104,7 @@ class PosteriorDesc(C.Structure):
         ("ll_on_out", C.c_void_p),
         ("ll_off_out", C.c_void_p),
         ("status_out", C.c_void_p),
+        ("models", C.c_void_p),
     ]
 
 
@@ -255,6 +256,7 @@ class Context(object):
         self.L, self.h, self.device = L, h, int(device)
         self._table_key = None
         self._dm_slots = {}
+        self._slot_key = {}  # slot -> the model it holds
         self._dm_lists = {}
         self._dm_next = 0
         self._lock = threading.RLock()
@@ -294,13 +296,14 @@ class Context(object):
         key = (mu.tobytes(), r.tobytes())
         with self._lock:
             slot = self._dm_slots.get(key)
-            if slot is None:
+            if slot is None or self._slot_key.get(slot) != key:
                 slot = self._dm_next % MAX_DM
                 self._dm_next += 1
                 for k in [k for k, v in self._dm_slots.items() if v == slot]:
                     del self._dm_slots[k]
                 check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
                 self._dm_slots[key] = slot
+                self._slot_key[slot] = key
             return slot
 
     def dispersion_slots(self, models):
@@ -313,8 +316,12 @@ class Context(object):
         packed = [(f64(mu).ravel(), f64(r).ravel()) for mu, r in models]
         key = tuple((mu.tobytes(), r.tobytes()) for mu, r in packed)
         with self._lock:
+            # a cached list is valid while every one of its slots still holds its model -- checked by what
+            # the SLOTS hold (a list with the same model twice has two slots for one key: a map from model
+            # to slot cannot vouch for it, and such a list was uploaded again at every call, overwriting
+            # slots a live scanner used)
             hit = self._dm_lists.get(key)
-            if hit is not None and all(self._dm_slots.get(k) == hit + i for i, k in enumerate(key)):
+            if hit is not None and all(self._slot_key.get(hit + i) == k for i, k in enumerate(key)):
                 return hit
             first = 0 if self._dm_next % MAX_DM + n > MAX_DM else self._dm_next % MAX_DM
             for i, (mu, r) in enumerate(packed):
@@ -323,8 +330,9 @@ class Context(object):
                     del self._dm_slots[k]
                 check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
                 self._dm_slots[key[i]] = slot
+                self._slot_key[slot] = key[i]
             self._dm_next = first + n
-            self._dm_lists = {key: first}  # older lists may have been overwritten: keep the newest only
+            self._dm_lists[key] = first
             return first
 
     def synchronize(self):

@@ -449,7 +449,7 @@ int fpt_window(fpt_ctx *c, int op, const double *x, const double *w, int64_t n_r
 int fpt_special(fpt_ctx *c, int fn, const double *a, const double *b, const double *x, int64_t n,
                 double *out) {
     if (int rc = check_ctx(c)) return rc;
-    if (fn < 0 || fn > 9) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
+    if (fn < 0 || fn > 10) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
     if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
     if (n == 0) return FPT_OK;
     if (!a || !out) return fail(FPT_ERR_INVALID, "null buffer");
@@ -1020,10 +1020,14 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     if (int rc = check_ctx(c)) return rc;
     if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
     if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
-    if (d->n_datasets < 1 || d->dm_id < 0 || d->dm_id + d->n_datasets > FPT_MAX_DISPERSION_MODELS)
-        return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range", d->dm_id, d->dm_id + d->n_datasets);
-    for (int i = 0; i < d->n_datasets; ++i)
-        if (!c->have_model[d->dm_id + i]) return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
+    if (d->n_datasets < 1 || d->n_datasets > (1 << 20)) return fail(FPT_ERR_INVALID, "n_datasets %d out of range", d->n_datasets);
+    if (!d->models) {  // the models of the datasets sit in consecutive slots
+        if (d->dm_id < 0 || d->dm_id + d->n_datasets > FPT_MAX_DISPERSION_MODELS)
+            return fail(FPT_ERR_INVALID, "dispersion model slots [%d, %d) out of range (more than %d datasets: pass `models`)",
+                        d->dm_id, d->dm_id + d->n_datasets, FPT_MAX_DISPERSION_MODELS);
+        for (int i = 0; i < d->n_datasets; ++i)
+            if (!c->have_model[d->dm_id + i]) return fail(FPT_ERR_INVALID, "dispersion model %d not set", d->dm_id + i);
+    }
     if (d->half_win_width < 0 || d->half_win_width > 32)
         return fail(FPT_ERR_INVALID, "half window %d out of range", d->half_win_width);
     if (d->n_intervals == 0 || d->total_bases == 0) return FPT_OK;
@@ -1036,10 +1040,13 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     }
     // the Beta priors travel through a small device buffer (slot 6: shared with the FDR pass's
     // lists, both are consumed by the launch that follows on the same stream)
+    // ... and so do models handed over with the call (any number of datasets), behind the priors
     void *d_beta;
-    const size_t nb = (size_t)d->n_datasets * 2 * sizeof(double);
+    const size_t n_beta = (size_t)d->n_datasets * 2, n_par = d->models ? (size_t)d->n_datasets * kModelDoubles : 0;
+    const size_t nb = (n_beta + n_par) * sizeof(double);
     if (int rc = ws_get(c, 6, nb, &d_beta)) return rc;
-    c->beta_host.assign(d->betas, d->betas + (size_t)d->n_datasets * 2);  // stays alive for the async copy
+    c->beta_host.assign(d->betas, d->betas + n_beta);  // stays alive for the async copy
+    if (d->models) c->beta_host.insert(c->beta_host.end(), d->models, d->models + n_par);
     HIP_TRY(hipMemcpyAsync(d_beta, c->beta_host.data(), nb, hipMemcpyHostToDevice, c->stream));
     fptk::posterior_launch pl{};
     pl.n_intervals = d->n_intervals;
@@ -1055,7 +1062,7 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     pl.exp = d->exp;
     pl.fdr = d->fdr;
     pl.w = d->w;
-    pl.models = c->d_models + (size_t)d->dm_id * kModelDoubles;
+    pl.models = d->models ? (const double *)d_beta + n_beta : c->d_models + (size_t)d->dm_id * kModelDoubles;
     pl.betas = (const double *)d_beta;
     pl.post_out = d->post_out;
     pl.prior_out = d->prior_out;

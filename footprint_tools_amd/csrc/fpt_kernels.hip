@@ -164,6 +164,10 @@ __global__ void __launch_bounds__(256, 4) k_nb_scalar(int what, const int32_t *_
     }
 }
 
+// the table of fptm::ndtr_fast_tab (tools/fit_ndtr_gtab.py), for the special-function entry point that
+// checks it; the scan kernels keep their own copy and stage it in LDS
+__device__ const double g_ndtr_gtab[4 * FPT_NDTR_GTAB_N + 1] = {FPT_NDTR_GTAB_LIST};
+
 __global__ void __launch_bounds__(256) k_special(int fn, const double *__restrict__ a,
                                                  const double *__restrict__ b,
                                                  const double *__restrict__ x, int64_t n,
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(256) k_special(int fn, const double *__restric
         case 6: res = fptm::erfc_fn(v); break;
         case 7: res = fptm::incbet(v, b[i], x[i]); break;
         case 9: res = fptm::ndtr_window(v); break;
+        case 10: res = fabs(v) < fptm::kNdtrFastLimit ? fptm::ndtr_fast_tab(v, g_ndtr_gtab) : fptm::ndtr(v); break;
         default: res = fptm::chdtrc(v, x[i]); break;
         }
         out[i] = res;

@@ -24,6 +24,7 @@ struct lean_coef {
     double e[FPT_NDTR_E_N + 1];  // FPT_NDTR_E_LIST times that entry
     double neg_r0, neg_half_log2e;
     double c99, band, limit;
+    double inv_g0;  // 1 / FPT_NDTR_G_LIST[0]: the table of g is staged divided by what e's coefficients carry
 };
 
 struct lean_args {
@@ -132,13 +133,27 @@ __device__ __forceinline__ double horner_e_s(double x, kdouble *c) {
 // zero through ldexp whatever the polynomials extrapolate to (they stay bounded: 1/(t+5) only moves
 // from 0.032 to 0 -- which is also how the sentinel edge slot yields 1.0), so only arguments below
 // -26, where the reference's own value runs into the subnormal range, have to leave this kernel.
-__device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c) {
+// TAB: g from the 256-interval table of fptm::ndtr_fast_tab staged in LDS (`gt`: c3, c2, c1, c0 per
+// interval TIMES the leading coefficient the e chain carries -- see fill_lean_gtab) instead of the
+// 14-step chain: 15 fp64 instructions become 6 fp64 + 2 integer ones and two 16-byte LDS reads.
+template <bool TAB = false>
+__device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c, const double *gt = nullptr) {
     asm volatile("" : "+s"(c) : "v"(a));
     const double t = fabs(a);
     const double d = t + 5.0;
     double r = __builtin_amdgcn_rcp(d);  // 2^-24 (measured 4.6e-8); one Newton step: 2.2e-15
     r = fma(fma(-d, r, 1.0), r, r);
-    const double g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient
+    double g;
+    if (TAB) {
+        const double kf = fma(r, FPT_NDTR_GTAB_SCALE, -(FPT_NDTR_GTAB_XLO * FPT_NDTR_GTAB_SCALE));
+        const int k = min(max((int)kf, 0), FPT_NDTR_GTAB_N - 1);
+        const double w = __builtin_amdgcn_fract(kf);
+        const double2 c32 = *reinterpret_cast<const double2 *>(gt + 4 * k);
+        const double2 c10 = *reinterpret_cast<const double2 *>(gt + 4 * k + 2);
+        g = fma(fma(fma(c32.x, w, c32.y), w, c10.x), w, c10.y);
+    } else {
+        g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient
+    }
     const double q = mul_vs(t * t, c->neg_half_log2e);           // exp(-t^2/2) = 2^q = 2^n 2^(q - n)
     const double n = rint(q);
     const double e = horner_e_s(q - n, c->e);                   // e * that coefficient
@@ -213,10 +228,15 @@ template <int NT>
 __device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *C, double *Z) {
     Z[16 + tid] = zr + C[1 + (tid >> 4)];
 }
-template <int NT, typename Args>
-__device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
+template <int NT, typename Args, bool TAB = false>
+__device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z,
+                                             const double *gt = nullptr) {
     constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
-    double *row = a.winp_out + o.out_off;  // uniform: the store takes it as a scalar base + a 32-bit byte offset per lane
+    // (uniform; typed as GLOBAL memory: behind the empty asm below a generic pointer made the store a
+    // flat_store with a 64-bit vector add for its address -- and flat instructions count in lgkmcnt, which the
+    // next scale's LDS reads wait for; this way it is global_store with the base in scalar registers)
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble *row = (gdouble *)(a.winp_out + o.out_off);
     const u32 t8 = (u32)o.t * 8u;
     // a window of half-width hs fits iff hs <= the distance to the nearer end (-1: not this lane's base)
     const int room = o.mine ? min(o.t, o.L - 1 - o.t) : -1;
@@ -239,9 +259,10 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
         const double sv = *(lds_double *)(size_t)ah - *(lds_double *)(size_t)al;
         const double arg = -(sv * a.scale_rsqrt[s]);  // (the edge lanes' argument is +1e4 / sqrt(K))
         low |= !(arg > neg_limit);
-        const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+        const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s<TAB>(arg, kc, gt);
         asm volatile("" : "+s"(row));  // keeps the scale's base in scalar registers (no per-lane pointer carried through the loop)
-        if (o.mine) store_at(row, t8, pw);
+        // (written out: the compiler forms the address with a 64-bit vector add and stores through it)
+        if (o.mine) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(t8), "v"(pw), "s"(row) : "memory");
         row += stride;
     }
     return low;
@@ -309,6 +330,7 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.c.c99 = (double)(kW - 2);
     a.c.band = 1e-13;
     a.c.limit = fptm::kNdtrFastLimit;
+    a.c.inv_g0 = 1.0 / g[0];
 }
 
 }  // namespace fptlean

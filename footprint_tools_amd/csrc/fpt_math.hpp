@@ -15,6 +15,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "fpt_ndtr_gtab.hpp"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define FPT_HD __host__ __device__ __forceinline__
@@ -551,6 +553,35 @@ FPT_HD double ndtr_fast(double a) {
     // exp(-t^2/2) = 2^q, q = t^2 (-log2(e) / 2) = n + f: f = q - n is exact, and the rounding of q (1e-13
     // absolute at t = 26) is far below the polynomial's error -- no reduction by ln 2 in two parts
     const double q = t2 * kNdtrNegHalfLog2e;
+    const double n = rint(q);
+    const double e = horner<FPT_NDTR_E_N>(q - n, kE);
+    const double y = ldexp(e * g, (int)n);
+    return a > 0.0 ? 1.0 - y : y;
+}
+// The same formula with g read from a TABLE (fpt_ndtr_gtab.hpp, tools/fit_ndtr_gtab.py): 256 intervals of
+// equal width in x = 1/(t + 5), a cubic in the position w inside the interval each -- a multiply-add
+// for the slot, a truncation, a fraction and three multiply-adds in place of the 14-step Horner chain
+// (fp64 instructions run at half the rate of the others on gfx950, tools/micro/issue.hip).  `tab`:
+// FPT_NDTR_GTAB_N x (c3, c2, c1, c0).  Relative error of g 1.2e-11, of the whole 1.4e-11 (measured).
+// Arguments beyond the range index a clamped slot: a > 26 still gives exactly 1 (2^n underflows),
+// a < -26 is handed on by the callers as before.
+FPT_HD double ndtr_fast_tab(double a, const double *tab) {
+    const double kE[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
+    const double t = fabs(a);
+    const double d = t + 5.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+#else
+    const double r = 1.0 / d;
+#endif
+    const double kf = fma(r, FPT_NDTR_GTAB_SCALE, -(FPT_NDTR_GTAB_XLO * FPT_NDTR_GTAB_SCALE));
+    int k = (int)kf;
+    k = k < 0 ? 0 : (k > FPT_NDTR_GTAB_N - 1 ? FPT_NDTR_GTAB_N - 1 : k);
+    const double w = kf - floor(kf);
+    const double *c = tab + 4 * k;
+    const double g = fma(fma(fma(c[0], w, c[1]), w, c[2]), w, c[3]);
+    const double q = (t * t) * kNdtrNegHalfLog2e;
     const double n = rint(q);
     const double e = horner<FPT_NDTR_E_N>(q - n, kE);
     const double y = ldexp(e * g, (int)n);

@@ -22,6 +22,8 @@
 // work, not HBM traffic (40 bytes per dataset-base): see DESIGN.md for the measured rate.
 #include "fpt_kernels.hpp"
 
+#include <cstdlib>
+
 #include "fpt_device.hpp"
 
 using namespace fptd;
@@ -93,17 +95,28 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {
     return t;  // NaN
 }
 
+// datasets whose results are staged in LDS before they are stored (one 64-byte piece of a base's row)
+constexpr int kPostChunk = 8;
+// models and Beta priors are staged in LDS up to this many datasets (26 doubles each); beyond it they
+// are read where they lie (one address per wavefront: L1 / L2 hits) -- any number of datasets runs
+constexpr int kPostLdsModels = 128;
+
 template <int NT>
 __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     extern __shared__ double smem[];
     const int D = a.n_datasets, hw = a.hw;
-    double *par = smem;                  // D x 24
-    double *beta = par + (size_t)D * 24; // D x 2
-    double *lp = beta + (size_t)D * 2;   // [2 buffers][on, off][NT]
+    const bool staged = D <= kPostLdsModels;
+    double *lp = smem;                              // [2 buffers][on, off][NT]
+    double *stage = lp + 4 * NT;                    // [NT][kPostChunk + 1]: the posteriors of a chunk of datasets
+    double *par_lds = stage + NT * (kPostChunk + 1);// D x 24, D x 2 (when staged)
+    const double *par = staged ? par_lds : a.models;
+    const double *beta = staged ? par_lds + (size_t)D * 24 : a.betas;
     const int tid = threadIdx.x;
-    for (int i = tid; i < D * 24; i += NT) par[i] = a.models[i];
-    for (int i = tid; i < D * 2; i += NT) beta[i] = a.betas[i];
-    __syncthreads();
+    if (staged) {
+        for (int i = tid; i < D * 24; i += NT) par_lds[i] = a.models[i];
+        for (int i = tid; i < D * 2; i += NT) par_lds[(size_t)D * 24 + i] = a.betas[i];
+        __syncthreads();
+    }
 
     const int64_t iv = blockIdx.x;
     int64_t off;
@@ -125,7 +138,6 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
         const int64_t g = off + (valid ? u : 0);
         // ---- 1: the priors of this base (both are reductions over the datasets)
         double pr = 1.0, delta = 1.0;
-        unsigned long long uncovered = 0;  // bit d: w[d] == 0 (the prior of that dataset is 1)
         if (valid) {
             double k_called = 0.0, n_cov = 0.0, sw = 0.0, swm = 0.0;
             for (int d = 0; d < D; ++d) {
@@ -134,7 +146,6 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                 const double f = a.fdr[j], ww = a.w[j], o = a.obs[j], e = a.exp[j];
                 if (f <= a.cutoff) k_called += 1.0;
                 n_cov += ww;
-                if (ww == 0.0) uncovered |= 1ull << d;
                 // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean and variance
                 const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
                 double mu = NAN, var = NAN;  // scipy returns NaN for arguments outside the domain
@@ -198,17 +209,35 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                         ll_off += lp_off[j];
                     }
                 }
-                const bool unc = (uncovered >> d) & 1ull;
+                const int64_t j = (int64_t)d * T + g;
+                // (w is read again rather than remembered from the first loop: a bit per dataset in a
+                // register capped the datasets at 64, and the reference's tutorials run hundreds)
+                const bool unc = a.w[j] == 0.0;  // the prior of a dataset without a hotspot here is 1
                 // posterior.py:140-149 with prior = 1 where the dataset has no hotspot (log 0 = -inf)
                 const double p_off = (unc ? 0.0 : log_pr) + ll_off;
                 const double p_on = (unc ? -fptm::kInf : log_1mpr) + ll_on;
                 double post = -(p_off - np_logaddexp(p_on, p_off));
                 if (post <= 0.0) post = 0.0;  // post.py:122 (a NaN stays)
-                a.post_out[g * D + d] = post;
-                const int64_t j = (int64_t)d * T + g;
+                stage[tid * (kPostChunk + 1) + (d % kPostChunk)] = post;
                 if (a.prior_out) a.prior_out[j] = unc ? 1.0 : pr;
                 if (a.ll_on_out) a.ll_on_out[j] = ll_on;
                 if (a.ll_off_out) a.ll_off_out[j] = ll_off;
+            }
+            // The record is base-major -- (sum(L), D), what the reference's writer prints per base -- so a
+            // lane's own store would touch one 64-byte piece per lane and dataset (64 lines per store
+            // instruction).  A chunk of kPostChunk datasets is staged instead and stored with the lanes
+            // ALONG the rows: eight lanes write the 64 contiguous bytes of a base, a wavefront eight bases
+            // (a whole contiguous 512 bytes when there are eight datasets).
+            if ((d % kPostChunk) == kPostChunk - 1 || d == D - 1) {
+                __syncthreads();
+                const int d0 = d - (d % kPostChunk), nd = d - d0 + 1;
+                const int n_out = min(TL, L - t0);          // output bases of this tile: lanes hw .. hw + n_out - 1
+                for (int i = tid; i < n_out * kPostChunk; i += NT) {
+                    const int b = i / kPostChunk, e = i % kPostChunk;
+                    if (e < nd)
+                        a.post_out[(off + t0 + b) * D + d0 + e] = stage[(hw + b) * (kPostChunk + 1) + e];
+                }
+                // (the next chunk's first write to `stage` comes after the next dataset's barrier)
             }
         }
     }
@@ -223,7 +252,9 @@ size_t posterior_table_bytes(int n_datasets) {
     return ((size_t)n_datasets * kTabExp * kTabObs + kTabLgam) * sizeof(double);
 }
 
-size_t posterior_lds_bytes(int n_datasets, int nt) { return (size_t)(n_datasets * 26 + 4 * nt) * sizeof(double); }
+size_t posterior_lds_bytes(int n_datasets, int nt) {
+    return (size_t)((n_datasets <= kPostLdsModels ? n_datasets * 26 : 0) + 4 * nt + nt * (kPostChunk + 1)) * sizeof(double);
+}
 
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     post_args a;
@@ -252,15 +283,21 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     if (pl.off_table && pl.lgam_table)
         hipLaunchKernelGGL(k_posterior_tables, dim3(kTabExp * kTabObs / 256, pl.n_datasets + 1), dim3(256), 0, st, pl.models,
                            pl.n_datasets, pl.off_table, pl.lgam_table);
-    // short intervals (the whole-genome hotspot set averages 162 bases) in 128-lane workgroups,
-    // anything longer in 256-lane ones; an interval longer than 8 tiles is spread over gridDim.y
-    const int nt = pl.max_len + 2 * pl.hw <= 128 ? 128 : 256;
+    // Batches of short intervals (the whole-genome hotspot set averages 162 bases) run one WAVEFRONT per
+    // workgroup, which walks its interval in tiles of 64 - 2 hw bases: 162 + 6 positions fill 3 x 64 lanes
+    // to 88 %, where one 256-lane tile was 66 % full (SQ_THREAD_CYCLES_VALU said 39 % of the lanes idle);
+    // long intervals keep 256 lanes (a halo of 2 hw lanes per tile is 2 % there, 9 % of a wavefront);
+    // an interval longer than 8 tiles is spread over gridDim.y
+    const int64_t mean_len = pl.n_intervals > 0 ? pl.total_bases / pl.n_intervals : pl.max_len;
+    int nt = mean_len + 2 * pl.hw <= 320 && pl.hw <= 8 ? 64 : 256;
+    if (const char *e = getenv("FPT_POSTERIOR_NT")) nt = atoi(e) == 64 ? 64 : (atoi(e) == 128 ? 128 : 256);
+    if (nt - 2 * pl.hw < 16) nt = 256;  // (a tile must hold more than its halo)
     const int tl = nt - 2 * pl.hw;
     int64_t tiles = ((int64_t)pl.max_len + tl - 1) / tl;
     int gy = tiles <= 8 ? 1 : (int)((tiles + 7) / 8);
     if (gy > 65535) gy = 65535;
     const size_t lds = posterior_lds_bytes(pl.n_datasets, nt);
-    void (*kern)(const post_args) = nt == 128 ? k_posterior<128> : k_posterior<256>;
+    void (*kern)(const post_args) = nt == 64 ? k_posterior<64> : (nt == 128 ? k_posterior<128> : k_posterior<256>);
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     for (int64_t done = 0; done < pl.n_intervals; done += 0x7fffff00) {

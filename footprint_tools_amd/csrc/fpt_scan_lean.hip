@@ -46,6 +46,9 @@ using namespace fptlean;
 
 namespace {
 
+// the table of fptm::ndtr_fast_tab (this translation unit's copy: staged in LDS per workgroup)
+__device__ const double g_lean_gtab[4 * FPT_NDTR_GTAB_N + 1] = {FPT_NDTR_GTAB_LIST};
+
 // LDS carve-up for a workgroup of NT lanes: positions are padded up to NCR = NT + 128
 // (NT output bases + 2*pad + 1 padded positions + 6 sequence bases, in whole 64-position tiles)
 template <int NT>
@@ -56,7 +59,15 @@ struct lean_lds {
     static constexpr int oPP = 0;                  // P+[v]
     static constexpr int oPM = oPP + NCR;          // P-[v-1] (slot 0 is a dummy)
     static constexpr int oRT = oPM + NCR + 2;      // row totals (NROW), then row carries (NROW + 4)
-    static constexpr int nDoubles = oRT + 2 * NROW + 4;
+    // The table form of the normal cdf's g (fptm::ndtr_fast_tab: 256 cubics staged in 8 KB of LDS, two
+    // 16-byte reads and 9 instructions in place of the 15 fp64 ones of the Horner chain) is built and
+    // OFF: config 3 23.7 / 23.7 / 24.6 ms with it against 23.6 / 23.7 without (same box, same lease) --
+    // thirty fp64 instructions fewer per base changed nothing, like ninety scalar ones in phase B: at
+    // 1 kb per tile the kernel is not waiting for instruction issue at the margin
+    static constexpr bool kTab = false;
+    static constexpr int oTB = oRT + 2 * NROW + 4;
+    static constexpr int nDoubles = oTB + (kTab ? 4 * FPT_NDTR_GTAB_N : 0);
+    static_assert((oTB % 2) == 0, "the table is read 16 bytes at a time");
     // 32-bit words, after the doubles
     static constexpr int oB0 = 0;                  // sequence bit planes
     static constexpr int oB1 = oB0 + NCR / 32 + 4;
@@ -197,11 +208,11 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
 // LDS arrays of one workgroup (see lean_lds)
 template <int NT>
 struct lean_mem {
-    double *PP, *PM, *Z, *rowtot, *C;
+    double *PP, *PM, *Z, *rowtot, *C, *gt;
     u32 *bits0, *bits1, *pk, *psP, *psM, *xP, *xPs, *xM, *xMs, *edge;
     __device__ __forceinline__ explicit lean_mem(double *smem) {
         typedef lean_lds<NT> LY;
-        PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW;
+        PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW, gt = smem + LY::oTB;
         u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
         Z = reinterpret_cast<double *>(words + LY::oZB);
         bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK;
@@ -411,6 +422,8 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
     lean_inputs in;
     lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    if (lean_lds<NT>::kTab && a.n_scales > 1)  // (read four barriers from here)
+        for (int i = tid; i < 4 * FPT_NDTR_GTAB_N; i += NT) m.gt[i] = g_lean_gtab[i] * kc->inv_g0;
     bool bad = lean_stage<NT>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
     LEAN_TRACE(2);
     __syncthreads();
@@ -450,7 +463,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
             m.Z[kEdge] = -1e4;
         }
         __syncthreads();
-        bad |= lean_windows<NT>(a, kc, o, tid, m.Z);
+        bad |= lean_windows<NT, lean_args, lean_lds<NT>::kTab>(a, kc, o, tid, m.Z, m.gt);
     }
     if (bad) a.redo[tile] = 1;
     LEAN_TRACE(6);

@@ -68,13 +68,27 @@ def posterior(prior, ll_on, ll_off):
 
 
 # ---- the batched form: cli/post.py:98-124 for a whole batch in one launch ----------------------
+def pack_models(models):
+    """(datasets, 24) array -- mu_params (9) then r_params (15) per dataset -- of dispersion models or
+    (mu_params, r_params) pairs: what fpt_posterior_desc.models takes"""
+    rows = []
+    for m in models:
+        mu, r = (m.mu_params, m.r_params) if hasattr(m, "mu_params") else m
+        mu, r = _lib.f64(mu).ravel(), _lib.f64(r).ravel()
+        if mu.size != 9 or r.size != 15:
+            raise ValueError("mu_params needs 9 and r_params 15 values")
+        rows.append(np.concatenate([mu, r]))
+    return np.ascontiguousarray(np.stack(rows))
+
+
 def posterior_dev(ctx, n_intervals, total_bases, n_datasets, dm_slot, betas, obs, exp, fdr, w, post_out,
                   interval_len=None, interval_off_dev=None, max_interval_len=0, fdr_cutoff=0.05,
                   half_win_width=3, pseudocount=0.5, prior_out=None, delta_out=None, ll_on_out=None,
-                  ll_off_out=None, status_out=None):
+                  ll_off_out=None, status_out=None, models=None):
     """Enqueue fpt_posterior_dev on device pointers (ints); does not synchronise.  Tracks are
-    (n_datasets, total_bases) row-major, post_out (total_bases, n_datasets); dataset d uses
-    dispersion slot dm_slot + d and betas[d]."""
+    (n_datasets, total_bases) row-major, post_out (total_bases, n_datasets); dataset d uses betas[d]
+    and row d of `models` (pack_models: any number of datasets, nothing kept on the context) or,
+    without it, dispersion slot dm_slot + d (at most 64 datasets)."""
     d = _lib.PosteriorDesc()
     d.n_intervals, d.interval_len, d.interval_off = int(n_intervals), int(interval_len or 0), interval_off_dev
     d.total_bases, d.max_interval_len = int(total_bases), int(max_interval_len)
@@ -84,6 +98,10 @@ def posterior_dev(ctx, n_intervals, total_bases, n_datasets, dm_slot, betas, obs
     d.betas = keep.ctypes.data
     d.obs, d.exp, d.fdr, d.w, d.post_out = obs, exp, fdr, w, post_out
     d.prior_out, d.delta_out, d.ll_on_out, d.ll_off_out, d.status_out = prior_out, delta_out, ll_on_out, ll_off_out, status_out
+    keep_m = None
+    if models is not None:
+        keep_m = _lib.f64(models).reshape(int(n_datasets), 24)
+        d.models = keep_m.ctypes.data
     _lib.check(ctx.L.fpt_posterior_dev(ctx.h, C.byref(d)))
 
 
@@ -116,8 +134,8 @@ def posterior_batch(obs, exp, fdr, w, betas, dm, fdr_cutoff=0.05, half_win_width
     if total == 0:
         empty = np.zeros((0, D))
         return (empty, dict(prior=np.zeros((D, 0)), delta=np.zeros(0), ll_on=np.zeros((D, 0)), ll_off=np.zeros((D, 0)))) if pieces else empty
-    slot = (ctx.dispersion_slot(models[0].mu_params, models[0].r_params) if D == 1
-            else ctx.dispersion_slots([(m.mu_params, m.r_params) for m in models]))
+    packed = pack_models(models)  # handed over with the call: any number of datasets, no slot of the context touched
+    slot = 0
     bufs = []
     try:
         def dev(a):
@@ -136,7 +154,8 @@ def posterior_batch(obs, exp, fdr, w, betas, dm, fdr_cutoff=0.05, half_win_width
                       max_interval_len=int(np.diff(off).max()), fdr_cutoff=fdr_cutoff,
                       half_win_width=half_win_width, status_out=d_st.ptr,
                       prior_out=base + n * 8 if pieces else None, ll_on_out=base + 2 * n * 8 if pieces else None,
-                      ll_off_out=base + 3 * n * 8 if pieces else None, delta_out=base + 4 * n * 8 if pieces else None)
+                      ll_off_out=base + 3 * n * 8 if pieces else None, delta_out=base + 4 * n * 8 if pieces else None,
+                      models=packed)
         ctx.synchronize()
         if d_st.download(np.int32, n_iv).any():
             raise ZeroDivisionError("float division")  # dispersion.pyx:160-161 through log_pmf_values

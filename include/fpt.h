@@ -63,7 +63,8 @@ enum fpt_special_fn {
     FPT_FN_GAMMA = 0, FPT_FN_LGAM = 1, FPT_FN_NDTR = 2, FPT_FN_NDTRI = 3, FPT_FN_LOG1P = 4,
     FPT_FN_ERF = 5, FPT_FN_ERFC = 6, FPT_FN_INCBET = 7, /* (a,b,x) */
     FPT_FN_CHDTRC = 8, /* (df = a, x) */
-    FPT_FN_NDTR_WINDOW = 9 /* the normal cdf as the fused scan's Stouffer windows evaluate it */
+    FPT_FN_NDTR_WINDOW = 9, /* the normal cdf as the fused scan's Stouffer windows evaluate it */
+    FPT_FN_NDTR_WINDOW_TAB = 10 /* ... and its table form (256 cubics for g; measured, not in use: DESIGN.md 4) */
 };
 
 #define FPT_MAX_DISPERSION_MODELS 64
@@ -282,8 +283,8 @@ typedef struct fpt_posterior_desc {
     const int64_t *interval_off;      /* ragged: DEVICE offsets into the tracks (n_intervals+1) */
     int64_t total_bases;              /* sum(L): the row length of the tracks */
     int32_t max_interval_len;         /* ragged: the longest interval (a sizing hint; 0 = unknown) */
-    int32_t n_datasets;               /* 1 .. FPT_MAX_DISPERSION_MODELS */
-    int32_t dm_id;                    /* model slot of dataset 0; dataset d uses dm_id + d */
+    int32_t n_datasets;               /* >= 1; more than FPT_MAX_DISPERSION_MODELS need `models` */
+    int32_t dm_id;                    /* model slot of dataset 0; dataset d uses dm_id + d (ignored with `models`) */
     int32_t half_win_width;           /* likelihood window (cli/post.py: 3), <= 32 */
     double fdr_cutoff;                /* cli/post.py --fdr_cutoff (0.05) */
     double pseudocount;               /* compute_prior_weighted's default 0.5 */
@@ -294,6 +295,10 @@ typedef struct fpt_posterior_desc {
     double *delta_out;                /* optional DEVICE (sum(L)) */
     double *ll_on_out, *ll_off_out;   /* optional DEVICE (n_datasets, sum(L)) */
     int32_t *status_out;              /* optional DEVICE int32[n_intervals], zeroed by the caller */
+    const double *models;             /* optional HOST n_datasets x 24 (mu_params 9, r_params 15 per dataset): the
+                                       * datasets' dispersion models handed over with the call instead of through
+                                       * slots dm_id .. -- ANY number of datasets (cli/post.py:98-124 loops over
+                                       * however many samples the sample file lists; the slots hold 64) */
 } fpt_posterior_desc;
 int fpt_posterior_dev(fpt_ctx *ctx, const fpt_posterior_desc *desc);
 

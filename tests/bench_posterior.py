@@ -27,8 +27,7 @@ w = (rs.uniform(0, 1, (D, total)) < 0.9).astype(float)
 obs[w == 0], exp[w == 0], fdr[w == 0] = 0.0, 0.0, 1.0
 betas = np.array([[2.0 + 0.5 * d, 8.0 - 0.5 * d] for d in range(D)])
 ctx = _lib.get_ctx()
-slot = ctx.dispersion_slots([(lat["mu_" + "ABC"[d % 3]], lat["r_" + "ABC"[d % 3]]) for d in range(D)]) if D > 1 else \
-    ctx.dispersion_slot(lat["mu_A"], lat["r_A"])
+packed = posterior.pack_models([(lat["mu_" + "ABC"[d % 3]], lat["r_" + "ABC"[d % 3]]) for d in range(D)])
 d_in = DeviceArray(ctx, 4 * D * total * 8).upload(np.concatenate([obs.ravel(), exp.ravel(), fdr.ravel(), w.ravel()]))
 d_off = DeviceArray(ctx, off.nbytes).upload(off)
 d_out = DeviceArray(ctx, D * total * 8)
@@ -36,8 +35,8 @@ n = D * total * 8
 
 
 def step():
-    posterior.posterior_dev(ctx, n_iv, total, D, slot, betas, d_in.ptr, d_in.ptr + n, d_in.ptr + 2 * n, d_in.ptr + 3 * n,
-                            d_out.ptr, interval_off_dev=d_off.ptr, max_interval_len=int(lens.max()))
+    posterior.posterior_dev(ctx, n_iv, total, D, 0, betas, d_in.ptr, d_in.ptr + n, d_in.ptr + 2 * n, d_in.ptr + 3 * n,
+                            d_out.ptr, interval_off_dev=d_off.ptr, max_interval_len=int(lens.max()), models=packed)
 
 
 step()

@@ -75,6 +75,12 @@ def test_ndtr_window_device(fpt, ctx, orc):
     err = rel_err(got, want)
     print("ndtr_window max rel err %.2e" % err)
     assert err < 2e-11
+    # the table form of the same formula (g from 256 cubics in 1/(t + 5) instead of a degree-14 polynomial:
+    # what the wide-window phase of the large workgroups evaluates, from LDS): fit 1.2e-11
+    assert rel_err(special(fpt, ctx, "ndtr_window_tab", w["ndtr_a"]), w["ndtr_val"]) < 5e-11
+    err_t = rel_err(special(fpt, ctx, "ndtr_window_tab", a), want)
+    print("ndtr_window_tab max rel err %.2e" % err_t)
+    assert err_t < 5e-11
 
 
 # ---------------------------------------------------------------- A1: 6-mer lookup, bit-exact
@@ -891,12 +897,17 @@ def test_posterior_batch_fuzz(fpt, orc, seed):
     from footprint_tools_amd.stats import posterior
     rs = np.random.RandomState(4200 + seed)
     lat = golden("nb_lattice.npz")
-    D = int(rs.choice([1, 2, 3, 8, 8, 11]))
+    D = int(rs.choice([1, 2, 3, 8, 8, 11, 17]))
     hw = int(rs.choice([0, 1, 3, 3, 3, 7]))
     n_iv = int(rs.randint(1, 9))
-    lens = rs.choice([1, 2, 6, 7, 8, 100, 122, 123, 250, 251, 500, 1000, 2300], n_iv)
+    lens = rs.choice([1, 2, 6, 7, 8, 57, 58, 59, 100, 122, 123, 250, 251, 500, 1000, 2300], n_iv)
     if seed % 4 == 0:
         lens[0] = 2600  # more than eight 250-base tiles: spread over gridDim.y
+    if seed % 5 == 2:
+        # hundreds of datasets (docs/source/tutorials/posterior.rst: "hundreds of samples"): beyond the 64
+        # model slots of a context and beyond what the kernel stages of the models in LDS
+        D, lens = int(rs.choice([65, 129, 200])), lens[:3]
+        n_iv = lens.size
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     total = int(off[-1])
     keys = [str(rs.choice(["A", "B", "C"])) for _ in range(D)]
@@ -918,6 +929,14 @@ def test_posterior_batch_fuzz(fpt, orc, seed):
     stats, pc = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
                                           interval_off=off, pieces=True)
     assert stats.shape == (total, D)
+    # one wavefront per workgroup (batches of short intervals), 128 or 256 lanes: the same bits
+    for nt in ("64", "128", "256"):
+        os.environ["FPT_POSTERIOR_NT"] = nt
+        try:
+            s_nt = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw, interval_off=off)
+        finally:
+            del os.environ["FPT_POSTERIOR_NT"]
+        assert np.array_equal(s_nt, stats, equal_nan=True), (seed, D, hw, nt, lens.tolist())
     models = [(lat["mu_" + k], lat["r_" + k]) for k in keys]
     tag = (seed, D, hw, lens.tolist())
     for a, b in zip(off[:-1], off[1:]):
