@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="3", choices=sorted(CONFIGS))
     ap.add_argument("--intervals", type=int, default=0, help="override the number of intervals per GPU")
+    ap.add_argument("--scales", default=None, help="override the Stouffer half-widths, comma-separated ('' = none): diagnostics")
     ap.add_argument("--nb-mode", default="memo", choices=["memo", "direct"],
                     help="per-base NB p-value: exact (exp,obs) memo table rebuilt inside every step, "
                          "or direct incbet per base; at N=1 the other mode is timed too and reported")
@@ -267,6 +268,9 @@ def main():
     cfg = CONFIGS[args.config]
     if args.intervals:
         cfg = dict(cfg, n_iv=args.intervals, name=cfg["name"].replace(str(cfg["n_iv"]), str(args.intervals), 1))
+    if args.scales is not None:
+        sc_ = tuple(int(x) for x in args.scales.split(",") if x.strip())
+        cfg = dict(cfg, scales=sc_, name=cfg["name"] + "+scales_%s" % "_".join(map(str, sc_)))
     n_iv, L, scales = cfg["n_iv"], cfg["L"], cfg["scales"]
     fdr_times, n_models = cfg.get("fdr_times", 0), cfg.get("n_models", 1)
     S = len(scales)

@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-constexpr int kSlots = 14;
+constexpr int kSlots = 15;
 constexpr int kModelDoubles = 24;
 
 }  // namespace
@@ -88,6 +88,7 @@ struct fpt_ctx {
     bool m2_extended = false;  // the last scan call launched k_nb_memo2: its misses become bounds at the next call
     bool posterior_direct = false;  // FPT_POSTERIOR_TABLES=0: every log-pmf evaluated in the kernel (tests compare the two)
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
+    bool fdr_split = true;  // fpt_fdr_dev: the per-interval set-up as a launch of its own (FPT_FDR_SPLIT=0: one launch)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     // size classes of a batch's tiles; FPT_SCAN_WAVE = 4 / 5 / 6 (read at creation): whole intervals of up to
     // 139 / 203 / 267 bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip).  Off by
@@ -213,6 +214,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     if (const char *e = getenv("FPT_MEMO2_KEEP")) c->memo2_cold = atoi(e) == 0;
     if (const char *e = getenv("FPT_POSTERIOR_TABLES")) c->posterior_direct = atoi(e) == 0;
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
+    if (const char *e = getenv("FPT_FDR_SPLIT")) c->fdr_split = atoi(e) != 0;
     if (const char *e = getenv("FPT_SCAN_WAVE")) c->classes = fptk::make_lean_classes(atoi(e));
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
@@ -948,6 +950,19 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
 #ifdef FPT_ABLATE
     if (const char *e = getenv("FPT_ABLATE")) fl.ablate = atoi(e);
 #endif
+    // the hand-over between the set-up launch and the draw launch (the `detect` width; FPT_FDR_SPLIT=0: one launch)
+    if (d->half_win_width == 3 && c->fdr_split) {
+        const int64_t total = d->interval_off ? (d->interval_off_host ? d->interval_off_host[d->n_intervals] : -1)
+                                              : d->n_intervals * (int64_t)d->interval_len;
+        if (total > 0) {
+            void *ws;
+            const size_t key_b = ((size_t)total * 8 + 255) & ~(size_t)255, idx_b = ((size_t)total * 2 + 255) & ~(size_t)255;
+            if (int rc = ws_get(c, 14, key_b + idx_b + (size_t)d->n_intervals * 8, &ws)) return rc;
+            fl.ws_key = (double *)ws;
+            fl.ws_idx = (uint16_t *)((char *)ws + key_b);
+            fl.ws_misc = (int32_t *)((char *)ws + key_b + idx_b);
+        }
+    }
     // long intervals: per-workgroup buffers in a global workspace of at most 1 GiB
     auto launch_long = [&](const int32_t *list, int64_t n_list) -> int {
         fl.n2_max = pow2(lmax);

@@ -1286,6 +1286,11 @@ struct fdr_args {
     int64_t iv_first;
     char *gws;               // GWS instances: per-workgroup buffers in global memory
     int64_t gws_stride;
+    // the hand-over between the set-up launch (MODE 1) and the draw launch (MODE 2): the interval's sorted
+    // thresholds and their positions (at the interval's offset in the tracks), and m / rank_one per interval
+    double *ws_key;
+    uint16_t *ws_idx;
+    int32_t *ws_misc;
 };
 
 // Guide table of the inverse-CDF sampler: guide[row][idx] = smallest k with
@@ -1640,7 +1645,12 @@ __device__ unsigned long long g_fdr_phase[16];
 // unroll into 14 LDS reads with immediate offsets), or 0 for any width.
 // ONE: no interval of the launch is longer than the workgroup -- a lane has one base, and what
 // belongs to the base (table row, Philox counter, addresses) is made once, not in every pass.
-template <int NT, bool GWS, int HSC, bool ONE>
+// MODE: 0 the whole pass; 1 the per-interval SET-UP alone (steps 0 - 1b: the observed windows re-made,
+// sorted, translated into thresholds -- a chain of barrier-separated phases with ~4 exact normal cdfs
+// per observed value, a third of a 50-draw call) with its results left in a workspace; 2 the DRAWS
+// (steps 2 - 3) reading them back.  As a launch of its own the set-up has a third of the LDS and no
+// part in the draw loop's 121 registers: twice as many workgroups cover each other's latencies.
+template <int NT, bool GWS, int HSC, bool ONE, int MODE = 0>
 __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     const int n2 = a.n2_max;
@@ -1648,12 +1658,15 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
     double *zb = skey + n2;                          // 4 x n2: z of the pass's four samples, the four of a position side by side
                                                      // (with wide windows: two arrays of n2 tile prefix sums)
-    double *zalt = zb + 4 * n2;                      // 4 x n2 more when a.dbuf (passes alternate between the sets)
+    double *zalt = zb + (MODE == 1 ? 2 : 4) * n2;    // 4 x n2 more when a.dbuf (passes alternate between the sets); the
+                                                     // set-up launch (MODE 1) uses two n2 of zb: the z, and the keys
     int *sidx = reinterpret_cast<int *>(zalt + (a.dbuf ? 4 * n2 : 0));  // n2 original positions
     int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
     int *hist = nf + n2;                             // n2 + 2 histogram / prefix
     int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
     int *rguide = misc + 8;                          // min(n2, 2048) + 1: #{sorted observed < b / nb}
+    // (MODE 1 is launched with the buffers it uses -- par, skey, two n2 of zb, sidx, nf, hist, misc:
+    // fdr_setup_lds_bytes -- and never touches rguide, whose address then lies beyond its allocation)
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -1687,7 +1700,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // flat to double precision near 1).  Taken from the p-value track of the scan, whose cdf is a
     // different (faster) evaluation, such ties fall either way by rounding -- and with sparse counts
     // ties are a large share of the null: an all-zero window is its own most likely null draw.
-    if (a.obs) {
+    if (MODE != 2 && a.obs) {
         for (int t = tid; t < L; t += NT) {
             const double ex = a.exp[off + t];
             const int ei = table_row_of(ex, a.memo_exp);
@@ -1711,7 +1724,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // constant 1.0 among the thresholds)
     int n_num = 0, n_below_one = 0;
     double v_one = fptm::kInf;  // ONE: this lane's key
-    for (int i = tid; i < (ONE ? L : np2); i += NT) {
+    for (int i = tid; MODE != 2 && i < (ONE ? L : np2); i += NT) {
         double v = fptm::kInf;
         int id = -1;
         if (i < L) {
@@ -1750,13 +1763,19 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
             sidx[i] = id;
         }
     }
+    if (MODE == 2) {  // what the set-up launch left: sorted thresholds, their positions, m and rank_one
+        for (int i = tid; i < (ONE ? L : np2); i += NT) {
+            skey[i] = i < L ? a.ws_key[off + i] : fptm::kInf;
+            sidx[i] = i < L ? (int)a.ws_idx[off + i] : -1;
+        }
+    }
     for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
-    if (tid < 4) misc[tid] = 0;
+    if (tid < 4) misc[tid] = (MODE == 2 && tid >= 1 && tid <= 2) ? a.ws_misc[2 * iv + tid - 1] : 0;
     __syncthreads();
     FDR_MARK(1)  // keys
     if (n_num) atomicAdd(&misc[1], n_num);
     if (n_below_one) atomicAdd(&misc[2], n_below_one);
-    if (ONE) {
+    if (ONE && MODE != 2) {
         // One key per lane: its place in the order is the number of keys that come before it -- a
         // walk over the interval's keys (LDS broadcast reads), a compare and an add each: 4 L
         // instructions per wavefront where the bitonic network below issues ~2,000 for 256 slots and
@@ -1783,7 +1802,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     }
     // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
     // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
-    for (int k = 2; k <= ((ONE || ABL(16384)) ? 0 : np2); k <<= 1) {
+    for (int k = 2; k <= ((ONE || MODE == 2 || ABL(16384)) ? 0 : np2); k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NT) {
                 const int ixj = i ^ j;
@@ -1808,7 +1827,8 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
     // (after the sort: neighbouring lanes then search neighbouring values, whose searches are about
     // equally long -- in the order of the positions a wavefront waits for its one value in the tail)
-    if (!a.obs) {
+    if (MODE == 2) {
+    } else if (!a.obs) {
         for (int i = tid; i < m; i += NT)
             skey[i] = sum_threshold(ABL(8192) ? fptm::ndtri(skey[i]) : ndtr_threshold(skey[i]), a.sqrt_k, a.inv_sqrt_k);
         __syncthreads();
@@ -1832,6 +1852,17 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // first and last reach to infinity) bracket #{X <= x}, so a rank needs a probe or two, not log2(L)
     FDR_MARK(3)  // thresholds
     const int rank_one = misc[2];  // thresholds of values below 1
+    if (MODE == 1) {  // hand over and stop: the draw launch picks these up
+        for (int i = tid; i < L; i += NT) {
+            a.ws_key[off + i] = skey[i];
+            a.ws_idx[off + i] = (uint16_t)sidx[i];
+        }
+        if (tid == 0) {
+            a.ws_misc[2 * iv] = m;
+            a.ws_misc[2 * iv + 1] = rank_one;
+        }
+        return;
+    }
     const double kYR = 4.5 * a.sqrt_k;
     // (measured and dropped: four times as many slices -- no faster; the slice of x as fma / clamp /
     // truncation with the guide built on the same function -- 1 % per pass, 5 % more set-up)
@@ -2079,13 +2110,13 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
 
 // size classes of short intervals (64, 128, 192 lanes): fewer idle lanes; 192 lanes take 129..192
 // bases in one pass and 257..384 in two
-template <int HSC, bool ONE>
+template <int HSC, bool ONE, int MODE = 0>
 fdr_kernel_t fdr_kernel(int nt) {
     // (512 lanes: intervals of 513 bases and more, in several rounds -- their buffers let two
     // workgroups live on a CU, and with 256 lanes each those were 8 wavefronts)
-    if (!ONE && nt == 512) return k_fdr_null<512, false, HSC, false>;
-    return nt == 64 ? k_fdr_null<64, false, HSC, ONE> : nt == 128 ? k_fdr_null<128, false, HSC, ONE>
-           : nt == 192 ? k_fdr_null<192, false, HSC, ONE> : k_fdr_null<256, false, HSC, ONE>;
+    if (!ONE && nt == 512) return k_fdr_null<512, false, HSC, false, MODE>;
+    return nt == 64 ? k_fdr_null<64, false, HSC, ONE, MODE> : nt == 128 ? k_fdr_null<128, false, HSC, ONE, MODE>
+           : nt == 192 ? k_fdr_null<192, false, HSC, ONE, MODE> : k_fdr_null<256, false, HSC, ONE, MODE>;
 }
 
 // ===========================================================================
@@ -2637,6 +2668,11 @@ size_t fdr_lds_bytes(int n2, bool dbuf) {
     return (size_t)(24 + (dbuf ? 9 : 5) * (size_t)n2) * sizeof(double) +
            (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
 }
+// the set-up launch (MODE 1): par, skey, two n2 of zb (the z of the observed counts, the keys), then sidx, nf,
+// hist and misc -- a third of the draw launch's buffers
+size_t fdr_setup_lds_bytes(int n2) {
+    return (size_t)(24 + 3 * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8) * sizeof(int);
+}
 
 hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     fdr_args a;
@@ -2690,15 +2726,31 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     // (the longest interval of the launch is known to be <= n2_max only; ONE when that says enough
     // or the caller does: max_len)
     const bool one = nt <= 256 && (fl.max_len > 0 ? fl.max_len : fl.n2_max) <= nt;  // (512 lanes: the several-rounds form only)
-    fdr_kernel_t kern = fl.hw == 3 ? (one ? fdr_kernel<3, true>(nt) : fdr_kernel<3, false>(nt))
-                                   : (one ? fdr_kernel<0, true>(nt) : fdr_kernel<0, false>(nt));
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
-        fdr_args b = a;
-        if (b.iv_list) b.iv_list += done; else b.iv_first = done;
-        const int64_t n = n_blocks - done < 0x7fffff00 ? n_blocks - done : 0x7fffff00;
-        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(nt), lds, st, b);
+    // two launches -- the per-interval set-up, then the draws -- where the caller gave a workspace for the
+    // hand-over (the `detect` window width; the other widths and the long intervals keep the single launch)
+    const bool split = fl.ws_key && fl.ws_idx && fl.ws_misc && fl.hw == 3;
+    a.ws_key = fl.ws_key;
+    a.ws_idx = fl.ws_idx;
+    a.ws_misc = fl.ws_misc;
+    for (int mode = split ? 1 : 0; mode <= (split ? 2 : 0); ++mode) {
+        fdr_kernel_t kern = fl.hw == 3 ? (mode == 1 ? (one ? fdr_kernel<3, true, 1>(nt) : fdr_kernel<3, false, 1>(nt))
+                                          : mode == 2 ? (one ? fdr_kernel<3, true, 2>(nt) : fdr_kernel<3, false, 2>(nt))
+                                                      : (one ? fdr_kernel<3, true>(nt) : fdr_kernel<3, false>(nt)))
+                                       : (one ? fdr_kernel<0, true>(nt) : fdr_kernel<0, false>(nt));
+        fdr_args am = a;
+        size_t lds_m = lds;
+        if (mode == 1) {
+            am.dbuf = 0;
+            lds_m = fdr_setup_lds_bytes(fl.n2_max);
+        }
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+        if (e != hipSuccess) return e;
+        for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
+            fdr_args b = am;
+            if (b.iv_list) b.iv_list += done; else b.iv_first = done;
+            const int64_t n = n_blocks - done < 0x7fffff00 ? n_blocks - done : 0x7fffff00;
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(nt), lds_m, st, b);
+        }
     }
 #ifdef FPT_ABLATE
     if (getenv("FPT_FDR_PHASES")) {

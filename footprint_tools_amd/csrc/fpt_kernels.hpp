@@ -101,6 +101,11 @@ struct fdr_launch {
     int32_t max_len;         // longest interval of the launch if known (0: n2_max is what is known)
     const int32_t *iv_list;  // optional DEVICE list of the intervals to process (n_list of them)
     int64_t n_list;
+    // the hand-over of the set-up launch to the draw launch (all three, or none: one launch does both):
+    // total_bases doubles, total_bases uint16, 2 x n_intervals int32
+    double *ws_key;
+    uint16_t *ws_idx;
+    int32_t *ws_misc;
     void *gws;               // non-null: global-memory buffers, gws_stride bytes per workgroup,
     int64_t gws_stride;      //           room for gws_blocks workgroups at a time
     int64_t gws_blocks;

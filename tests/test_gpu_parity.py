@@ -2153,6 +2153,42 @@ def test_fdr_fuzz(fpt, orc, seed):
         assert np.max(np.abs(ef[a:b] - want)) <= 2.5 / ((b - a) * times), tag
 
 
+def test_fdr_setup_launch_equals_single_launch(fpt, orc):
+    """fpt_fdr_dev runs the per-interval set-up (observed windows re-made, sorted, translated into
+    thresholds) as a launch of its own and the draws as a second one (the `detect` width): the same bits as
+    the single launch (a context made under FPT_FDR_SPLIT=0), with and without the observed counts, for
+    every workgroup size class and for uniform batches"""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    os.environ["FPT_FDR_SPLIT"] = "0"
+    try:
+        ctx1 = fpt.Context(0)
+    finally:
+        del os.environ["FPT_FDR_SPLIT"]
+    rs = np.random.RandomState(77)
+    lens = np.concatenate([[1, 2, 7, 64, 65, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 1000, 1024, 1025, 2048, 2049, 5000],
+                           rs.randint(50, 400, 60)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp = np.round(rs.gamma(2.0, 3.0, off[-1]))
+    obs = np.floor(exp * rs.uniform(0, 1.7, off[-1]))
+    winp = rs.uniform(0, 1, off[-1]) ** 2.0
+    winp[rs.randint(0, winp.size, winp.size // 30)] = np.nan
+    winp[rs.randint(0, winp.size, winp.size // 30)] = rs.choice([0.0, 1.0, 0.25], winp.size // 30)
+    outs = []
+    for ctx in (None, ctx1):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+        ef_track = sc.fdr(exp, winp, times=13, seed=5, half_win_width=3, interval_off=off, base_index0=12345)
+        ef_counts = sc.fdr(exp, winp, times=13, seed=5, half_win_width=3, interval_off=off, base_index0=12345, obs=obs)
+        L = 250
+        ef_uni = sc.fdr(exp[:40 * L], winp[:40 * L], times=7, seed=9, half_win_width=3, interval_len=L, obs=obs[:40 * L])
+        outs.append((winp, ef_track, ef_counts, ef_uni))
+    ctx1.close()
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    for k in (1, 2, 3):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
 def test_host_api_fuzz(fpt, orc, seed):
     """the host-buffer entry points one reference call each (predict, the five window reducers,
