@@ -322,6 +322,9 @@ def main():
         # the job does not depend on the number of ranks
         rs = np.random.RandomState(4)
         lens_all = np.clip(rs.lognormal(4.9, 0.62, n_iv * world), 50, 2000).astype(np.int64)
+        if os.environ.get("FPT_BENCH_ALIGN"):  # diagnostics: every interval a multiple of this many bases (aligned track segments)
+            q = int(os.environ["FPT_BENCH_ALIGN"])
+            lens_all = np.maximum(q, (lens_all // q) * q)
         bounds = shard_intervals(lens_all, world, HW + SHW)
         a_iv, b_iv = bounds[rank]
         lens = lens_all[a_iv:b_iv]
