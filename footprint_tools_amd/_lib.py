@@ -271,6 +271,17 @@ class Context(object):
             self.L.fpt_ctx_destroy(self.h)
             self.h = None
 
+    def trim_pool(self):
+        """Give the device buffers on scan.DeviceArray's free list back to the driver (the list keeps up to
+        8 GiB per context for reuse; a host that has finished its large batches calls this instead of
+        closing the context)."""
+        with self._lock:
+            self.synchronize()
+            for ptrs in self._dev_pool.values():
+                for p in ptrs:
+                    self.L.fpt_dev_free(self.h, p)
+            self._dev_pool, self._dev_pool_bytes = {}, 0
+
     def __del__(self):
         try:
             self.close()

@@ -857,10 +857,10 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     // whole-genome shape: 398 -> 69 ms per 7.1e7 bases)
     // and by the workgroup size that leaves the fewest lanes idle in the draw loop (one lane per
     // base and null track, intervals longer than the workgroup in several passes)
-    constexpr int kClasses = 9;
-    static const int cls_len[kClasses] = {64, 128, 192, 256, 384, 512, 1024, 2048, 4096};  // longest interval
-    static const int cls_n2[kClasses] = {64, 128, 256, 256, 512, 512, 1024, 2048, 4096};   // LDS buffers
-    static const int cls_nt[kClasses] = {64, 128, 192, 256, 192, 256, 512, 512, 512};      // lanes (512: measured slower for the 385..512 class, 2 x 8 wavefronts per CU against 3 x 4)
+    constexpr int kClasses = 8;
+    static const int cls_len[kClasses] = {64, 128, 192, 256, 384, 512, 1024, 2048};  // longest interval (kLdsMax: the last)
+    static const int cls_n2[kClasses] = {64, 128, 256, 256, 512, 512, 1024, 2048};   // LDS buffers
+    static const int cls_nt[kClasses] = {64, 128, 192, 256, 192, 256, 512, 512};      // lanes (512: measured slower for the 385..512 class, 2 x 8 wavefronts per CU against 3 x 4)
     auto cls_of = [&](int L) {
         int k = 0;
         while (cls_len[k] < L) ++k;

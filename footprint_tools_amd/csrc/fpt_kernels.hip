@@ -1685,6 +1685,14 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     const int Lr = (L + kWave - 1) & ~(kWave - 1);
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
+    // The launch and its buffers were sized from the HOST copy of the offsets; these come from the device.
+    // If the two disagree (a stale host array) the interval does not fit: it is not processed -- NaN in its
+    // efdr says so -- rather than written past the buffers.
+    if (np2 > n2 || (ONE && L > NT)) {
+        if (MODE != 1)
+            for (int i = tid; i < L; i += NT) a.efdr[off + i] = NAN;
+        return;
+    }
 
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;

@@ -309,6 +309,15 @@ bool load_tbi(track_file *t, const char *path) {
         lin[(size_t)r].resize((size_t)n_intv);
         if (n_intv) memcpy(lin[(size_t)r].data(), d.data() + q, (size_t)n_intv * 8);
         q += (size_t)n_intv * 8;
+        // Windows before a reference's first row: this library's writer (and the tabix manual's text) give
+        // them the offset 0, htslib the offset of the reference's first row.  A search that starts at 0
+        // walks every line of every reference before this one; the first non-zero entry is where the
+        // reference starts, and nothing of it lies before that (any reference but the first in the file)
+        std::vector<uint64_t> &v = lin[(size_t)r];
+        size_t first = 0;
+        while (first < v.size() && v[first] == 0) ++first;
+        if (first < v.size() && r > 0)
+            for (size_t i = 0; i < first; ++i) v[i] = v[first];
     }
     t->names = names;
     t->lin = lin;
