@@ -35,7 +35,6 @@ struct lean_args {
     int64_t tile_first;
     int64_t tile_count;       // k_scan_wave: tiles of this launch, tiles_per_wave consecutive ones per wavefront
     int32_t tiles_per_wave;
-    int32_t xcd_map;          // workgroup b takes slot (b mod 8) * ceil(grid / 8) + b / 8 of the launch (see k_scan_wave)
     int32_t tiles_per_interval, tile_len;
     int32_t n_scales;
     int32_t scales[FPT_MAX_SCALES];
@@ -289,7 +288,6 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.tile_first = sl.tile_first;
     a.tile_count = 0;
     a.tiles_per_wave = 1;
-    a.xcd_map = 0;
     a.tiles_per_interval = sl.tiles_per_interval;
     a.tile_len = sl.tile_len;
     a.n_scales = sl.n_scales;

@@ -892,7 +892,6 @@ void launch_scan_wave(hipStream_t st, int rp, int n_tiles, const scan_launch &sl
     if (const char *e = getenv("FPT_WAVE_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
     a.tile_count = n_tiles;
     a.tiles_per_wave = tpw;
-    a.xcd_map = 0;
     const int grid = (int)((n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave);
     hipLaunchKernelGGL(wave_kernel(rp, pipe), dim3(grid), dim3(64), scan_wave_lds_bytes(rp), st, a);
 }
