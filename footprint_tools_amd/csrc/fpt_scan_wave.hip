@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(64) k_scan_wave_pipe(const lean_args a_) {
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) {
                 const int tb = jb * 64 + lane - 6;
-                const u32 o8 = (tb >= 0 && tb < gcur.L && !LEAN_STOP(6)) ? (u32)tb * 8u : kNoLane;
+                const u32 o8 = (tb >= 0 && tb < gcur.L) ? (u32)tb * 8u : kNoLane;  // (the pipeline is not launched in ablation runs)
                 buffer_store_f64(re, o8, ex[jb]);
                 buffer_store_f64(ro, o8, (double)kk[jb]);
                 buffer_store_f64(rq, o8, pv[jb]);
