@@ -923,10 +923,10 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     const double *model = c->d_models + (size_t)d->dm_id * kModelDoubles;
     fptk::launch_nb_memo(c->stream, model, n_dm, c->memo_exp, c->fdr_memo_obs, d_memo);
     if (int rc = launch_ok("k_nb_memo")) return rc;
-    void *d_guide;
-    if (int rc = ws_get(c, 6, fptk::nb_guide_bytes(n_dm, c->memo_exp), &d_guide)) return rc;
-    fptk::launch_nb_guide(c->stream, d_memo, n_dm, c->memo_exp, c->fdr_memo_obs, d_guide);
-    if (int rc = launch_ok("k_nb_guide")) return rc;
+    void *d_alias;
+    if (int rc = ws_get(c, 6, fptk::nb_alias_bytes(n_dm, c->memo_exp, c->fdr_memo_obs), &d_alias)) return rc;
+    fptk::launch_nb_alias(c->stream, d_memo, n_dm, c->memo_exp, c->fdr_memo_obs, d_alias);
+    if (int rc = launch_ok("k_nb_alias")) return rc;
     fptk::fdr_launch fl{};
     fl.n_intervals = d->n_intervals;
     fl.interval_len = d->interval_off ? 0 : d->interval_len;
@@ -937,7 +937,8 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.seed = d->seed;
     fl.model = model;
     fl.memo = d_memo;
-    fl.guide = d_guide;
+    fl.alias = d_alias;
+    fl.n_models = n_dm;
     fl.memo_exp = c->memo_exp;
     fl.memo_obs = c->fdr_memo_obs;
     fl.exp = d->exp;

@@ -1269,7 +1269,10 @@ struct fdr_args {
     uint64_t seed;
     const double *model;
     const double2 *memo;
-    const uint16_t *guide;  // kGuide entries per (model, integer exp) row of the memo
+    const uint32_t *alias;  // alias tables (k_nb_alias): room for 2^alias_lg slots per (model, integer exp) row of the memo
+    const double *zt;       // z of outcome k of the same rows
+    const uint8_t *row_lg;  // the width of every row's table
+    int32_t alias_lg;
     int32_t memo_exp, memo_obs;
     const double *exp;
     const double *winp;
@@ -1293,25 +1296,109 @@ struct fdr_args {
     int32_t *ws_misc;
 };
 
-// Guide table of the inverse-CDF sampler: guide[row][idx] = smallest k with
-// cdf(k) >= guide_edge(idx) (or the last tabulated k), so a draw starts its search between
-// guide[row][guide_index(w)] and the next entry, and walks a step or two instead of bisecting the
-// whole row (every step is a divergent gather, and a wavefront waits for its slowest lane).
-constexpr int kGuide = fptm::kGuideEntries;
+// Alias tables of the null sampler (Walker / Vose): for every (model, integer exp) row of the memo the
+// outcomes 0 .. n-2 (their probabilities the differences of the row's cdf) and "n-1 or more" (the
+// rest) are spread over n = 2^lg slots of probability 1/n each; a slot holds one outcome up to a
+// threshold and a second one (its alias) above it.  A draw is then one 4-byte gather -- slot from
+// the top lg bits of the Philox word, threshold against the other 32 - lg -- and one 8-byte gather
+// of the outcome's z, with no search and no walk.
+// n is chosen PER ROW: the smallest power of two whose rest is at most 2^-32 (capped by the memo's
+// width), so that a row of small counts is a few hundred bytes and the tables of an interval's rows
+// stay in the vector L1 -- the gathers, not the arithmetic, bound the draws (FDR).
+// The construction is Vose's with two QUEUES filled in index order (small: n p < 1, large: the
+// rest), so that it is one fixed sequence of double operations -- include/fpt.h states it, and anything that
+// repeats it gets the same table bit for bit.  One wavefront per row: the probabilities and the queues are made by
+// all lanes, the pairing loop (n steps, each depending on the one before) by lane 0 in LDS.
+//   entry = threshold << lg | alias;   draw: slot = word >> (32 - lg), t = word & (2^(32-lg) - 1),
+//   outcome = t < threshold ? slot : alias
+// Every row's entries start at row << lg_max (its z at the same index of `zt`); row_lg[row] = lg.
+// A row with a NaN in it gets the identity table (outcome = slot: its z is the NaN).
+constexpr int kAliasLgMax = 11;
+constexpr double kAliasRest = 1.0 / 4294967296.0;
+__host__ __device__ inline int alias_lg_of(int memo_obs) {  // the cap: 2^lg <= memo_obs, 1 <= lg <= 11
+    int lg = 1;
+    while (lg < kAliasLgMax && (2 << lg) <= memo_obs) ++lg;
+    return lg;
+}
 
-__global__ void __launch_bounds__(256) k_nb_guide(const double2 *__restrict__ memo, int memo_exp, int memo_obs,
-                                                  uint16_t *__restrict__ guide) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= memo_exp * kGuide) return;
-    const int ei = i / kGuide, g = i % kGuide;
-    const double2 *row = memo + ((size_t)blockIdx.y * memo_exp + ei) * memo_obs;
-    const double t = fptm::guide_edge(g);
-    int l = 0, h = memo_obs - 1;  // (an edge no tabulated cdf reaches: the end of the table)
-    while (l < h) {
-        const int mid = (l + h) >> 1;
-        if (row[mid].x >= t) h = mid; else l = mid + 1;
+__global__ void __launch_bounds__(64) k_nb_alias(const double2 *__restrict__ memo, int memo_exp, int memo_obs, int lg_max,
+                                                 uint32_t *__restrict__ alias, double *__restrict__ zt,
+                                                 uint8_t *__restrict__ row_lg) {
+    extern __shared__ double alias_smem[];
+    const int lane = threadIdx.x;
+    const size_t r = (size_t)blockIdx.y * memo_exp + blockIdx.x;
+    const double2 *row = memo + r * memo_obs;
+    // the row's width: lane i tries lg = i + 1 (cdf(2^lg - 2) exists: 2^lg_max <= memo_obs, or the memo is a single
+    // column and the only outcome besides the rest is k = 0)
+    int lg = lg_max;
+    {
+        const int idx = (2 << lane) - 2;
+        const bool ok = lane < lg_max && idx < memo_obs && 1.0 - row[idx].x <= kAliasRest;
+        const unsigned long long m = __ballot(ok);
+        if (m) lg = __ffsll((long long)m);
     }
-    guide[((size_t)blockIdx.y * memo_exp + ei) * kGuide + g] = (uint16_t)l;
+    const int n = 1 << lg;
+    double *q = alias_smem;
+    uint16_t *sq = reinterpret_cast<uint16_t *>(q + ((size_t)1 << lg_max)), *lq = sq + ((size_t)1 << lg_max),
+             *al = lq + ((size_t)1 << lg_max);
+    bool bad = false;
+    int ns = 0, nl = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        double qq = 0.0;
+        if (k < n) {
+            const double2 e = k < memo_obs ? row[k] : make_double2(1.0, 0.0);
+            const double below = k > 0 ? row[k - 1].x : 0.0;
+            double pm = (k == n - 1 ? 1.0 : e.x) - below;
+            bad |= !(pm == pm);
+            pm = pm > 0.0 ? pm : 0.0;  // (a cdf that steps back by a rounding: probability 0)
+            qq = pm * (double)n;
+            q[k] = qq;
+            al[k] = (uint16_t)k;
+            zt[(r << lg_max) + k] = e.y;
+        }
+        const bool small = k < n && qq < 1.0, large = k < n && !small;
+        const unsigned long long ms = __ballot(small), ml = __ballot(large);
+        const unsigned long long below_me = (1ull << lane) - 1ull;
+        if (small) sq[ns + __popcll(ms & below_me)] = (uint16_t)k;
+        if (large) lq[nl + __popcll(ml & below_me)] = (uint16_t)k;
+        ns += __popcll(ms);
+        nl += __popcll(ml);
+    }
+    const bool any_bad = __ballot(bad) != 0ull;
+    __syncthreads();
+    if (lane == 0 && !any_bad) {
+        int si = 0, li = 0, se = ns;
+        while (si < se && li < nl) {
+            const int s = sq[si++], l = lq[li];
+            al[s] = (uint16_t)l;
+            const double ql = (q[l] + q[s]) - 1.0;
+            q[l] = ql;
+            if (ql < 1.0) {
+                sq[se++] = (uint16_t)l;
+                ++li;
+            }
+        }
+        // what is left on either queue is 1 up to rounding: its own slot, whole
+        while (li < nl) q[lq[li++]] = 1.0;
+        while (si < se) {
+            const int s = sq[si++];
+            q[s] = 1.0;
+            al[s] = (uint16_t)s;
+        }
+    }
+    __syncthreads();
+    const uint32_t top = 0xffffffffu >> lg;  // the largest threshold: 32 - lg bits
+    for (int k = lane; k < n; k += 64) {
+        uint32_t th = top, ak = (uint32_t)k;
+        if (!any_bad) {
+            const double t = floor(ldexp(q[k], 32 - lg) + 0.5);
+            th = t >= (double)top ? top : (uint32_t)t;
+            ak = al[k];
+        }
+        alias[(r << lg_max) + k] = (th << lg) | ak;
+    }
+    if (lane == 0) row_lg[r] = (uint8_t)lg;
 }
 
 // Draw beyond the table (or at a non-integer expected value): gallop, then bisect on the direct
@@ -1342,131 +1429,94 @@ __device__ __forceinline__ double2 nb_inverse_cdf_direct(const double *par, doub
     return make_double2(chi, fptm::ndtri(1.0 - chi));
 }
 
-// Two inverse-CDF NB draws at the same expected value: for each u the z = ndtri(1 - cdf(k)) of the
-// smallest k with cdf(k) >= u.  The guide brackets the answer between two table positions, the
-// first probe interpolates between them, and the walk from there (up while cdf < u, down while
-// the entry below is still >= u) is a step or two.  Every probe after the first falls into the
-// cache line of the first; both draws run interleaved so their gathers overlap.
 // ei: table row of the position's expected value, or -1 when it is not an integer inside the
 // table (then *exp_ptr is read and the draw is evaluated directly).
 __device__ __forceinline__ int table_row_of(double ex, int memo_exp) {
     const int ei = (int)ex;
     return (ex >= 0.0 && ex < (double)memo_exp && (double)ei == ex) ? ei : -1;
 }
+// the same with the width of the row's alias table above the row: row | lg << 16, or -1
+__device__ __forceinline__ int alias_row_of(double ex, int memo_exp, const uint8_t *row_lg) {
+    const int ei = table_row_of(ex, memo_exp);
+    return ei >= 0 ? (ei | ((int)row_lg[ei] << 16)) : -1;
+}
 
 // (the tables are addressed base + 32-bit byte offset: one vector register and no 64-bit address
-// arithmetic per probe; a model's table is at most 4096 x 4096 x 16 bytes)
-__device__ __forceinline__ double2 table_entry(const double2 *base, uint32_t byte_off) {
-    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+// arithmetic per gather; a model's alias table is at most 4096 x 2048 x 4 bytes, its z table twice that)
+template <typename T>
+__device__ __forceinline__ T table_at(const void *base, uint32_t byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
-__device__ __forceinline__ uint32_t guide_pair(const uint16_t *base, uint32_t byte_off) {  // entries idx, idx + 1
-    const char *p = reinterpret_cast<const char *>(base) + byte_off;
-    return (uint32_t)*reinterpret_cast<const uint16_t *>(p) | ((uint32_t)*reinterpret_cast<const uint16_t *>(p + 2) << 16);
-}
-// N draws (2 or 4) at the same expected value, in step: the N guide reads go out together, then the
-// N first probes, then every round of the walk -- a draw is two or three dependent trips to L2, and
-// a pass spends most of its time waiting for them (measured per phase), so the draws of a
-// Philox block share the trips instead of queueing behind each other.
-// The per-draw flags of the walk (still moving? upwards?) are kept as wavefront masks in scalar
-// registers -- ballots combined with scalar logic, turned back into a lane condition where a select
-// needs one (inverse ballot: free) --: as bools the compiler materialises each as 0 / 1 in a vector
-// register and re-tests it (3-5 vector instructions per flag and use; the kernel is bound by vector
-// issue), and "any lane still moving" is then a scalar compare instead of a vector one.
+// N draws (2 or 4) at the same expected value, in step: the N alias entries go out together, then
+// the N z values -- a draw is two dependent trips to the L1 / L2 and the draws of a Philox block share them.
+// z[j] = ndtri(1 - cdf(k)) of the outcome k drawn with word w[j].  The outcome "n-1 or more" (and a
+// position without a table row) is settled by the direct inverse cdf: the former with the uniform that
+// the word's low bits pick inside the rest (1 - cdf(n-2)), the latter with u[j].
+// rl: alias_row_of() of the position.
+// "Which draws still need the direct evaluation" is kept as wavefront masks in scalar registers --
+// ballots combined with scalar logic, turned back into a lane condition where a select needs one
+// (inverse ballot: free); as bools the compiler materialises each as 0 / 1 in a vector register.
 typedef unsigned long long lane_mask;
 #define FPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)
 #define FPT_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 template <int N>
-__device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint16_t *guide, int memo_obs, const double *par,
-                                           int ei, const double *exp_ptr, const uint32_t (&w)[N],
-                                           const double (&u)[N], double (&z)[N]) {
+__device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint32_t *alias, const double *zt, int memo_obs,
+                                           int lg_max, const double *par, int rl, const double *exp_ptr,
+                                           const uint32_t (&w)[N], const double (&u)[N], double (&z)[N]) {
     lane_mask D[N];  // still to be evaluated directly
     // (a mask is the same for every lane and must not be assigned under a lane's condition: the few
-    // lanes without a table row walk row 0 along with the others and their result is dropped)
-    const lane_mask tabled = FPT_BALLOT(ei >= 0), untabled = FPT_BALLOT(ei < 0);
-    const int lo_tab = ei >= 0 ? memo_obs - 1 : -1;
-    {
-        const uint32_t eiu = ei >= 0 ? (uint32_t)ei : 0u;
-        const uint32_t row = eiu * (uint32_t)memo_obs * 16u, gr = eiu * (uint32_t)(kGuide * 2);
-        const int kl = memo_obs - 1;
-        int a[N], k[N];
-        lane_mask UP[N], M[N];
-        double2 e[N];
-        uint32_t g[N], f[N];
+    // lanes without a table row read row 0 along with the others and their result is dropped)
+    const lane_mask tabled = FPT_BALLOT(rl >= 0), untabled = FPT_BALLOT(rl < 0);
+    const uint32_t eiu = rl >= 0 ? (uint32_t)rl & 0xffffu : 0u, lg = rl >= 0 ? (uint32_t)rl >> 16 : 1u;
+    const uint32_t arow = eiu << (lg_max + 2), zrow = eiu << (lg_max + 3), last = (1u << lg) - 1u;
+    uint32_t e[N], slot[N], k[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) g[j] = guide_pair(guide, gr + 2u * (uint32_t)fptm::guide_index_fixed(w[j], f[j]));
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            a[j] = (int)(g[j] & 0xffffu);  // answer in [a, b]
-            const int width = (int)(g[j] >> 16) - a[j];
-            // first probe: as far into the bracket as the word is into its slot (a wide bracket is an
-            // outermost slot, open towards the end of the table: start at its near end)
-            // (any start inside the bracket gives the same draw: the walk ends at the first entry >= u)
-            k[j] = a[j] + (width > 64 ? 0 : (int)(__umul24(f[j], (uint32_t)width) >> 24));
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j) e[j] = table_entry(memo, row + 16u * (uint32_t)k[j]);
-        // up: the current entry is < u, look above.  down: the current entry is >= u, and the one
-        // below has to be looked at unless the guide already says it is < u (k == a).
-        lane_mask any = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            UP[j] = FPT_BALLOT(e[j].x < u[j]);
-            M[j] = ((UP[j] & FPT_BALLOT(k[j] < kl)) | (~UP[j] & FPT_BALLOT(k[j] > a[j]))) & tabled;
-            any |= M[j];
-        }
-        // One step of the walk for every draw that moves, the loads together.  A lane rarely needs a
-        // second one (0.4 % of the draws: a guide bracket is mostly a step wide) but a wavefront's
-        // 256 draws do 60 % of the time, so the later steps are taken draw by draw: by the one or two
-        // of the four that still have a lane moving.
-        auto step_of = [&](lane_mask Mj, lane_mask UPj) { return FPT_LANE(Mj) ? (FPT_LANE(UPj) ? 1 : -1) : 0; };
-        auto settle = [&](const double2 &cj, int &kj, double2 &ej, lane_mask &Mj, lane_mask UPj, int aj, double uj) {
-            // up: take the entry, stop at the first one >= u.  down: take it while it is >= u (the
-            // entry below qualifies too), stop at the lane's guide bound.
-            const lane_mask lt = FPT_BALLOT(cj.x < uj), ge = FPT_BALLOT(cj.x >= uj);
-            const lane_mask mv = Mj & (UPj | ge);
-            if (FPT_LANE(mv)) {  // (moves under the lanes' mask: two 64-bit moves instead of four selects)
-                kj += FPT_LANE(UPj) ? 1 : -1;
-                ej = cj;
-            }
-            Mj &= (UPj & lt & FPT_BALLOT(kj < kl)) | (~UPj & ge & FPT_BALLOT(kj > aj));
-        };
-        if (any) {
-            double2 c[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) c[j] = table_entry(memo, row + 16u * (uint32_t)(k[j] + step_of(M[j], UP[j])));
-#pragma unroll
-            for (int j = 0; j < N; ++j) settle(c[j], k[j], e[j], M[j], UP[j], a[j], u[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            while (M[j]) {
-                const double2 cj = table_entry(memo, row + 16u * (uint32_t)(k[j] + step_of(M[j], UP[j])));
-                settle(cj, k[j], e[j], M[j], UP[j], a[j], u[j]);
-            }
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            z[j] = e[j].y;
-            // ran off the table (not for NaN rows: those return the NaN entry), or has no row
-            D[j] = (FPT_BALLOT(e[j].x < u[j]) & tabled) | untabled;
-        }
+    for (int j = 0; j < N; ++j) {
+        slot[j] = w[j] >> (32u - lg);
+        e[j] = table_at<uint32_t>(alias, arow + 4u * slot[j]);
     }
+#pragma unroll
+    for (int j = 0; j < N; ++j) k[j] = (w[j] << lg) < (e[j] & ~last) ? slot[j] : (e[j] & last);
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = table_at<double>(zt, zrow + 8u * k[j]);
     lane_mask any_direct = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) any_direct |= D[j];
+    for (int j = 0; j < N; ++j) {
+        D[j] = (FPT_BALLOT(k[j] == last) & tabled) | untabled;
+        any_direct |= D[j];
+    }
     if (any_direct) {  // rare: beyond the table or a non-integer expected value
-        const double ex = ei >= 0 ? (double)ei : *exp_ptr;
+        const double ex = rl >= 0 ? (double)eiu : *exp_ptr;
+        // the rest of the row: (cdf(n-2), 1]
+        const double base = (rl >= 0 && last > 1u) ? memo[(size_t)eiu * memo_obs + (last - 1u)].x
+                                                    : ((rl >= 0) ? memo[(size_t)eiu * memo_obs].x : 0.0);
         // one copy of the evaluation (it is ~8,000 instructions): a lane's draws that need it take
         // turns, picked with selects (an array indexed by the turn would live in scratch memory)
         for (;;) {
             int j = -1;
             double uj = 0.0;
+            uint32_t wj = 0u, ej = 0u;
 #pragma unroll
             for (int i = N - 1; i >= 0; --i) {
                 j = FPT_LANE(D[i]) ? i : j;
                 uj = FPT_LANE(D[i]) ? u[i] : uj;
+                wj = FPT_LANE(D[i]) ? w[i] : wj;
+                ej = FPT_LANE(D[i]) ? e[i] : ej;
             }
             double zz = 0.0;
-            if (j >= 0) zz = nb_inverse_cdf_direct(par, ex, uj, lo_tab).y;
+            if (j >= 0) {
+                int lo = -1;
+                if (rl >= 0) {
+                    // where in its share of the slot the word fell: the slot's own part [0, threshold)
+                    // or the alias part [threshold, 2^(32-lg))
+                    const uint32_t t = (wj << lg) >> lg, th = ej >> lg, span = (0xffffffffu >> lg) + 1u;
+                    const bool own = t < th;
+                    const double frac = ((double)(own ? t : t - th) + 0.5) / (double)(own ? th : span - th);
+                    uj = fma(1.0 - base, frac, base);
+                    lo = (int)last - 1;
+                }
+                zz = nb_inverse_cdf_direct(par, ex, uj, lo).y;
+            }
             any_direct = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1622,8 +1672,8 @@ __device__ __forceinline__ double sum_threshold(double T, double sqrt_k, double 
 
 typedef void (*fdr_kernel_t)(const fdr_args);
 
-#ifdef FPT_ABLATE
-// -DFPT_ABLATE builds: cycles of the first wavefront of every workgroup between the phase marks,
+#ifdef FPT_FDR_MARKS
+// -DFPT_FDR_MARKS builds: cycles of the first wavefront of every workgroup between the phase marks,
 // summed over workgroups (FPT_FDR_PHASES=1 prints them after each launch)
 __device__ unsigned long long g_fdr_phase[16];
 #define FDR_MARK(n)                                                                  \
@@ -1696,7 +1746,9 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
 
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
-    const uint16_t *guide = a.guide + (size_t)dm * a.memo_exp * kGuide;
+    const uint32_t *alias = a.alias + ((size_t)dm * a.memo_exp << a.alias_lg);
+    const double *zt = a.zt + ((size_t)dm * a.memo_exp << a.alias_lg);
+    const uint8_t *row_lg = a.row_lg + (size_t)dm * a.memo_exp;
     if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
     FDR_MARK_INIT
     // ---- 0. with the observed counts at hand, the observed window p-values are re-made here by the
@@ -1903,9 +1955,9 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     const bool direct = hs <= 8;
     int ei_one = -1;  // ONE: the table row of this lane's base
     if (ONE) {
-        if (tid < L) ei_one = table_row_of(a.exp[off + tid], a.memo_exp);
+        if (tid < L) ei_one = alias_row_of(a.exp[off + tid], a.memo_exp, row_lg);
     } else if (direct) {
-        for (int t = tid; t < L; t += NT) nf[t] = table_row_of(a.exp[off + t], a.memo_exp);
+        for (int t = tid; t < L; t += NT) nf[t] = alias_row_of(a.exp[off + t], a.memo_exp, row_lg);
         // (each lane reads back only the entries it wrote: no barrier needed)
     }
     // the loop over a lane's bases: a single trip when ONE
@@ -1935,7 +1987,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                 }
                 // the table row of a position does not change from pass to pass: with direct
                 // windows `nf` is free and holds it (filled above, before the first pass)
-                ei = ONE ? ei_one : (direct ? nf[t] : table_row_of(a.exp[off + t], a.memo_exp));
+                ei = ONE ? ei_one : (direct ? nf[t] : alias_row_of(a.exp[off + t], a.memo_exp, row_lg));
             }
             // u = (word + 1/2) 2^-32 (philox_uniform4), or the caller's uniforms (tests)
             if (direct) {  // the four draws of the block in step, their z side by side in the buffer
@@ -1946,13 +1998,13 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                 for (int j = 0; j < 4; ++j) {
                     w4[j] = w4_[j];
                     u4[j] = fma((double)w4[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
-                    if (ABL(512)) u4[j] = 0.37 + 1e-3 * s + 0.04 * j, w4[j] = fptm::guide_word(u4[j]);
+                    if (ABL(512)) u4[j] = 0.37 + 1e-3 * s + 0.04 * j, w4[j] = fptm::uniform_word(u4[j]);
                 }
                 if (up) {  // (tests: wave-uniform)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         u4[j] = (t < L && j < ns) ? up[j] : 0.5;
-                        w4[j] = fptm::guide_word(u4[j]);
+                        w4[j] = fptm::uniform_word(u4[j]);
                     }
                 }
                 if (t < L) {
@@ -1960,7 +2012,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
 #pragma unroll
                         for (int j = 0; j < 4; ++j) z4[j] = u4[j] - 0.5;
                     } else {
-                        nb_draw_zn<4>(memo, guide, a.memo_obs, par, ei, a.exp + off + t, w4, u4, z4);
+                        nb_draw_zn<4>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w4, u4, z4);
                     }
                     *reinterpret_cast<double2 *>(zq + 4 * t) = make_double2(z4[0], z4[1]);
                     *reinterpret_cast<double2 *>(zq + 4 * t + 2) = make_double2(z4[2], z4[3]);
@@ -1973,13 +2025,13 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                     u2[j] = fma((double)w2[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
                     if (up && t < L) {
                         u2[j] = j < ns ? up[j] : 0.5;
-                        w2[j] = fptm::guide_word(u2[j]);
+                        w2[j] = fptm::uniform_word(u2[j]);
                     }
-                    if (ABL(512)) u2[j] = 0.37 + 1e-3 * s + 0.04 * j, w2[j] = fptm::guide_word(u2[j]);
+                    if (ABL(512)) u2[j] = 0.37 + 1e-3 * s + 0.04 * j, w2[j] = fptm::uniform_word(u2[j]);
                 }
                 if (t < L) {
                     if (ABL(1024)) z2[0] = u2[0] - 0.5, z2[1] = u2[1] - 0.5;
-                    else nb_draw_zn<2>(memo, guide, a.memo_obs, par, ei, a.exp + off + t, w2, u2, z2);
+                    else nb_draw_zn<2>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w2, u2, z2);
                 }
                 const bool f0 = isfinite(z2[0]), f1 = isfinite(z2[1]);
                 const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
@@ -2663,13 +2715,25 @@ void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, 
     hipLaunchKernelGGL(k_plan_tiles, dim3((unsigned)((n_intervals + kPlanBlock - 1) / kPlanBlock)), dim3(kPlanBlock), 0, st, a);
 }
 
-void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide) {
-    hipLaunchKernelGGL(k_nb_guide, dim3((memo_exp * kGuide + 255) / 256, n_models), dim3(256), 0, st,
-                       (const double2 *)memo, memo_exp, memo_obs, (uint16_t *)guide);
+// alias tables, z tables and widths of n_models x memo_exp rows: `tables` holds nb_alias_bytes() -- the
+// entries, then the z (at nb_alias_z_offset), then a byte per row
+static size_t alias_rows(int n_models, int memo_exp) { return (size_t)n_models * memo_exp; }
+size_t nb_alias_z_offset(int n_models, int memo_exp, int memo_obs) {
+    return ((alias_rows(n_models, memo_exp) << alias_lg_of(memo_obs)) * 4 + 255) & ~(size_t)255;
 }
-
-size_t nb_guide_bytes(int n_models, int memo_exp) {
-    return (size_t)n_models * memo_exp * kGuide * sizeof(uint16_t);
+static size_t nb_alias_lg_offset(int n_models, int memo_exp, int memo_obs) {
+    return nb_alias_z_offset(n_models, memo_exp, memo_obs) + (alias_rows(n_models, memo_exp) << alias_lg_of(memo_obs)) * 8;
+}
+size_t nb_alias_bytes(int n_models, int memo_exp, int memo_obs) {
+    return nb_alias_lg_offset(n_models, memo_exp, memo_obs) + alias_rows(n_models, memo_exp);
+}
+void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *tables) {
+    const int lg = alias_lg_of(memo_obs);
+    const size_t n = (size_t)1 << lg;
+    char *t = (char *)tables;
+    hipLaunchKernelGGL(k_nb_alias, dim3(memo_exp, n_models), dim3(64), n * 8 + 3 * n * 2, st, (const double2 *)memo,
+                       memo_exp, memo_obs, lg, (uint32_t *)t, (double *)(t + nb_alias_z_offset(n_models, memo_exp, memo_obs)),
+                       (uint8_t *)(t + nb_alias_lg_offset(n_models, memo_exp, memo_obs)));
 }
 
 size_t fdr_lds_bytes(int n2, bool dbuf) {
@@ -2693,7 +2757,10 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.seed = fl.seed;
     a.model = fl.model;
     a.memo = (const double2 *)fl.memo;
-    a.guide = (const uint16_t *)fl.guide;
+    a.alias = (const uint32_t *)fl.alias;
+    a.zt = (const double *)((const char *)fl.alias + nb_alias_z_offset(fl.n_models, fl.memo_exp, fl.memo_obs));
+    a.row_lg = (const uint8_t *)fl.alias + nb_alias_lg_offset(fl.n_models, fl.memo_exp, fl.memo_obs);
+    a.alias_lg = alias_lg_of(fl.memo_obs);
     a.memo_exp = fl.memo_exp;
     a.memo_obs = fl.memo_obs;
     a.exp = fl.exp;
@@ -2760,7 +2827,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(nt), lds_m, st, b);
         }
     }
-#ifdef FPT_ABLATE
+#ifdef FPT_FDR_MARKS
     if (getenv("FPT_FDR_PHASES")) {
         unsigned long long h[16], z[16] = {};
         (void)hipStreamSynchronize(st);

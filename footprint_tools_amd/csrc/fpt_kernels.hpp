@@ -87,7 +87,8 @@ struct fdr_launch {
     uint64_t seed;
     const double *model;
     const void *memo;
-    const void *guide;  // nb_guide_bytes(), filled by launch_nb_guide after launch_nb_memo
+    const void *alias;  // nb_alias_bytes(), filled by launch_nb_alias after launch_nb_memo
+    int32_t n_models;   // models in `memo` / `alias` (1 without dm_ids)
     int32_t memo_exp, memo_obs;
     const double *exp, *winp;
     const double *obs;  // optional (see fpt_fdr_desc.obs)
@@ -148,14 +149,15 @@ struct segment_launch {
 };
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
 size_t fdr_lds_bytes(int n2, bool dbuf = false);
-void launch_nb_guide(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *guide);
+void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *tables);
 // the tile table of a ragged batch (three int32 arrays of n_tiles in `flat`, 32-byte records in `recs`)
 // from the device offsets: class-major, intervals in order.  block_base (device): for every
 // kPlanBlock intervals and class, the table index of the first tile of the block's first interval.
 constexpr int kPlanBlock = 256;
 void launch_plan_tiles(hipStream_t st, const int64_t *off, int64_t n_intervals, int64_t n_tiles, int H, int split_len,
                        const lean_class_set &cls, const int32_t *block_base, int32_t *flat, void *recs);
-size_t nb_guide_bytes(int n_models, int memo_exp);
+size_t nb_alias_bytes(int n_models, int memo_exp, int memo_obs);
+size_t nb_alias_z_offset(int n_models, int memo_exp, int memo_obs);
 
 void launch_kmer_probs(hipStream_t st, const uint8_t *seq, int64_t n_out, const double *table,
                        double *fwd, double *rev);

@@ -796,47 +796,12 @@ FPT_HD double fit_r(const double *r15, double x, bool *zero_div) {
 }
 
 // ---------------------------------------------------------------------------
-// Guide index of the inverse-CDF null sampler, on the 32-bit word a draw is made of
-// (u = (w + 1/2) 2^-32; a caller-supplied double u is floored to its word).  Two levels of uniform
-// slots, located with shifts: 256 slots on the top byte of w, and the first and the last of them --
-// the two NB tails -- cut into 256 again on the next byte, so every slot but the outermost two
-// (2^-16 of the draws each) holds a k or two and a draw starts its walk next to the answer.
-// Entry layout of a row: [0, 256] level 1 (edge j / 256), [257, 513] the low tail (edge j / 65536),
-// [514, 770] the high tail (edge 255/256 + j / 65536); entry idx + 1 always closes slot idx.
-// guide_index is monotone in w within a level and guide_edge(idx) <= u < guide_edge(idx + 1).
+// The 32-bit word of a caller-supplied uniform of the null sampler: floor(u 2^32) inside the table,
+// so that u = (w + 1/2) 2^-32 gives back w (NaN and u < 0: 0).
 // ---------------------------------------------------------------------------
-constexpr int kGuideEntries = 3 * 257;
-
-FPT_HD uint32_t guide_word(double u) {  // the word of a caller-supplied uniform (NaN and u < 0: 0)
+FPT_HD uint32_t uniform_word(double u) {
     const double x = u * 4294967296.0;
     return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 0xffffffffu : (uint32_t)x);
-}
-
-// index of the slot of w and the position of w inside it, frac in [0, 1)
-FPT_HD int guide_index(uint32_t w, float &frac) {
-    const uint32_t top = w >> 24;
-    const bool low = top == 0u, high = top == 255u;
-    const uint32_t sub = (low || high) ? ((w >> 16) & 255u) : top;
-    const uint32_t fb = (low || high) ? ((w & 0xffffu) << 8) : (w & 0xffffffu);
-    frac = (float)fb * (1.0f / 16777216.0f);
-    return (int)sub + (low ? 257 : (high ? 514 : 0));
-}
-
-// the same with the position as 24 fixed-point bits (frac = frac24 / 2^24): what the sampler's first
-// probe wants -- frac24 * width >> 24 is one 24-bit multiply and a shift where the float form is two
-// conversions, two multiplications and a truncation
-FPT_HD int guide_index_fixed(uint32_t w, uint32_t &frac24) {
-    const uint32_t top = w >> 24;
-    const bool low = top == 0u, high = top == 255u;
-    const uint32_t sub = (low || high) ? ((w >> 16) & 255u) : top;
-    frac24 = (low || high) ? ((w & 0xffffu) << 8) : (w & 0xffffffu);
-    return (int)sub + (low ? 257 : (high ? 514 : 0));
-}
-
-FPT_HD double guide_edge(int idx) {
-    if (idx <= 256) return (double)idx * (1.0 / 256.0);
-    if (idx <= 513) return (double)(idx - 257) * (1.0 / 65536.0);
-    return 255.0 / 256.0 + (double)(idx - 514) * (1.0 / 65536.0);
 }
 
 }  // namespace fptm

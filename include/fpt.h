@@ -215,12 +215,27 @@ int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
  * pooled null values: efdr = min(1, #{null <= p} / (L*times)), NaN -> 1 (fdr/__init__.py:12-33,
  * utils.pyx:52-79).
  *
- * Here all of that is one kernel per interval.  The draw and its p-value are taken together by
- * inverse-CDF sampling on the (exp, obs) table of FPT_NB_MEMO: for u ~ U(0,1) the draw is the
- * smallest k with cdf(k) >= u and its p-value is that cdf(k) (outside the table: galloping +
- * bisection on the direct incbet).  u comes from Philox4x32-10 keyed by `seed` with counter
- * (global base index, sample index), so results are reproducible and independent of how
- * intervals are sharded; they are statistically, not bitwise, the reference's (numpy MT19937). */
+ * Here all of that is one kernel per interval.  The draw and its p-value are taken together from a
+ * 32-bit word w of Philox4x32-10 keyed by `seed` with counter (global base index, sample index), so
+ * results are reproducible and independent of how intervals are sharded; they are statistically, not
+ * bitwise, the reference's (numpy MT19937).
+ *
+ * The null draws, exactly (tests restate this; doubles operation for operation):
+ *   - at an expected value that is an integer below the table's height (256) the draw is an ALIAS-table
+ *     lookup.  The row's outcomes are k = 0 .. n-2 with probability cdf(k) - cdf(k-1) and "n-1 or more"
+ *     with 1 - cdf(n-2); n = 2^lg is the smallest power of two with 1 - cdf(n-2) <= 2^-32, at most the
+ *     largest power of two <= the table's width (2048), lg >= 1.  With q(k) = n p(k), negative p taken
+ *     as 0: outcomes with q < 1 are queued as "small", the others as "large", both in index order; while
+ *     both queues hold something, the first small s gets alias = first large l, q(l) = (q(l) + q(s)) - 1,
+ *     and l moves to the end of the small queue when that is < 1; whatever is left gets q = 1.
+ *     entry(k) = threshold << lg | alias, threshold = floor(q(k) 2^(32-lg) + 1/2) capped at 2^(32-lg) - 1.
+ *     Draw: slot = w >> (32 - lg), t = w mod 2^(32-lg), outcome = t < threshold(slot) ? slot : alias(slot);
+ *     its p-value is cdf(outcome).  (A row with a NaN: outcome = slot.)
+ *   - the outcome "n-1 or more" is the smallest k >= n-1 with cdf(k) >= u', u' = cdf(n-2) + (1 - cdf(n-2)) f,
+ *     f = (position of t within its part of the slot -- [0, threshold) or [threshold, 2^(32-lg)) -- + 1/2)
+ *     / (size of that part): galloping + bisection on the direct incbet.
+ *   - at any other expected value: the smallest k with cdf(k) >= u, u = (w + 1/2) 2^-32, by the same search.
+ * A table's probabilities are the row's to about 2^-31 per outcome (thresholds are rounded to 2^-32). */
 typedef struct fpt_fdr_desc {
     int64_t n_intervals;
     int32_t interval_len;             /* uniform batches (interval_off == NULL) */
@@ -236,7 +251,7 @@ typedef struct fpt_fdr_desc {
     const double *winp;               /* DEVICE: observed window p-values, same window */
     double *efdr_out;                 /* DEVICE: empirical FDR track */
     const double *null_uniform;       /* optional DEVICE [sum(L) * times] uniforms replacing Philox
-                                       * (row-major base x sample): deterministic tests */
+                                       * (row-major base x sample; w = floor(u 2^32)): deterministic tests */
     double *null_winp_out;            /* optional DEVICE [sum(L) * times]: the null window p-values
                                        * (detect.py:133 win_pvals_null, row-major base x sample) */
     const double *obs;                /* optional DEVICE: the observed counts track the p-values were made

@@ -1082,8 +1082,8 @@ void orc_synth_hotspots(uint64_t seed, int64_t pos0, int64_t n, int stream, int 
 }
 
 /* ------------------------------------------------------------------ empirical FDR with the
- * library's reproducible null sampler (cli/detect.py:132-135 with the NB draws taken by
- * inverse-CDF from Philox uniforms instead of numpy's MT19937; see include/fpt.h fpt_fdr_dev) */
+ * library's reproducible null sampler (cli/detect.py:132-135 with the NB draws made from Philox
+ * words -- alias tables, the inverse cdf off them -- instead of numpy's MT19937; see include/fpt.h fpt_fdr_dev) */
 
 static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     for (int r = 0; r < 10; r++) {
@@ -1108,31 +1108,89 @@ double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample) {
     return ((double)c[sample & 3u] + 0.5) * (1.0 / 4294967296.0);
 }
 
-/* smallest k with cdf(k) >= u -> cdf(k); table_k = number of tabulated k per integer exp */
-static double inverse_cdf_pvalue(const double *mu_par9, const double *r_par15, double ex, double u,
-                                 int table_exp, int table_k, double **rows) {
-    double r, mu;
-    orc_fit_r(r_par15, ex, &r);
-    mu = orc_fit_mu(mu_par9, ex);
-    double pr = r / (r + mu);
-    int lo = -1;
-    int ei = (int)ex;
-    if (ex >= 0.0 && ex < (double)table_exp && (double)ei == ex) {
-        if (!rows[ei]) {
-            rows[ei] = (double *)malloc(table_k * sizeof(double));
-            for (int k = 0; k < table_k; k++) rows[ei][k] = orc_nb_cdf(k, pr, r);
-        }
-        const double *row = rows[ei];
-        if (!(row[table_k - 1] < u)) {
-            int l = 0, h = table_k - 1;
-            while (l < h) {
-                int mid = (l + h) >> 1;
-                if (row[mid] >= u) h = mid; else l = mid + 1;
-            }
-            return row[h];
-        }
-        lo = table_k - 1;
+/* The library's null sampler (include/fpt.h fpt_fdr_dev, "the null draws"): at an integer expected
+ * value below table_exp a draw is an ALIAS-table lookup on the 32-bit word, anywhere else the inverse
+ * cdf on u.  Restated from the header's definition, operation for operation where doubles are involved:
+ *   - the row's outcomes are k = 0 .. n-2 (probability cdf(k) - cdf(k-1)) and "n-1 or more" (1 - cdf(n-2)),
+ *     n = 2^lg the smallest power of two with 1 - cdf(n-2) <= 2^-32, at most 2^lg_max <= table_k (lg_max <= 11)
+ *   - Vose's construction with two queues filled in index order (small: n p < 1)
+ *   - entry = threshold << lg | alias, threshold = round(q 2^(32-lg)) capped at 2^(32-lg) - 1
+ *   - draw: slot = w >> (32 - lg), t = w mod 2^(32-lg), outcome = t < threshold ? slot : alias
+ *   - the outcome "n-1 or more": inverse cdf from k = n-1 on with u' = cdf(n-2) + (1 - cdf(n-2)) frac,
+ *     frac = (position of t in its part of the slot + 1/2) / (size of that part)
+ * A row with a NaN gets the identity table. */
+typedef struct {
+    int lg, n;
+    double *cdf;      /* cdf(0 .. n-1) (the last one is not an outcome of its own) */
+    uint32_t *entry;  /* n */
+} alias_row;
+
+static int alias_lg_cap(int table_k) {
+    int lg = 1;
+    while (lg < 11 && (2 << lg) <= table_k) ++lg;
+    return lg;
+}
+
+static uint32_t uniform_word(double u) { /* floor(u 2^32) inside the table; NaN and u < 0: 0 */
+    double x = u * 4294967296.0;
+    return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 0xffffffffu : (uint32_t)x);
+}
+
+static alias_row *alias_row_build(double pr, double r, int table_k) {
+    alias_row *a = (alias_row *)malloc(sizeof *a);
+    int lg_max = alias_lg_cap(table_k);
+    a->lg = lg_max;
+    for (int c = 1; c <= lg_max; c++) {
+        int idx = (1 << c) - 2;
+        if (idx < table_k && 1.0 - orc_nb_cdf(idx, pr, r) <= 1.0 / 4294967296.0) { a->lg = c; break; }
     }
+    int lg = a->lg, n = a->n = 1 << lg;
+    a->cdf = (double *)malloc(n * sizeof(double));
+    a->entry = (uint32_t *)malloc(n * sizeof(uint32_t));
+    double *q = (double *)malloc(n * sizeof(double));
+    int *sq = (int *)malloc(n * sizeof(int)), *lq = (int *)malloc(n * sizeof(int)), *al = (int *)malloc(n * sizeof(int));
+    int ns = 0, nl = 0, bad = 0;
+    for (int k = 0; k < n; k++) a->cdf[k] = k < table_k ? orc_nb_cdf(k, pr, r) : 1.0;
+    for (int k = 0; k < n; k++) {
+        double pm = (k == n - 1 ? 1.0 : a->cdf[k]) - (k > 0 ? a->cdf[k - 1] : 0.0);
+        if (pm != pm) bad = 1;
+        pm = pm > 0.0 ? pm : 0.0;
+        q[k] = pm * (double)n;
+        al[k] = k;
+        if (q[k] < 1.0) sq[ns++] = k; else lq[nl++] = k;
+    }
+    uint32_t top = 0xffffffffu >> lg;
+    if (!bad) {
+        int si = 0, li = 0, se = ns;
+        while (si < se && li < nl) {
+            int s_ = sq[si++], l = lq[li];
+            al[s_] = l;
+            double ql = (q[l] + q[s_]) - 1.0;
+            q[l] = ql;
+            if (ql < 1.0) { sq[se++] = l; ++li; }
+        }
+        while (li < nl) q[lq[li++]] = 1.0;
+        while (si < se) { int s_ = sq[si++]; q[s_] = 1.0; al[s_] = s_; }
+    }
+    for (int k = 0; k < n; k++) {
+        uint32_t th = top, ak = (uint32_t)k;
+        if (!bad) {
+            double t = floor(ldexp(q[k], 32 - lg) + 0.5);
+            th = t >= (double)top ? top : (uint32_t)t;
+            ak = (uint32_t)al[k];
+        }
+        a->entry[k] = (th << lg) | ak;
+    }
+    free(q); free(sq); free(lq); free(al);
+    return a;
+}
+
+static void alias_row_free(alias_row *a) {
+    if (a) { free(a->cdf); free(a->entry); free(a); }
+}
+
+/* smallest k > lo with cdf(k) >= u -> cdf(k): gallop, then bisect (lo: largest k known to have cdf(k) < u) */
+static double inverse_cdf_from(double pr, double r, double u, int lo) {
     int step = 1, hi = lo + 1;
     double chi = orc_nb_cdf(hi, pr, r);
     while (chi < u && hi < (1 << 28)) {
@@ -1149,12 +1207,67 @@ static double inverse_cdf_pvalue(const double *mu_par9, const double *r_par15, d
     return chi;
 }
 
+/* one draw at expected value ex with the uniform u (word = uniform_word(u)) -> cdf(k) of the outcome k;
+ * rows: table_exp lazily built alias rows; k_out (optional): the outcome, -1 when it came from the direct search */
+static double null_draw_pvalue(const double *mu_par9, const double *r_par15, double ex, double u,
+                               int table_exp, int table_k, alias_row **rows, int *k_out) {
+    double r, mu;
+    orc_fit_r(r_par15, ex, &r);
+    mu = orc_fit_mu(mu_par9, ex);
+    double pr = r / (r + mu);
+    int ei = (int)ex;
+    if (k_out) *k_out = -1;
+    if (!(ex >= 0.0 && ex < (double)table_exp && (double)ei == ex)) return inverse_cdf_from(pr, r, u, -1);
+    if (!rows[ei]) rows[ei] = alias_row_build(pr, r, table_k);
+    const alias_row *a = rows[ei];
+    const int lg = a->lg;
+    const uint32_t w = uniform_word(u), last = (uint32_t)a->n - 1u;
+    const uint32_t slot = w >> (32 - lg), t = (uint32_t)(w << lg) >> lg, e = a->entry[slot], th = e >> lg;
+    const uint32_t k = t < th ? slot : (e & last);
+    if (k != last) {
+        if (k_out) *k_out = (int)k;
+        return a->cdf[k];
+    }
+    const double base = a->cdf[last - 1u];
+    const uint32_t span = (0xffffffffu >> lg) + 1u;
+    const int own = t < th;
+    const double frac = ((double)(own ? t : t - th) + 0.5) / (double)(own ? th : span - th);
+    return inverse_cdf_from(pr, r, fma(1.0 - base, frac, base), (int)last - 1);
+}
+
+/* test access to one row's table: entry_out[2^lg], cdf_out[2^lg]; returns lg */
+int orc_null_alias_row(const double *mu_par9, const double *r_par15, double ex, int table_k, uint32_t *entry_out,
+                       double *cdf_out) {
+    double r, mu;
+    orc_fit_r(r_par15, ex, &r);
+    mu = orc_fit_mu(mu_par9, ex);
+    alias_row *a = alias_row_build(r / (r + mu), r, table_k);
+    int lg = a->lg;
+    if (entry_out) memcpy(entry_out, a->entry, a->n * sizeof(uint32_t));
+    if (cdf_out) memcpy(cdf_out, a->cdf, a->n * sizeof(double));
+    alias_row_free(a);
+    return lg;
+}
+
+/* n draws at one expected value from given uniforms: outcome (or -1) and cdf of each (tests of the sampler) */
+void orc_null_draws(const double *mu_par9, const double *r_par15, double ex, const double *u, int64_t n,
+                    int table_exp, int table_k, int32_t *k_out, double *p_out) {
+    alias_row **rows = (alias_row **)calloc(table_exp > 0 ? table_exp : 1, sizeof(alias_row *));
+    for (int64_t i = 0; i < n; i++) {
+        int k;
+        p_out[i] = null_draw_pvalue(mu_par9, r_par15, ex, u[i], table_exp, table_k, rows, &k);
+        if (k_out) k_out[i] = k;
+    }
+    for (int i = 0; i < table_exp; i++) alias_row_free(rows[i]);
+    free(rows);
+}
+
 /* one interval: exp_[L], winp[L] -> efdr[L].  uniforms (L*times, base-major) may be NULL
  * (then Philox(seed, base0 + t, s)); null_out (L*times) optionally receives the null p-values */
 void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *exp_, const double *winp,
                   int L, int hw, int times, uint64_t seed, int64_t base0, const double *uniforms,
                   int table_exp, int table_k, double *efdr_out, double *null_out) {
-    double **rows = (double **)calloc(table_exp > 0 ? table_exp : 1, sizeof(double *));
+    alias_row **rows = (alias_row **)calloc(table_exp > 0 ? table_exp : 1, sizeof(alias_row *));
     double *pn = (double *)malloc((size_t)L * times * sizeof(double));   /* [L][times] like sample() */
     double *wn = (double *)malloc((size_t)L * times * sizeof(double));
     double *col = (double *)malloc((size_t)L * sizeof(double));
@@ -1163,8 +1276,7 @@ void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *ex
         for (int s = 0; s < times; s++) {
             double u = uniforms ? uniforms[(size_t)t * times + s]
                                 : orc_philox_uniform(seed, (uint64_t)(base0 + t), (uint32_t)s);
-            pn[(size_t)t * times + s] = inverse_cdf_pvalue(mu_par9, r_par15, exp_[t], u, table_exp,
-                                                           table_k, rows);
+            pn[(size_t)t * times + s] = null_draw_pvalue(mu_par9, r_par15, exp_[t], u, table_exp, table_k, rows, NULL);
         }
     /* detect.py:133: np.apply_along_axis(win_pval_fn, 0, pvals_null) */
     for (int s = 0; s < times; s++) {
@@ -1174,6 +1286,6 @@ void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *ex
     }
     if (null_out) memcpy(null_out, wn, (size_t)L * times * sizeof(double));
     orc_emperical_fdr(wn, (int64_t)L * times, winp, L, efdr_out);
-    for (int i = 0; i < table_exp; i++) free(rows[i]);
+    for (int i = 0; i < table_exp; i++) alias_row_free(rows[i]);
     free(rows); free(pn); free(wn); free(col); free(wcol);
 }

@@ -108,6 +108,10 @@ int orc_log_likelihood_row(const double *mu_par9, const double *r_par15, const d
 /* ---- empirical FDR with the library's reproducible (Philox, inverse-CDF) null sampler */
 void orc_philox_raw(uint32_t *c4, uint32_t k0, uint32_t k1); /* Philox4x32-10 */
 double orc_philox_uniform(uint64_t seed, uint64_t base, uint32_t sample);
+int orc_null_alias_row(const double *mu_par9, const double *r_par15, double ex, int table_k, uint32_t *entry_out,
+                       double *cdf_out);
+void orc_null_draws(const double *mu_par9, const double *r_par15, double ex, const double *u, int64_t n,
+                    int table_exp, int table_k, int32_t *k_out, double *p_out);
 void orc_fdr_null(const double *mu_par9, const double *r_par15, const double *exp_, const double *winp,
                   int L, int hw, int times, uint64_t seed, int64_t base0, const double *uniforms,
                   int table_exp, int table_k, double *efdr_out, double *null_out);

@@ -272,9 +272,34 @@ def posterior_stats(obs, exp, fdr, w, betas, models, cutoff=0.05, hw=3, pseudoco
     return post.T, dict(prior=prior, delta=delta, ll_on=ll_on, ll_off=ll_off)
 
 
-def fdr_null(mu_par, r_par, exp, winp, hw, times, seed, base0=0, uniforms=None, table=(256, 256),
+def null_alias_row(mu_par, r_par, ex, table_k=2048):
+    """The alias table of the null sampler at the integer expected value `ex`: (lg, entries[2^lg], cdf[2^lg])."""
+    L = lib()
+    L.orc_null_alias_row.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_null_alias_row.restype = C.c_int
+    ent, cdf = np.zeros(2048, np.uint32), np.zeros(2048)
+    mu_par, r_par = _f(mu_par), _f(r_par)
+    lg = L.orc_null_alias_row(mu_par.ctypes.data, r_par.ctypes.data, float(ex), int(table_k), ent.ctypes.data, cdf.ctypes.data)
+    return lg, ent[:1 << lg].copy(), cdf[:1 << lg].copy()
+
+
+def null_draws(mu_par, r_par, ex, u, table=(256, 2048)):
+    """Draws of the null sampler at one expected value from the uniforms `u`: (outcome or -1, cdf of the outcome)."""
+    L = lib()
+    L.orc_null_draws.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_null_draws.restype = None
+    u = _f(u)
+    k, p = np.empty(u.size, np.int32), np.empty(u.size)
+    mu_par, r_par = _f(mu_par), _f(r_par)
+    L.orc_null_draws(mu_par.ctypes.data, r_par.ctypes.data, float(ex), u.ctypes.data, u.size, table[0], table[1],
+                     k.ctypes.data, p.ctypes.data)
+    return k, p
+
+
+def fdr_null(mu_par, r_par, exp, winp, hw, times, seed, base0=0, uniforms=None, table=(256, 2048),
              return_null=False):
-    """One interval of the reproducible empirical-FDR pass (see fpt_fdr_dev in include/fpt.h)."""
+    """One interval of the reproducible empirical-FDR pass (see fpt_fdr_dev in include/fpt.h).  `table`: the
+    library's table dimensions (the alias tables of the draws depend on the second)."""
     exp, winp = _f(exp), _f(winp)
     L = exp.size
     out = np.empty(L)

@@ -23,10 +23,7 @@ void hm_incbet(const double *a, const double *b, const double *x, long n, double
 void hm_chdtrc(const double *df, const double *x, long n, double *out) {
     for (long i = 0; i < n; i++) out[i] = fptm::chdtrc(df[i], x[i]);
 }
-int hm_guide_entries() { return fptm::kGuideEntries; }
-unsigned hm_guide_word(double u) { return fptm::guide_word(u); }
-double hm_guide_edge(int idx) { return fptm::guide_edge(idx); }
-int hm_guide_index(unsigned w, float *frac) { return fptm::guide_index(w, *frac); }
+unsigned hm_uniform_word(double u) { return fptm::uniform_word(u); }
 // what: 0 cdf, 1 logpmf, 2 pmf; returns 1 if a zero division was flagged
 int hm_nb_values(int what, const double *mu9, const double *r15, const double *e, const double *o,
                  long n, double *out) {

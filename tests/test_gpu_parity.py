@@ -1080,36 +1080,43 @@ def test_fdr_null_given_uniforms_and_ragged(fpt, orc):
 
 
 def test_fdr_null_draws_exact(fpt, orc):
-    """every draw of the null sampler is the smallest k with cdf(k) >= u of the device's own
-    table, also for uniforms chosen to sit ON the decision boundaries (table cdf values, their
-    neighbours, both ends of a row, slot edges of the guide); odd `times`; and the Philox draws
-    equal the oracle's."""
-    from footprint_tools_amd.modeling import dispersion
+    """every draw of the null sampler is the outcome include/fpt.h defines for its word -- the device's
+    alias tables are the oracle's entry for entry -- also for words chosen to sit ON the decision
+    boundaries (a slot's threshold and its neighbours, both ends of a slot, the first and the last slot of
+    a row, the rest "n-1 or more" of a capped row); odd `times`; and the Philox draws equal the oracle's."""
     from footprint_tools_amd.scan import FootprintScanner
     from footprint_tools_amd.stats import windowing
     lat = golden("nb_lattice.npz")
     table = golden("kmer_probs.npz")["table"]
     sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,))
-    dm = dispersion.dispersion_model()
-    dm.mu_params, dm.r_params = lat["mu_A"], lat["r_A"]
     rs = np.random.RandomState(12)
     L, times = 333, 9
     exp = rs.choice([0, 1, 2, 3, 5, 8, 13, 19, 19, 19, 30, 44, 60, 90, 150, 255], L).astype(np.float64)
-    ks = np.arange(256, dtype=np.float64)
-    u = rs.uniform(0, 1, (L, times))
+    u = np.empty((L, times))
     pn = np.empty((L, times))
     rows = {}
+    on_edge = in_rest = 0
     for t in range(L):
         if exp[t] not in rows:
-            rows[exp[t]] = dm.p_values(np.full(256, exp[t]), ks)  # the bits the device table holds
-        cdf = rows[exp[t]]
-        c = cdf[rs.randint(0, 256, times)]
-        pick = rs.randint(0, 9, times)
-        e2 = 2.0 ** -rs.randint(1, 21, times)
-        cand = np.stack([c, np.nextafter(c, 1.0), np.nextafter(c, 0.0), e2, 1.0 - e2, np.nextafter(e2, 0.0),
-                         np.zeros(times), np.full(times, cdf[255]), u[t]])
-        u[t] = np.minimum(np.clip(cand[pick, np.arange(times)], 0.0, 1.0 - 2.0 ** -53), cdf[255])
-        pn[t] = cdf[np.searchsorted(cdf, u[t], side="left")]
+            rows[exp[t]] = orc.null_alias_row(lat["mu_A"], lat["r_A"], exp[t])
+        lg, ent, cdf = rows[exp[t]]
+        n, span = 1 << lg, 1 << (32 - lg)
+        slot = np.where(rs.randint(0, 4, times) == 0, rs.choice([0, n - 1], times), rs.randint(0, n, times))
+        th = (ent[slot] >> lg).astype(np.int64)
+        pick = rs.randint(0, 7, times)
+        tt = np.stack([th - 1, th, th + 1, np.zeros(times, np.int64), np.full(times, span - 1), rs.randint(0, span, times),
+                       rs.randint(0, span, times)])[pick, np.arange(times)]
+        tt = np.clip(tt, 0, span - 1)
+        w = (slot.astype(np.int64) << (32 - lg)) | tt
+        u[t] = (w + rs.choice([0.0, 0.5, 0.999], times)) / 2.0 ** 32   # any u of the word's cell is the word
+        k = np.where(tt < th, slot, (ent[slot] & (n - 1)).astype(np.int64))
+        kk, pp = orc.null_draws(lat["mu_A"], lat["r_A"], exp[t], u[t])
+        assert np.array_equal(kk[k != n - 1], k[k != n - 1]) and np.all(kk[k == n - 1] == -1)
+        assert np.array_equal(pp[k != n - 1], cdf[k[k != n - 1]])
+        pn[t] = pp
+        on_edge += int(((tt == th) | (tt == th - 1)).sum())
+        in_rest += int((k == n - 1).sum())
+    assert on_edge > L and in_rest > 0
     winp = rs.uniform(0, 1, L)
     ef, nul = sc.fdr(exp, winp, times=times, interval_len=L, null_uniform=u, return_null=True)
     want = np.stack([windowing.stouffers_z(np.ascontiguousarray(pn[:, s]), 3) for s in range(times)], axis=1)
@@ -1123,6 +1130,33 @@ def test_fdr_null_draws_exact(fpt, orc):
                                       return_null=True)
     assert rel_err(nul, want_null) < 1e-9
     assert np.max(np.abs(ef - want_ef)) <= 2.5 / (L * times)
+
+
+def test_fdr_null_narrow_table_rest_of_the_row(fpt, orc):
+    """a memo of 16 columns (fpt_set_memo_dims on a context of its own): every row's alias table is capped at
+    16 outcomes and a good share of the draws falls into "15 or more", which is settled by the inverse cdf
+    with the uniform the word picks inside the rest -- draw for draw the oracle's with the same dimensions."""
+    from footprint_tools_amd import _lib
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = _lib.Context()
+    try:
+        _lib.check(ctx.L.fpt_set_memo_dims(ctx.h, 64, 16))
+        sc = FootprintScanner(table, _DM(lat["mu_C"], lat["r_C"]), 5, 50, 0.01, (3,), ctx=ctx)
+        rs = np.random.RandomState(21)
+        L, times = 211, 13
+        exp = rs.choice([0, 1, 3, 8, 8, 13, 19, 30, 44, 63, 64, 90, 2.5], L).astype(np.float64)
+        winp = rs.uniform(0, 1, L)
+        ef, nul = sc.fdr(exp, winp, times=times, seed=3, interval_len=L, base_index0=999, return_null=True)
+        want_ef, want_null = orc.fdr_null(lat["mu_C"], lat["r_C"], exp, winp, 3, times, seed=3, base0=999,
+                                          table=(64, 16), return_null=True)
+        assert rel_err(nul, want_null) < 1e-9
+        assert np.max(np.abs(ef - want_ef)) <= 2.5 / (L * times)
+        u = (rs.randint(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.float64) + 0.5) / 2.0 ** 32
+        assert (orc.null_draws(lat["mu_C"], lat["r_C"], 19, u, table=(64, 16))[0] < 0).mean() > 0.2
+    finally:
+        ctx.close()
 
 
 def test_fdr_null_vs_reference_sampler(fpt, orc):

@@ -87,58 +87,91 @@ def test_nb_lattice_host(hm):
     assert hm.hm_nb_values(0, g["mu_D"], g["r_D"], np.array([1., 2.5, 3.]), np.ones(3), 3, out) == 1
 
 
-def test_guide_index_of_null_sampler(hm, orc):
-    """The slot of a draw's 32-bit word: guide_edge(idx) <= u < guide_edge(idx + 1), the index and the
-    position inside a slot grow with the word, and a walk that starts at the guide entry is short for
-    every expected value of the NB lattice."""
-    hm.hm_guide_edge.argtypes = [C.c_int]
-    hm.hm_guide_edge.restype = C.c_double
-    hm.hm_guide_word.argtypes = [C.c_double]
-    hm.hm_guide_word.restype = C.c_uint32
-    hm.hm_guide_index.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
-    n = hm.hm_guide_entries()
-    assert n == 3 * 257
-    rs = np.random.RandomState(4)
-    w = np.concatenate([rs.randint(0, 2 ** 32, 20000, dtype=np.uint64), rs.randint(0, 2 ** 24, 5000, dtype=np.uint64),
-                        2 ** 32 - 1 - rs.randint(0, 2 ** 24, 5000, dtype=np.uint64),
-                        [0, 1, 2 ** 16 - 1, 2 ** 16, 2 ** 24 - 1, 2 ** 24, 255 * 2 ** 24 - 1, 255 * 2 ** 24,
-                         2 ** 32 - 2 ** 16 - 1, 2 ** 32 - 2 ** 16, 2 ** 32 - 1]]).astype(np.uint64)
-    w.sort()
-    u = (w.astype(np.float64) + 0.5) / 2.0 ** 32
-    fr = C.c_float()
-    loc = np.array([(hm.hm_guide_index(int(x), C.byref(fr)), fr.value) for x in w])
-    idx, frac = loc[:, 0].astype(int), loc[:, 1]
-    edge = np.array([hm.hm_guide_edge(int(s)) for s in range(n)])
-    assert idx[0] == 257 and idx[-1] == 769 and idx.min() == 1 and 0 <= frac.min() and frac.max() < 1.0
-    assert not np.any((idx == 0) | ((idx >= 255) & (idx <= 256)) | (idx == 513) | (idx == 770))  # closing entries only
-    assert np.all(edge[idx] <= u) and np.all(u < edge[idx + 1])
-    for lo, hi in ((0, 256), (257, 513), (514, 770)):  # every level: edges and indices in order
-        assert np.all(np.diff(edge[lo:hi + 1]) > 0)
-        lvl = (idx >= lo) & (idx < hi)
-        assert np.all(np.diff(idx[lvl]) >= 0)
-    same = np.diff(idx) == 0
-    assert np.all(np.diff(frac)[same] >= 0)  # position inside a slot grows with the word
-    assert edge[256] == 1.0 and edge[513] == edge[1] and edge[770] == 1.0 and edge[514] == edge[255]
-    # the word of a caller-supplied double: floor(u 2^32), out-of-range / NaN inside the table
-    assert [hm.hm_guide_word(x) for x in (0.0, 0.5, 1.0 - 2.0 ** -53, -1.0, 7.0, float("nan"), 2.0 ** -33)] == \
+def test_uniform_word_of_null_sampler(hm):
+    """The word of a caller-supplied double: floor(u 2^32), out-of-range / NaN inside the table, and the
+    library's own uniforms (w + 1/2) 2^-32 give back w."""
+    hm.hm_uniform_word.argtypes = [C.c_double]
+    hm.hm_uniform_word.restype = C.c_uint32
+    assert [hm.hm_uniform_word(x) for x in (0.0, 0.5, 1.0 - 2.0 ** -53, -1.0, 7.0, float("nan"), 2.0 ** -33)] == \
         [0, 2 ** 31, 2 ** 32 - 1, 0, 2 ** 32 - 1, 0, 0]
+    rs = np.random.RandomState(4)
     uu = rs.random_sample(2000)
-    ww = np.array([hm.hm_guide_word(float(x)) for x in uu], np.float64)
+    ww = np.array([hm.hm_uniform_word(float(x)) for x in uu], np.float64)
     assert np.all(ww / 2.0 ** 32 <= uu) and np.all(uu < (ww + 1) / 2.0 ** 32)
-    # probes of the walk from the interpolated start (nb_draw_z2): up while cdf < u, down while the
-    # entry below still qualifies
+    w = np.concatenate([rs.randint(0, 2 ** 32, 2000, dtype=np.uint64), [0, 1, 2 ** 21 - 1, 2 ** 21, 2 ** 32 - 1]])
+    assert [hm.hm_uniform_word(float((x + 0.5) / 2.0 ** 32)) for x in w] == [int(x) for x in w]
+
+
+def _alias_implied_pmf(lg, ent):
+    """The distribution an alias table draws from, exactly: slot s gives itself for threshold / 2^(32-lg) of
+    its 1 / n and its alias for the rest."""
+    n = 1 << lg
+    acc = (ent >> lg).astype(np.float64) / 2.0 ** (32 - lg)
+    p = np.zeros(n)
+    np.add.at(p, np.arange(n), acc / n)
+    np.add.at(p, (ent & (n - 1)).astype(int), (1.0 - acc) / n)
+    return p
+
+
+def test_null_sampler_alias_tables(orc):
+    """The alias tables of the null sampler (include/fpt.h, fpt_fdr_dev): the width of a row is the smallest
+    power of two whose rest is <= 2^-32 (or the cap), every entry's alias is an outcome of the row, and the
+    distribution the table draws from is the row's pmf to a few 2^-32 per outcome."""
     lat = golden("nb_lattice.npz")
-    ks = np.arange(256, dtype=np.float64)
-    worst, mean = 0, 0.0
-    for ex in (0.0, 1.0, 5.0, 19.0, 60.0):
-        cdf = orc.nb_values("cdf", lat["mu_A"], lat["r_A"], np.full(256, ex), ks)
-        g = np.minimum(np.searchsorted(cdf, edge, side="left"), 255)
-        a, b = g[idx], g[idx + 1]
-        k0 = a + np.where(b - a > 64, 0, (frac.astype(np.float32) * (b - a).astype(np.float32)).astype(int))
-        stop = np.minimum(np.searchsorted(cdf, u, side="left"), 255)
-        steps = np.where(stop > k0, stop - k0, np.where(k0 > a, k0 - stop + 1, 0))
-        assert np.all((a <= stop) & (stop <= b))  # the bracket holds the answer
-        inner = (u < 1 - 2.0 ** -16) & (u > 2.0 ** -16)
-        worst = max(worst, int(steps[inner].max()))
-        mean = max(mean, float(steps.mean()))  # (two thirds of the words are uniform, the rest from the tails)
-    assert worst <= 8 and mean < 0.5, (worst, mean)
+    for key in "ABC":
+        for ex in (0, 1, 2, 3, 7, 10, 40, 120, 255):
+            lg, ent, cdf = orc.null_alias_row(lat["mu_" + key], lat["r_" + key], ex)
+            n = 1 << lg
+            assert 1 <= lg <= 11 and ent.size == n
+            want = orc.nb_values("cdf", lat["mu_" + key], lat["r_" + key], np.full(n, float(ex)), np.arange(n, dtype=np.float64))
+            assert np.array_equal(cdf, want)
+            rest = 1.0 - cdf[n - 2]
+            assert rest <= 2.0 ** -32 or lg == 11
+            if lg > 1 and n // 2 - 2 >= 0:
+                assert 1.0 - cdf[n // 2 - 2] > 2.0 ** -32  # no narrower table would do
+            pm = np.diff(np.concatenate([[0.0], cdf[:n - 1], [1.0]]))
+            assert np.abs(_alias_implied_pmf(lg, ent) - pm).max() < 4e-9, (key, ex)
+            assert np.all(pm[(ent & (n - 1)).astype(int)][(ent >> lg) < (2 ** (32 - lg) - 1)] > 0)  # an alias has mass
+    # a narrow memo caps the width: 2^lg <= table_k, the rest of the row goes to "n-1 or more"
+    lg, ent, cdf = orc.null_alias_row(lat["mu_A"], lat["r_A"], 40, table_k=16)
+    assert lg == 4
+    pm = np.diff(np.concatenate([[0.0], cdf[:15], [1.0]]))
+    assert pm[-1] > 0.1 and np.abs(_alias_implied_pmf(lg, ent) - pm).max() < 1e-9
+    lg, ent, cdf = orc.null_alias_row(lat["mu_A"], lat["r_A"], 3, table_k=1)
+    assert lg == 1 and ent.size == 2
+
+
+def test_null_sampler_draws_follow_the_pmf(orc):
+    """Draws of the null sampler from uniform words: outcome counts against the row's pmf (chi-square over the
+    outcomes with an expected count of 20 or more), the rest of a capped row through the inverse cdf, and a
+    non-integer expected value by the inverse cdf on u."""
+    lat = golden("nb_lattice.npz")
+    rs = np.random.RandomState(11)
+    n_draw = 400000
+    for key, ex, table in (("A", 3, (256, 2048)), ("B", 40, (256, 2048)), ("C", 10, (256, 2048)), ("A", 40, (256, 16))):
+        w = rs.randint(0, 2 ** 32, n_draw, dtype=np.uint64)
+        u = (w.astype(np.float64) + 0.5) / 2.0 ** 32
+        k, p = orc.null_draws(lat["mu_" + key], lat["r_" + key], ex, u, table=table)
+        ks = np.arange(4096, dtype=np.float64)
+        cdf = orc.nb_values("cdf", lat["mu_" + key], lat["r_" + key], np.full(ks.size, float(ex)), ks)
+        # every draw returns the cdf of an outcome; the outcome itself is k, or found by the search (k = -1)
+        kk = np.where(k >= 0, k, np.searchsorted(cdf, p, side="left"))
+        assert np.array_equal(cdf[kk], p)
+        lg = orc.null_alias_row(lat["mu_" + key], lat["r_" + key], ex, table_k=table[1])[0]
+        assert np.all(k[k >= 0] < (1 << lg) - 1) and np.all(kk[k < 0] >= (1 << lg) - 1)
+        if table[1] == 16:
+            assert (k < 0).mean() > 0.1  # the capped row: a good share of the draws is beyond the table
+        pm = np.diff(np.concatenate([[0.0], cdf]))
+        cnt = np.bincount(kk, minlength=pm.size)[:pm.size].astype(np.float64)
+        big = pm * n_draw >= 20
+        chi2 = ((cnt[big] - pm[big] * n_draw) ** 2 / (pm[big] * n_draw)).sum() + \
+            (cnt[~big].sum() - pm[~big].sum() * n_draw) ** 2 / max(pm[~big].sum() * n_draw, 1.0)
+        dof = int(big.sum())
+        assert chi2 < dof + 5.0 * np.sqrt(2.0 * dof), (key, ex, table, chi2, dof)
+    # non-integer expected value: the smallest k with cdf(k) >= u
+    u = rs.random_sample(2000)
+    k, p = orc.null_draws(lat["mu_A"], lat["r_A"], 2.5, u)
+    ks = np.arange(512, dtype=np.float64)
+    cdf = orc.nb_values("cdf", lat["mu_A"], lat["r_A"], np.full(ks.size, 2.5), ks)
+    assert np.all(k == -1) and np.array_equal(p, cdf[np.searchsorted(cdf, u, side="left")])
+
