@@ -89,6 +89,8 @@ struct fpt_ctx {
     bool posterior_direct = false;  // FPT_POSTERIOR_TABLES=0: every log-pmf evaluated in the kernel (tests compare the two)
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool fdr_split = true;  // fpt_fdr_dev: the per-interval set-up as a launch of its own (FPT_FDR_SPLIT=0: one launch)
+    bool fdr_light = true;  // ... and the draws by the light instance first, the full one for what it leaves (FPT_FDR_LIGHT=0: full only)
+    bool fdr_light_dbuf = false;  // the light instance with two sets of z buffers (FPT_FDR_LIGHT_DBUF=1)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     // size classes of a batch's tiles; FPT_SCAN_WAVE = 4 / 5 / 6 (read at creation): whole intervals of up to
     // 139 / 203 / 267 bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip).  Off by
@@ -215,6 +217,8 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     if (const char *e = getenv("FPT_POSTERIOR_TABLES")) c->posterior_direct = atoi(e) == 0;
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
     if (const char *e = getenv("FPT_FDR_SPLIT")) c->fdr_split = atoi(e) != 0;
+    if (const char *e = getenv("FPT_FDR_LIGHT")) c->fdr_light = atoi(e) != 0;
+    if (const char *e = getenv("FPT_FDR_LIGHT_DBUF")) c->fdr_light_dbuf = atoi(e) != 0;
     if (const char *e = getenv("FPT_SCAN_WAVE")) c->classes = fptk::make_lean_classes(atoi(e));
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
@@ -939,6 +943,8 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.memo = d_memo;
     fl.alias = d_alias;
     fl.n_models = n_dm;
+    fl.light = c->fdr_light;
+    fl.light_dbuf = c->fdr_light_dbuf;
     fl.memo_exp = c->memo_exp;
     fl.memo_obs = c->fdr_memo_obs;
     fl.exp = d->exp;
@@ -958,7 +964,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         if (total > 0) {
             void *ws;
             const size_t key_b = ((size_t)total * 8 + 255) & ~(size_t)255, idx_b = ((size_t)total * 2 + 255) & ~(size_t)255;
-            if (int rc = ws_get(c, 14, key_b + idx_b + (size_t)d->n_intervals * 8, &ws)) return rc;
+            if (int rc = ws_get(c, 14, key_b + idx_b + (size_t)d->n_intervals * 12, &ws)) return rc;
             fl.ws_key = (double *)ws;
             fl.ws_idx = (uint16_t *)((char *)ws + key_b);
             fl.ws_misc = (int32_t *)((char *)ws + key_b + idx_b);

@@ -1293,7 +1293,8 @@ struct fdr_args {
     // thresholds and their positions (at the interval's offset in the tracks), and m / rank_one per interval
     double *ws_key;
     uint16_t *ws_idx;
-    int32_t *ws_misc;
+    int32_t *ws_misc;        // three per interval: m, rank_one, and "left to the full draw launch" (see MODE 3)
+    int32_t redo_only;       // MODE 2: only the intervals the light draw launch left
 };
 
 // Alias tables of the null sampler (Walker / Vose): for every (model, integer exp) row of the memo the
@@ -1314,7 +1315,7 @@ struct fdr_args {
 // Every row's entries start at row << lg_max (its z at the same index of `zt`); row_lg[row] = lg.
 // A row with a NaN in it gets the identity table (outcome = slot: its z is the NaN).
 constexpr int kAliasLgMax = 11;
-constexpr double kAliasRest = 1.0 / 4294967296.0;
+constexpr double kAliasRest = 1.0 / 4294967296.0, kAliasHeavyRest = 1.0 / 16777216.0;
 __host__ __device__ inline int alias_lg_of(int memo_obs) {  // the cap: 2^lg <= memo_obs, 1 <= lg <= 11
     int lg = 1;
     while (lg < kAliasLgMax && (2 << lg) <= memo_obs) ++lg;
@@ -1398,7 +1399,8 @@ __global__ void __launch_bounds__(64) k_nb_alias(const double2 *__restrict__ mem
         }
         alias[(r << lg_max) + k] = (th << lg) | ak;
     }
-    if (lane == 0) row_lg[r] = (uint8_t)lg;
+    // (0x80: a capped row whose rest is not negligible -- its intervals go to the full draw launch straight away)
+    if (lane == 0) row_lg[r] = (uint8_t)(lg | ((lg == lg_max && !(1.0 - row[n - 2 < memo_obs ? n - 2 : 0].x <= kAliasHeavyRest)) ? 0x80 : 0));
 }
 
 // Draw beyond the table (or at a non-integer expected value): gallop, then bisect on the direct
@@ -1438,7 +1440,7 @@ __device__ __forceinline__ int table_row_of(double ex, int memo_exp) {
 // the same with the width of the row's alias table above the row: row | lg << 16, or -1
 __device__ __forceinline__ int alias_row_of(double ex, int memo_exp, const uint8_t *row_lg) {
     const int ei = table_row_of(ex, memo_exp);
-    return ei >= 0 ? (ei | ((int)row_lg[ei] << 16)) : -1;
+    return ei >= 0 ? (ei | ((int)(row_lg[ei] & 0x1f) << 16)) : -1;
 }
 
 // (the tables are addressed base + 32-bit byte offset: one vector register and no 64-bit address
@@ -1459,8 +1461,10 @@ __device__ __forceinline__ T table_at(const void *base, uint32_t byte_off) {
 typedef unsigned long long lane_mask;
 #define FPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)
 #define FPT_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
-template <int N>
-__device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint32_t *alias, const double *zt, int memo_obs,
+// LIGHT: the direct evaluation is left out (it is what the draw loop's 121 registers are for): the return
+// value says that a draw needed it, and the caller hands the interval to the full instance.
+template <int N, bool LIGHT>
+__device__ __forceinline__ bool nb_draw_zn(const double2 *memo, const uint32_t *alias, const double *zt, int memo_obs,
                                            int lg_max, const double *par, int rl, const double *exp_ptr,
                                            const uint32_t (&w)[N], const double (&u)[N], double (&z)[N]) {
     lane_mask D[N];  // still to be evaluated directly
@@ -1485,6 +1489,7 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint32_t *
         D[j] = (FPT_BALLOT(k[j] == last) & tabled) | untabled;
         any_direct |= D[j];
     }
+    if (LIGHT) return any_direct != 0;
     if (any_direct) {  // rare: beyond the table or a non-integer expected value
         const double ex = rl >= 0 ? (double)eiu : *exp_ptr;
         // the rest of the row: (cdf(n-2), 1]
@@ -1527,6 +1532,7 @@ __device__ __forceinline__ void nb_draw_zn(const double2 *memo, const uint32_t *
             if (!any_direct) break;
         }
     }
+    return false;
 }
 #undef FPT_BALLOT
 #undef FPT_LANE
@@ -1700,9 +1706,14 @@ __device__ unsigned long long g_fdr_phase[16];
 // per observed value, a third of a 50-draw call) with its results left in a workspace; 2 the DRAWS
 // (steps 2 - 3) reading them back.  As a launch of its own the set-up has a third of the LDS and no
 // part in the draw loop's 121 registers: twice as many workgroups cover each other's latencies.
+// MODE 3: the draws WITHOUT the direct inverse cdf -- 58 registers instead of 127, eight wavefronts per SIMD
+// instead of four.  An interval with a base off the tables (or on a capped row with a heavy rest) is
+// marked by the set-up launch and skipped; one whose draw falls into a row's rest (2^-32 of the draws)
+// marks itself and stores nothing.  The full instance (MODE 2 with redo_only) then does the marked ones.
 template <int NT, bool GWS, int HSC, bool ONE, int MODE = 0>
-__global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(const fdr_args a) {
+__global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || NT > 256) ? 2 : 4)) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
+    constexpr bool DRAWS = MODE == 2 || MODE == 3, LIGHT = MODE == 3;
     const int n2 = a.n2_max;
     double *par = GWS ? reinterpret_cast<double *>(a.gws + (size_t)blockIdx.x * a.gws_stride) : smem;  // 24
     double *skey = par + 24;                         // n2 sorted observed values (NaN -> +inf)
@@ -1744,6 +1755,10 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
         return;
     }
 
+    if (DRAWS) {
+        const bool marked = a.ws_misc[3 * iv + 2] != 0;
+        if (LIGHT ? marked : (a.redo_only && !marked)) return;
+    }
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint32_t *alias = a.alias + ((size_t)dm * a.memo_exp << a.alias_lg);
@@ -1760,7 +1775,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // flat to double precision near 1).  Taken from the p-value track of the scan, whose cdf is a
     // different (faster) evaluation, such ties fall either way by rounding -- and with sparse counts
     // ties are a large share of the null: an all-zero window is its own most likely null draw.
-    if (MODE != 2 && a.obs) {
+    if (!DRAWS && a.obs) {
         for (int t = tid; t < L; t += NT) {
             const double ex = a.exp[off + t];
             const int ei = table_row_of(ex, a.memo_exp);
@@ -1784,7 +1799,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // constant 1.0 among the thresholds)
     int n_num = 0, n_below_one = 0;
     double v_one = fptm::kInf;  // ONE: this lane's key
-    for (int i = tid; MODE != 2 && i < (ONE ? L : np2); i += NT) {
+    for (int i = tid; !DRAWS && i < (ONE ? L : np2); i += NT) {
         double v = fptm::kInf;
         int id = -1;
         if (i < L) {
@@ -1823,19 +1838,19 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
             sidx[i] = id;
         }
     }
-    if (MODE == 2) {  // what the set-up launch left: sorted thresholds, their positions, m and rank_one
+    if (DRAWS) {  // what the set-up launch left: sorted thresholds, their positions, m and rank_one
         for (int i = tid; i < (ONE ? L : np2); i += NT) {
             skey[i] = i < L ? a.ws_key[off + i] : fptm::kInf;
             sidx[i] = i < L ? (int)a.ws_idx[off + i] : -1;
         }
     }
     for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
-    if (tid < 4) misc[tid] = (MODE == 2 && tid >= 1 && tid <= 2) ? a.ws_misc[2 * iv + tid - 1] : 0;
+    if (tid < 4) misc[tid] = (DRAWS && tid >= 1 && tid <= 2) ? a.ws_misc[3 * iv + tid - 1] : 0;
     __syncthreads();
     FDR_MARK(1)  // keys
     if (n_num) atomicAdd(&misc[1], n_num);
     if (n_below_one) atomicAdd(&misc[2], n_below_one);
-    if (ONE && MODE != 2) {
+    if (ONE && !DRAWS) {
         // One key per lane: its place in the order is the number of keys that come before it -- a
         // walk over the interval's keys (LDS broadcast reads), a compare and an add each: 4 L
         // instructions per wavefront where the bitonic network below issues ~2,000 for 256 slots and
@@ -1862,7 +1877,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     }
     // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
     // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
-    for (int k = 2; k <= ((ONE || MODE == 2 || ABL(16384)) ? 0 : np2); k <<= 1) {
+    for (int k = 2; k <= ((ONE || DRAWS || ABL(16384)) ? 0 : np2); k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NT) {
                 const int ixj = i ^ j;
@@ -1887,7 +1902,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     // ---- 1b. the sorted observed values become thresholds in y (see ndtr_threshold)
     // (after the sort: neighbouring lanes then search neighbouring values, whose searches are about
     // equally long -- in the order of the positions a wavefront waits for its one value in the tail)
-    if (MODE == 2) {
+    if (DRAWS) {
     } else if (!a.obs) {
         for (int i = tid; i < m; i += NT)
             skey[i] = sum_threshold(ABL(8192) ? fptm::ndtri(skey[i]) : ndtr_threshold(skey[i]), a.sqrt_k, a.inv_sqrt_k);
@@ -1917,9 +1932,17 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
             a.ws_key[off + i] = skey[i];
             a.ws_idx[off + i] = (uint16_t)sidx[i];
         }
+        // a base off the tables (or on a capped row with a heavy rest) needs the direct inverse cdf
+        int off_table = 0;
+        for (int t = tid; t < L; t += NT) {
+            const int ei = table_row_of(a.exp[off + t], a.memo_exp);
+            off_table |= (ei < 0 || (row_lg[ei] & 0x80)) ? 1 : 0;
+        }
+        off_table = __syncthreads_or(off_table);
         if (tid == 0) {
-            a.ws_misc[2 * iv] = m;
-            a.ws_misc[2 * iv + 1] = rank_one;
+            a.ws_misc[3 * iv] = m;
+            a.ws_misc[3 * iv + 1] = rank_one;
+            a.ws_misc[3 * iv + 2] = off_table;
         }
         return;
     }
@@ -1968,6 +1991,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
     const int spp = direct ? 4 : 2;  // samples per pass
     double *const zset0 = zb, *const zset1 = zalt;  // 4 (direct) or 2 buffers of n2 each
     int pass = 0;
+    bool left_out = false;  // LIGHT: a draw needed the direct evaluation (wave-uniform)
     for (int s = 0; s < a.times; s += spp, ++pass) {
         const int ns = a.times - s < spp ? a.times - s : spp;  // samples of this pass
         double *const zq = (alternate && (pass & 1)) ? zset1 : zset0;
@@ -2012,7 +2036,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
 #pragma unroll
                         for (int j = 0; j < 4; ++j) z4[j] = u4[j] - 0.5;
                     } else {
-                        nb_draw_zn<4>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w4, u4, z4);
+                        left_out |= nb_draw_zn<4, LIGHT>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w4, u4, z4);
                     }
                     *reinterpret_cast<double2 *>(zq + 4 * t) = make_double2(z4[0], z4[1]);
                     *reinterpret_cast<double2 *>(zq + 4 * t + 2) = make_double2(z4[2], z4[3]);
@@ -2031,7 +2055,7 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
                 }
                 if (t < L) {
                     if (ABL(1024)) z2[0] = u2[0] - 0.5, z2[1] = u2[1] - 0.5;
-                    else nb_draw_zn<2>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w2, u2, z2);
+                    else left_out |= nb_draw_zn<2, LIGHT>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w2, u2, z2);
                 }
                 const bool f0 = isfinite(z2[0]), f1 = isfinite(z2[1]);
                 const int zc = (t < L) ? ((f0 ? 0 : 1) | (f1 ? 0 : 1 << 16)) : 0;
@@ -2135,7 +2159,14 @@ __global__ void __launch_bounds__(NT, (GWS || NT > 256) ? 2 : 4) k_fdr_null(cons
         FDR_MARK(9)  // a pass: windows + ranks
         if (!alternate) __syncthreads();
     }
-    __syncthreads();
+    if (LIGHT) {  // one of this interval's draws fell into a row's rest: nothing is stored, the full launch does it
+        if (__syncthreads_or(left_out ? 1 : 0)) {
+            if (tid == 0) a.ws_misc[3 * iv + 2] = 1;
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
 
     FDR_MARK(5)  // the passes
     // ---- 3. counts: inclusive prefix of the histogram (one wavefront, carried over chunks)
@@ -2807,9 +2838,14 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.ws_key = fl.ws_key;
     a.ws_idx = fl.ws_idx;
     a.ws_misc = fl.ws_misc;
-    for (int mode = split ? 1 : 0; mode <= (split ? 2 : 0); ++mode) {
+    // split: set-up (1), light draws (3), full draws of what the light ones left (2); without `light`: 1, 2
+    const bool light = fl.light;
+    const int modes_split[3] = {1, light ? 3 : 2, 2}, n_modes = split ? (light ? 3 : 2) : 1;
+    for (int mi = 0; mi < n_modes; ++mi) {
+        const int mode = split ? modes_split[mi] : 0;
         fdr_kernel_t kern = fl.hw == 3 ? (mode == 1 ? (one ? fdr_kernel<3, true, 1>(nt) : fdr_kernel<3, false, 1>(nt))
                                           : mode == 2 ? (one ? fdr_kernel<3, true, 2>(nt) : fdr_kernel<3, false, 2>(nt))
+                                          : mode == 3 ? (one ? fdr_kernel<3, true, 3>(nt) : fdr_kernel<3, false, 3>(nt))
                                                       : (one ? fdr_kernel<3, true>(nt) : fdr_kernel<3, false>(nt)))
                                        : (one ? fdr_kernel<0, true>(nt) : fdr_kernel<0, false>(nt));
         fdr_args am = a;
@@ -2817,6 +2853,13 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
         if (mode == 1) {
             am.dbuf = 0;
             lds_m = fdr_setup_lds_bytes(fl.n2_max);
+        }
+        am.redo_only = (mode == 2 && light) ? 1 : 0;
+        if (mode == 3) {
+            // (eight wavefronts per SIMD cover a second barrier per pass; the second set of z buffers would
+            // cost a third of them: 8.3 against 8.5 ms per 100-draw call)
+            am.dbuf = am.dbuf && fl.light_dbuf;
+            lds_m = fdr_lds_bytes(fl.n2_max, am.dbuf != 0);
         }
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
         if (e != hipSuccess) return e;

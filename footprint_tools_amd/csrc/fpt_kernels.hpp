@@ -89,6 +89,7 @@ struct fdr_launch {
     const void *memo;
     const void *alias;  // nb_alias_bytes(), filled by launch_nb_alias after launch_nb_memo
     int32_t n_models;   // models in `memo` / `alias` (1 without dm_ids)
+    bool light, light_dbuf;  // split launches: the light draw instance first (see k_fdr_null MODE 3)
     int32_t memo_exp, memo_obs;
     const double *exp, *winp;
     const double *obs;  // optional (see fpt_fdr_desc.obs)

@@ -2223,6 +2223,62 @@ def test_fdr_setup_launch_equals_single_launch(fpt, orc):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
 
 
+def test_fdr_light_draw_launch_equals_full(fpt, orc):
+    """the draws run by the light instance first (no direct inverse cdf: half the registers, twice the
+    wavefronts per SIMD) and by the full one for the intervals it leaves: intervals with a base off the
+    tables (non-integer, beyond the table's height) are marked by the set-up launch, an interval whose draw
+    falls into the rest of a row marks itself.  The same bits as a context made under FPT_FDR_LIGHT=0, and
+    the oracle's draws where a given word hits the rest of a row (model A at 17: slot 127, threshold 1)."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    os.environ["FPT_FDR_LIGHT"] = "0"
+    try:
+        ctx1 = fpt.Context(0)
+    finally:
+        del os.environ["FPT_FDR_LIGHT"]
+    rs = np.random.RandomState(78)
+    lens = np.concatenate([[1, 2, 7, 64, 65, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 1000, 1025, 2049],
+                           rs.randint(50, 400, 80)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp = np.round(rs.gamma(2.0, 3.0, off[-1]))
+    for i in rs.randint(0, lens.size, 12):   # a third kind of interval each: beyond the table, non-integer, a heavy capped row
+        exp[rs.randint(off[i], off[i + 1])] = (300.0, 2.5, 255.0)[i % 3]
+    obs = np.floor(exp * rs.uniform(0, 1.7, off[-1]))
+    winp = rs.uniform(0, 1, off[-1]) ** 2.0
+    winp[rs.randint(0, winp.size, winp.size // 30)] = np.nan
+    outs = []
+    for ctx in (None, ctx1):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+        ef_counts = sc.fdr(exp, winp, times=13, seed=5, half_win_width=3, interval_off=off, base_index0=12345, obs=obs)
+        L = 250
+        ef_uni = sc.fdr(exp[:40 * L], winp[:40 * L], times=7, seed=9, half_win_width=3, interval_len=L)
+        outs.append((ef_counts, ef_uni))
+    for k in (0, 1):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    # a word in the rest of a row that is not marked beforehand
+    lg, ent, cdf = orc.null_alias_row(lat["mu_A"], lat["r_A"], 17)
+    assert lg == 7 and (ent[127] >> 7) == 1 and 1.0 - cdf[126] < 2.0 ** -24
+    n_iv, L, times = 6, 150, 5
+    e2 = np.round(rs.gamma(2.0, 3.0, n_iv * L))
+    u = rs.uniform(0, 1, (n_iv * L, times))
+    for i in (1, 4):                      # intervals 1 and 4 get such a word; the others stay with the light launch
+        e2[i * L + 70] = 17.0
+        u[i * L + 70, 2] = (127 * 2.0 ** 25 + 0.5) / 2.0 ** 32
+    w2 = rs.uniform(0, 1, n_iv * L)
+    for ctx in (None, ctx1):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+        ef, nul = sc.fdr(e2, w2, times=times, half_win_width=3, interval_len=L, null_uniform=u, return_null=True)
+        for i in range(n_iv):
+            sl = slice(i * L, (i + 1) * L)
+            want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], e2[sl], w2[sl], 3, times, seed=0, uniforms=u[sl], return_null=True)
+            assert rel_err(nul[sl], wn) < 1e-9, i
+            assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (L * times), i
+    k, p = orc.null_draws(lat["mu_A"], lat["r_A"], 17, u[1 * L + 70, 2:3])
+    assert k[0] == -1 and p[0] >= cdf[126]   # that draw did come from the search beyond the table
+    ctx1.close()
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
 def test_host_api_fuzz(fpt, orc, seed):
     """the host-buffer entry points one reference call each (predict, the five window reducers,
