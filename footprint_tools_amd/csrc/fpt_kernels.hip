@@ -2038,8 +2038,10 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
                     } else {
                         left_out |= nb_draw_zn<4, LIGHT>(memo, alias, zt, a.memo_obs, a.alias_lg, par, ei, a.exp + off + t, w4, u4, z4);
                     }
-                    *reinterpret_cast<double2 *>(zq + 4 * t) = make_double2(z4[0], z4[1]);
-                    *reinterpret_cast<double2 *>(zq + 4 * t + 2) = make_double2(z4[2], z4[3]);
+                    // (two arrays of pairs, not one of quadruples: consecutive lanes then touch consecutive 16
+                    // bytes, and a 16-byte access at a 32-byte stride is a two-way bank conflict)
+                    reinterpret_cast<double2 *>(zq)[t] = make_double2(z4[0], z4[1]);
+                    reinterpret_cast<double2 *>(zq + 2 * n2)[t] = make_double2(z4[2], z4[3]);
                 }
             } else {  // wide windows: two draws per pass, through the scans
                 uint32_t w2[2] = {o[0], o[1]};
@@ -2076,23 +2078,24 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
             if (direct) {
                 if (t >= hs && t < L - hs) {
                     double sm[4] = {0.0, 0.0, 0.0, 0.0};
-                    const double2 *zw = reinterpret_cast<const double2 *>(zq + 4 * (t - hs));
+                    const double2 *zw01 = reinterpret_cast<const double2 *>(zq) + (t - hs);
+                    const double2 *zw23 = reinterpret_cast<const double2 *>(zq + 2 * n2) + (t - hs);
                     if (ABL(2048)) {  // no window: the position's own four z
-                        const double2 p01 = zw[2 * hs], p23 = zw[2 * hs + 1];
+                        const double2 p01 = zw01[hs], p23 = zw23[hs];
                         sm[0] = p01.x, sm[1] = p01.y, sm[2] = p23.x, sm[3] = p23.y;
                     } else if constexpr (HSC > 0) {
                         // (the sum starts at the first z, not at 0.0 + z: the same value, but for the
                         // sign of a zero sum, which no comparison below sees)
-                        const double2 f01 = zw[0], f23 = zw[1];
+                        const double2 f01 = zw01[0], f23 = zw23[0];
                         sm[0] = f01.x, sm[1] = f01.y, sm[2] = f23.x, sm[3] = f23.y;
 #pragma unroll
                         for (int j = 1; j <= 2 * HSC; ++j) {
-                            const double2 p01 = zw[2 * j], p23 = zw[2 * j + 1];
+                            const double2 p01 = zw01[j], p23 = zw23[j];
                             sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
                         }
                     } else {
                         for (int j = 0; j <= 2 * hs; ++j) {
-                            const double2 p01 = zw[2 * j], p23 = zw[2 * j + 1];
+                            const double2 p01 = zw01[j], p23 = zw23[j];
                             sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
                         }
                     }
