@@ -29,6 +29,16 @@ __global__ void __launch_bounds__(256) k(int iters, unsigned *out) {
         if (MODE == 6) asm volatile(R16("v_add_u32 %0, %0, %0\n s_nop 0\n v_add_u32 %1, %1, %1\n s_nop 0\n") : "+v"(v0), "+v"(v1));
         if (MODE == 7) asm volatile(R16("v_add_u32 %0, %0, %0\n v_readlane_b32 %2, %0, 3\n s_add_u32 %2, %2, %2\n v_add_u32 %1, %1, %2\n") : "+v"(v0), "+v"(v1), "+s"(s0) : : "scc");
         if (MODE == 8) asm volatile(R16("v_cmp_lt_u32 vcc, %0, %1\n s_and_b64 %2, vcc, exec\n v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %1, %1, %0\n") : "+v"(v0), "+v"(v1), "+s"(sm) : : "vcc", "scc");
+        if (MODE == 10) {  // 32 x 32 -> 64 multiply-add (what a Philox round is made of)
+            unsigned long long m0 = v0, m1 = v1, m2 = v2, m3 = v3;
+            asm volatile(R16("v_mad_u64_u32 %0, vcc, %4, %5, 0\n v_mad_u64_u32 %1, vcc, %5, %6, 0\n v_mad_u64_u32 %2, vcc, %6, %7, 0\n v_mad_u64_u32 %3, vcc, %7, %4, 0\n") : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "vcc");
+            v0 += (unsigned)(m0 + m1 + m2 + m3);
+        }
+        if (MODE == 11) asm volatile(R16("v_mul_lo_u32 %0, %0, %1\n v_mul_hi_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_hi_u32 %3, %3, %0\n") : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        if (MODE == 12) asm volatile(R16("v_mul_u32_u24 %0, %0, %1\n v_mul_hi_u32_u24 %1, %1, %2\n v_mul_u32_u24 %2, %2, %3\n v_mul_hi_u32_u24 %3, %3, %0\n") : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        if (MODE == 13) asm volatile(R16("v_cvt_f64_u32 %0, %2\n v_cvt_u32_f64 %2, %0\n v_cvt_f64_u32 %1, %3\n v_cvt_u32_f64 %3, %1\n") : "+v"(d0), "+v"(d1), "+v"(v0), "+v"(v1));
+        if (MODE == 14) asm volatile(R16("v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %2\n v_add_f64 %2, %2, %3\n v_add_f64 %3, %3, %0\n") : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        if (MODE == 15) asm volatile(R16("v_cmp_le_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_le_f64 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc\n") : "+v"(d0), "+v"(d1), "+v"(v0), "+v"(v1) : : "vcc");
         if (MODE == 9) asm volatile(R16("v_fma_f64 %0, %0, %0, %0\n s_add_u32 %2, %2, %2\n v_fma_f64 %1, %1, %1, %1\n s_add_u32 %3, %3, %3\n") : "+v"(d0), "+v"(d1), "+s"(s0), "+s"(s1) : : "scc");
     }
     if (v0 + v1 + v2 + v3 + s0 + s1 + s2 + s3 + (unsigned)sm == 0x12345 && d0 + d1 + d2 + d3 == 7.0) out[0] = 1;
@@ -64,5 +74,11 @@ int main() {
     run<7>("v_add, v_readlane, s_add, v_add(sgpr) dependent", out, n_cu, ghz);
     run<8>("v_cmp, s_and, v_cndmask, v_add dependent", out, n_cu, ghz);
     run<9>("v_fma_f64 / s_add alternating in each wave", out, n_cu, ghz);
+    run<10>("v_mad_u64_u32 x4", out, n_cu, ghz);
+    run<11>("v_mul_lo_u32 / v_mul_hi_u32", out, n_cu, ghz);
+    run<12>("v_mul_u32_u24 / v_mul_hi_u32_u24", out, n_cu, ghz);
+    run<13>("v_cvt_f64_u32 / v_cvt_u32_f64", out, n_cu, ghz);
+    run<14>("v_add_f64 x4 chains", out, n_cu, ghz);
+    run<15>("v_cmp_le_f64 + v_cndmask", out, n_cu, ghz);
     return 0;
 }
