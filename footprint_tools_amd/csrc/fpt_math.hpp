@@ -142,6 +142,7 @@ FPT_HD double gamma_fn(double x) {
 
 // gamma.c:152-235, for x >= -34 plus the reflection branch (one level deep).
 FPT_HD double lgam_pos(double x) {
+#pragma clang fp contract(off)  // (x - 0.5) log x - x and log z + p are two roundings each in gamma.c
     const double kA[5] = {8.11614167470508450300E-4, -5.95061904284301438324E-4,
                           7.93650340457716943945E-4, -2.77777777730099687205E-3,
                           8.33333333333331927722E-2};
@@ -151,8 +152,12 @@ FPT_HD double lgam_pos(double x) {
     const double kC[6] = {-3.51815701436523470549E2, -1.70642106651881159223E4,
                           -2.20528590553854454839E5, -1.13933444367982507207E6,
                           -2.53252307177582951285E6, -2.01889141433532773231E6};
-    if (x < 13.0) {
-        double z = 1.0, p = 0.0, u = x;
+    // One logarithm for both ranges (of the reduction's product below 13, of x itself above): the values
+    // are gamma.c's, operation for operation, but a wavefront whose lanes fall on both sides of 13 -- the
+    // posterior's lgam(k + r) and lgam(r) mostly do -- runs the ~35 instructions of log once, not twice.
+    const bool small = x < 13.0;
+    double z = 1.0, p = 0.0, u = x;
+    if (small) {
         while (u >= 3.0) {
             p -= 1.0;
             u = x + p;
@@ -165,16 +170,20 @@ FPT_HD double lgam_pos(double x) {
             u = x + p;
         }
         z = fabs(z);
-        if (u == 2.0) return log(z);
+    } else if (x > 2.556348e305) {
+        return kInf;
+    }
+    const double lg = log(small ? z : x);
+    if (small) {
+        if (u == 2.0) return lg;
         p -= 2.0;
         x = x + p;
         p = x * horner<5>(x, kB) / horner1<6>(x, kC);
-        return log(z) + p;
+        return lg + p;
     }
-    if (x > 2.556348e305) return kInf;
-    double q = (x - 0.5) * log(x) - x + 0.91893853320467274178;
+    double q = (x - 0.5) * lg - x + 0.91893853320467274178;
     if (x > 1.0e8) return q;
-    double p = 1.0 / (x * x);
+    p = 1.0 / (x * x);
     if (x >= 1000.0)
         q += ((7.9365079365079365079365e-4 * p - 2.7777777777777777777778e-3) * p +
               0.0833333333333333333333) /
