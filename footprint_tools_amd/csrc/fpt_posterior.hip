@@ -87,12 +87,14 @@ __global__ void __launch_bounds__(256) k_posterior_tables(const double *__restri
 __device__ __forceinline__ double np_max2(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
 
 // numpy's logaddexp (npy_logaddexp): the branch on the sign of x - y keeps exp's argument <= 0
+// (one exp and one log1p for both signs: lanes of a wavefront fall on both sides, and as two branches each side
+// ran its own ~80 instructions; the values are the branches')
 __device__ __forceinline__ double np_logaddexp(double x, double y) {
-    if (x == y) return x + 0.6931471805599453094;  // also +-inf == +-inf
     const double t = x - y;
-    if (t > 0) return x + log1p(exp(-t));
-    if (t <= 0) return y + log1p(exp(t));
-    return t;  // NaN
+    const bool pos = t > 0;
+    const double r = (pos ? x : y) + log1p(exp(pos ? -t : t));
+    if (x == y) return x + 0.6931471805599453094;  // also +-inf == +-inf
+    return t == t ? r : t;  // NaN
 }
 
 // datasets whose results are staged in LDS before they are stored (one 64-byte piece of a base's row)
