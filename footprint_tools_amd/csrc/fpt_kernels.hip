@@ -1733,6 +1733,8 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
     const int lane = tid & (kWave - 1);
     const int hs = HSC ? HSC : a.hw;
     const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
+    // (the full draw launch behind a light one finds nearly every interval done: out before anything else is read)
+    if (MODE == 2 && a.redo_only && a.ws_misc[3 * iv + 2] == 0) return;
     int64_t off;
     int L;
     if (a.interval_off) {
@@ -1755,10 +1757,7 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
         return;
     }
 
-    if (DRAWS) {
-        const bool marked = a.ws_misc[3 * iv + 2] != 0;
-        if (LIGHT ? marked : (a.redo_only && !marked)) return;
-    }
+    if (LIGHT && a.ws_misc[3 * iv + 2] != 0) return;  // left to the full launch by the set-up
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint32_t *alias = a.alias + ((size_t)dm * a.memo_exp << a.alias_lg);
