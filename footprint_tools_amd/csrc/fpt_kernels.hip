@@ -1309,7 +1309,7 @@ struct fdr_args {
 // The construction is Vose's with two QUEUES filled in index order (small: n p < 1, large: the
 // rest), so that it is one fixed sequence of double operations -- include/fpt.h states it, and anything that
 // repeats it gets the same table bit for bit.  One wavefront per row: the probabilities and the queues are made by
-// all lanes, the pairing loop (n steps, each depending on the one before) by lane 0 in LDS.
+// all lanes, the pairing loop (n steps, each depending on the one before) on registers filled 64 steps at a time.
 //   entry = threshold << lg | alias;   draw: slot = word >> (32 - lg), t = word & (2^(32-lg) - 1),
 //   outcome = t < threshold ? slot : alias
 // Every row's entries start at row << lg_max (its z at the same index of `zt`); row_lg[row] = lg.
@@ -1368,24 +1368,51 @@ __global__ void __launch_bounds__(64) k_nb_alias(const double2 *__restrict__ mem
     }
     const bool any_bad = __ballot(bad) != 0ull;
     __syncthreads();
-    if (lane == 0 && !any_bad) {
-        int si = 0, li = 0, se = ns;
+    if (!any_bad) {
+        // The pairing is a chain -- every step needs the large outcome's running value of the step before --
+        // but its reads need not be: the wavefront loads the next 64 entries of the small queue and their
+        // probabilities at once (lane j the j-th), and the steps take them out of the registers with
+        // v_readlane; the current large outcome and its value stay in registers until it turns small.  All
+        // lanes run the steps on the same values (lane 0 stores); what is appended to the queue meanwhile is
+        // picked up by the next load.  The same pairs in the same order as a plain loop over the queues.
+        int si = 0, li = 0, se = ns, l = 0;
+        double ql = 0.0;
+        if (nl > 0) {
+            l = lq[0];
+            ql = q[l];
+        }
         while (si < se && li < nl) {
-            const int s = sq[si++], l = lq[li];
-            al[s] = (uint16_t)l;
-            const double ql = (q[l] + q[s]) - 1.0;
-            q[l] = ql;
-            if (ql < 1.0) {
-                sq[se++] = (uint16_t)l;
-                ++li;
+            const int chunk = se - si < kWave ? se - si : kWave;
+            const int sj = lane < chunk ? (int)sq[si + lane] : 0;
+            const double qj = q[sj];
+            const int qj_lo = __double2loint(qj), qj_hi = __double2hiint(qj);
+            for (int j = 0; j < chunk && li < nl; ++j, ++si) {
+                const int s = __builtin_amdgcn_readlane(sj, j);
+                const double qs = __hiloint2double(__builtin_amdgcn_readlane(qj_hi, j), __builtin_amdgcn_readlane(qj_lo, j));
+                if (lane == 0) al[s] = (uint16_t)l;
+                ql = (ql + qs) - 1.0;
+                if (ql < 1.0) {
+                    if (lane == 0) {
+                        q[l] = ql;
+                        sq[se] = (uint16_t)l;
+                    }
+                    ++se;
+                    ++li;
+                    if (li < nl) {
+                        l = lq[li];
+                        ql = q[l];
+                    }
+                }
             }
         }
-        // what is left on either queue is 1 up to rounding: its own slot, whole
-        while (li < nl) q[lq[li++]] = 1.0;
-        while (si < se) {
-            const int s = sq[si++];
-            q[s] = 1.0;
-            al[s] = (uint16_t)s;
+        if (lane == 0) {
+            // what is left on either queue is 1 up to rounding: its own slot, whole
+            while (li < nl) q[lq[li++]] = 1.0;
+            while (si < se) {
+                const int s = sq[si++];
+                q[s] = 1.0;
+                al[s] = (uint16_t)s;
+            }
         }
     }
     __syncthreads();
