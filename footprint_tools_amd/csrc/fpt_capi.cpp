@@ -973,7 +973,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     // long intervals: per-workgroup buffers in a global workspace of at most 1 GiB
     auto launch_long = [&](const int32_t *list, int64_t n_list) -> int {
         fl.n2_max = pow2(lmax);
-        fl.gws_stride = (int64_t)((fptk::fdr_lds_bytes(fl.n2_max) + 255) & ~(size_t)255);
+        fl.gws_stride = (int64_t)((fptk::fdr_lds_bytes(fl.n2_max, false, true) + 255) & ~(size_t)255);
         const int64_t n_blocks = list ? n_list : d->n_intervals;
         fl.gws_blocks = std::max<int64_t>(1, std::min<int64_t>(n_blocks, ((int64_t)1 << 30) / fl.gws_stride));
         if (int rc = ws_get(c, 4, (size_t)(fl.gws_stride * fl.gws_blocks), &fl.gws)) return rc;

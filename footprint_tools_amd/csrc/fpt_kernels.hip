@@ -13,6 +13,8 @@
 // Reference citations are paths under vierstralab/footprint-tools v1.3.7.
 #include "fpt_kernels.hpp"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "fpt_device.hpp"
@@ -1260,6 +1262,8 @@ FPT_SCAN_INSTANCES(FPT_INST)
 //   3. a prefix sum of the histogram gives #{null <= observed} for every base
 // The null values are never stored: 100 draws per base stay on chip.
 // ===========================================================================
+__host__ __device__ inline int fdr_guide_slices(int n2) { return 4 * n2 < 4096 ? 4 * n2 : 4096; }
+
 struct fdr_args {
     int64_t n_intervals;
     int32_t interval_len;
@@ -1752,7 +1756,10 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
     int *nf = sidx + n2;                             // n2 tile prefix counts of non-finite z (16 bits per sample)
     int *hist = nf + n2;                             // n2 + 2 histogram / prefix
     int *misc = hist + n2 + 2;                       // [0] n_nan, [1] m
-    int *rguide = misc + 8;                          // min(n2, 2048) + 1: #{sorted observed < b / nb}
+    // rank guide, fdr_guide_slices(n2) + 1 entries: #{sorted observed whose slice is < b}; 16-bit where the buffers
+    // are in LDS (an interval there has at most 2,048 bases)
+    typedef typename std::conditional<GWS, int, uint16_t>::type guide_t;
+    guide_t *rguide = reinterpret_cast<guide_t *>(misc + 8);
     // (MODE 1 is launched with the buffers it uses -- par, skey, two n2 of zb, sidx, nf, hist, misc:
     // fdr_setup_lds_bytes -- and never touches rguide, whose address then lies beyond its allocation)
 
@@ -1973,9 +1980,11 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
         return;
     }
     const double kYR = 4.5 * a.sqrt_k;
-    // (measured and dropped: four times as many slices -- no faster; the slice of x as fma / clamp /
-    // truncation with the guide built on the same function -- 1 % per pass, 5 % more set-up)
-    const int nb = np2 < 2048 ? np2 : 2048;
+    // Four slices per observed value (of the power of two above the interval's length; at most 4,096): the largest
+    // bracket of a wavefront's 256 null values -- which is how long its rank search runs -- holds three or four
+    // thresholds instead of seven or eight.  (Round 3 measured the same at four wavefronts per SIMD and with the
+    // guide as 32-bit entries, a quarter of the workgroups lost to LDS: slower then.)
+    const int nb = fdr_guide_slices(np2);
     const double yscale = (double)nb / (2.0 * kYR);
     // rguide[b] = #{thresholds below 1 whose slice is < b}, with the slice of a threshold found by the
     // very expression a null window's is below -- it is monotone in x, so the thresholds <= x lie
@@ -1990,7 +1999,7 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
     for (int i = tid; i <= rank_one; i += NT) {
         const int from = i == 0 ? 0 : slice_of(skey[i - 1]) + 1;
         const int to = i == rank_one ? nb : slice_of(skey[i]);  // (the last entry: every threshold below 1)
-        for (int b = from; b <= to; ++b) rguide[b] = i;
+        for (int b = from; b <= to; ++b) rguide[b] = (guide_t)i;
     }
     __syncthreads();
 
@@ -2801,9 +2810,10 @@ void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_ex
                        (uint8_t *)(t + nb_alias_lg_offset(n_models, memo_exp, memo_obs)));
 }
 
-size_t fdr_lds_bytes(int n2, bool dbuf) {
-    return (size_t)(24 + (dbuf ? 9 : 5) * (size_t)n2) * sizeof(double) +
-           (size_t)(3 * (size_t)n2 + 2 + 8 + (n2 < 2048 ? n2 : 2048) + 1) * sizeof(int);
+size_t fdr_lds_bytes(int n2, bool dbuf, bool global_buffers) {
+    const size_t guide = ((size_t)fdr_guide_slices(n2) + 2) * (global_buffers ? sizeof(int) : sizeof(uint16_t));
+    return (size_t)(24 + (dbuf ? 9 : 5) * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8) * sizeof(int) +
+           ((guide + 7) & ~(size_t)7);
 }
 // the set-up launch (MODE 1): par, skey, two n2 of zb (the z of the observed counts, the keys), then sidx, nf,
 // hist and misc -- a third of the draw launch's buffers

@@ -149,7 +149,7 @@ struct segment_launch {
     double *seg_score;
 };
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
-size_t fdr_lds_bytes(int n2, bool dbuf = false);
+size_t fdr_lds_bytes(int n2, bool dbuf = false, bool global_buffers = false);
 void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *tables);
 // the tile table of a ragged batch (three int32 arrays of n_tiles in `flat`, 32-byte records in `recs`)
 // from the device offsets: class-major, intervals in order.  block_base (device): for every
