@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-constexpr int kSlots = 15;
+constexpr int kSlots = 16;
 constexpr int kModelDoubles = 24;
 
 }  // namespace
@@ -90,6 +90,8 @@ struct fpt_ctx {
     bool memo2_cold = false;  // FPT_MEMO2_KEEP=0: the second-level table is emptied at every call (measurements)
     bool fdr_split = true;  // fpt_fdr_dev: the per-interval set-up as a launch of its own (FPT_FDR_SPLIT=0: one launch)
     bool fdr_light = true;  // ... and the draws by the light instance first, the full one for what it leaves (FPT_FDR_LIGHT=0: full only)
+    bool fdr_slices_always = false;  // (tests: also for calls of a few draws)
+    bool fdr_slices = true;   // ... and, in ragged batches, intervals of more than 256 bases drawn as slices (FPT_FDR_SLICES=0: one workgroup each)
     bool fdr_light_dbuf = false;  // the light instance with two sets of z buffers (FPT_FDR_LIGHT_DBUF=1)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
     // size classes of a batch's tiles; FPT_SCAN_WAVE = 4 / 5 / 6 (read at creation): whole intervals of up to
@@ -218,6 +220,7 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     if (const char *e = getenv("FPT_TABLE_LDS")) c->table_lds = atoi(e) != 0;
     if (const char *e = getenv("FPT_FDR_SPLIT")) c->fdr_split = atoi(e) != 0;
     if (const char *e = getenv("FPT_FDR_LIGHT")) c->fdr_light = atoi(e) != 0;
+    if (const char *e = getenv("FPT_FDR_SLICES")) c->fdr_slices = atoi(e) != 0, c->fdr_slices_always = atoi(e) == 2;
     if (const char *e = getenv("FPT_FDR_LIGHT_DBUF")) c->fdr_light_dbuf = atoi(e) != 0;
     if (const char *e = getenv("FPT_SCAN_WAVE")) c->classes = fptk::make_lean_classes(atoi(e));
     c->device = device_id;
@@ -874,6 +877,16 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     // back in a pinned buffer the context keeps -- counted, then placed: no growing vectors, one
     // copy to the device that needs no wait
     int64_t cls_n[kClasses + 1] = {}, cls_at[kClasses + 2] = {};
+    // slices (ragged batches, the `detect` width, split + light launches): the draws of an interval of more than
+    // 256 bases by several three-wavefront workgroups (k_fdr_slice); lists and offsets ride in the pinned buffer
+    // behind the interval lists: goff (int64 per interval), slice_iv and slice_start (int32 per slice, class-major)
+    // (per call the slices cost two more launches per size class, a list and a memset -- 0.15 ms per 100,000
+    // intervals -- and win 0.0055 ms per draw: from 32 draws per base on, or when asked for by FPT_FDR_SLICES=2)
+    const bool use_slices = d->interval_off && d->half_win_width == 3 && c->fdr_split && c->fdr_light && c->fdr_slices &&
+                            (d->times >= 32 || c->fdr_slices_always);
+    const int slice_len = fptk::fdr_slice_positions();
+    int64_t sl_n[kClasses + 1] = {}, sl_at[kClasses + 2] = {}, ghist_total = 0;
+    size_t pin_goff = 0, pin_slice_iv = 0, pin_slice_start = 0, pin_bytes = 0;
     if (d->interval_off) {
         if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
         // interval lengths: from the caller's host copy of the offsets, else back from the device
@@ -896,9 +909,15 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
             const int k = L > kLdsMax ? kClasses : cls_of((int)L);
             cls[(size_t)i] = (uint8_t)k;
             cls_n[k] += 1;
+            if (use_slices && k < kClasses && L > 256) sl_n[k] += (L + slice_len - 1) / slice_len;
         }
         for (int k = 0; k <= kClasses; ++k) cls_at[k + 1] = cls_at[k] + cls_n[k];
-        const size_t need = (size_t)d->n_intervals * sizeof(int32_t);
+        for (int k = 0; k <= kClasses; ++k) sl_at[k + 1] = sl_at[k] + sl_n[k];
+        pin_goff = ((size_t)d->n_intervals * sizeof(int32_t) + 7) & ~(size_t)7;
+        pin_slice_iv = pin_goff + (use_slices && sl_at[kClasses] ? (size_t)d->n_intervals * sizeof(int64_t) : 0);
+        pin_slice_start = pin_slice_iv + (size_t)sl_at[kClasses] * sizeof(int32_t);
+        pin_bytes = pin_slice_start + (size_t)sl_at[kClasses] * sizeof(int32_t);
+        const size_t need = pin_bytes;
         if (c->pin_list_busy) {  // the copy of the call before has long happened; make sure
             HIP_TRY(hipEventSynchronize(c->pin_list_copied));
             c->pin_list_busy = false;
@@ -915,6 +934,26 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         int64_t cur[kClasses + 1];
         for (int k = 0; k <= kClasses; ++k) cur[k] = cls_at[k];
         for (int64_t i = 0; i < d->n_intervals; ++i) c->pin_list[cur[cls[(size_t)i]]++] = (int32_t)i;
+        if (use_slices && sl_at[kClasses]) {
+            int64_t *goff = (int64_t *)((char *)c->pin_list + pin_goff);
+            int32_t *s_iv = (int32_t *)((char *)c->pin_list + pin_slice_iv), *s_start = (int32_t *)((char *)c->pin_list + pin_slice_start);
+            int64_t scur[kClasses + 1];
+            for (int k = 0; k <= kClasses; ++k) scur[k] = sl_at[k];
+            for (int64_t i = 0; i < d->n_intervals; ++i) {
+                const int64_t L = off[i + 1] - off[i];
+                const int k = cls[(size_t)i];
+                if (k >= kClasses || L <= 256) {
+                    goff[i] = -1;
+                    continue;
+                }
+                goff[i] = ghist_total;
+                ghist_total += L + 2;
+                for (int64_t st0 = 0; st0 < L; st0 += slice_len) {
+                    s_iv[scur[k]] = (int32_t)i;
+                    s_start[scur[k]++] = (int32_t)st0;
+                }
+            }
+        }
     } else if (lmax <= 0) {
         return fail(FPT_ERR_INVALID, "interval_len must be positive");
     } else if (lmax > kLongMax) {
@@ -992,8 +1031,17 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     }
     // ragged batch: the lists to the device in one copy (pinned: it is queued, nobody waits)
     void *d_list;
-    if (int rc = ws_get(c, 5, (size_t)d->n_intervals * sizeof(int32_t), &d_list)) return rc;
-    HIP_TRY(hipMemcpyAsync(d_list, c->pin_list, (size_t)d->n_intervals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (int rc = ws_get(c, 5, pin_bytes, &d_list)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_list, c->pin_list, pin_bytes, hipMemcpyHostToDevice, c->stream));
+    if (use_slices && sl_at[kClasses] && fl.ws_key) {
+        void *d_counts;  // the sliced intervals' counts (L + 2 each), then a count of NaN windows per interval: zeroed
+        const size_t count_bytes = ((size_t)ghist_total + (size_t)d->n_intervals) * sizeof(int32_t);
+        if (int rc = ws_get(c, 15, count_bytes, &d_counts)) return rc;
+        HIP_TRY(hipMemsetAsync(d_counts, 0, count_bytes, c->stream));
+        fl.goff = (const int64_t *)((const char *)d_list + pin_goff);
+        fl.ghist = (int32_t *)d_counts;
+        fl.gnan = (int32_t *)d_counts + ghist_total;
+    }
     if (!c->pin_list_copied) HIP_TRY(hipEventCreateWithFlags(&c->pin_list_copied, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->pin_list_copied, c->stream));
     c->pin_list_busy = true;
@@ -1005,9 +1053,13 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
         fl.max_len = cls_len[k];
         fl.iv_list = lists + cls_at[k];
         fl.n_list = cls_n[k];
+        fl.n_slices = fl.ghist ? sl_n[k] : 0;
+        fl.slice_iv = (const int32_t *)((const char *)d_list + pin_slice_iv) + sl_at[k];
+        fl.slice_start = (const int32_t *)((const char *)d_list + pin_slice_start) + sl_at[k];
         HIP_TRY(fptk::launch_fdr(c->stream, fl));
         if (int rc = launch_ok("k_fdr_null")) return rc;
     }
+    fl.n_slices = 0;
     if (cls_n[kClasses]) return launch_long(lists + cls_at[kClasses], cls_n[kClasses]);
     return FPT_OK;
 }

@@ -2242,6 +2242,214 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
     FDR_MARK(6)  // prefix and output
 }
 
+// ===========================================================================
+// k_fdr_slice / k_fdr_slice_finish: the light draws of an interval of more than 256 bases as SLICES.
+// An interval's null tracks are independent across positions but for the 2 hw + 1 window, and a draw
+// is a function of its position (the Philox counter): so a long interval is drawn by several workgroups of
+// the size that suits the short ones -- three wavefronts, one lane per position, kFdrSliceLanes - 2 hw output
+// positions each with hw halo positions either side drawn again -- every one holding the interval's
+// thresholds, its rank guide and a private histogram that it adds to a global one at the end;
+// k_fdr_slice_finish then turns the interval's counts into its efdr like step 3 of k_fdr_null.  As one
+// workgroup an interval of 300 bases left five workgroups on a CU (its 512-entry buffers) and ran its lanes
+// in two trips, one of 1,000 bases left two: 1.35 and 2.6 times the time per base of a short interval.
+// Only the light form exists (split launches, the `detect` width): a marked interval is skipped here like in
+// k_fdr_null<MODE 3>, one whose draw falls into a row's rest is marked by the slice that meets it, and the
+// full launch that follows (MODE 2, redo_only, one workgroup per interval) does those.
+// LDS: par 24 | skey n2 | z 4 x lanes | hist n2 + 2 (int) | misc 8 (int) | guide (16-bit).
+// ===========================================================================
+constexpr int kFdrSliceLanes = 192;
+struct fdr_slice_args {
+    fdr_args a;
+    const int32_t *slice_iv;     // per workgroup: the interval ...
+    const int32_t *slice_start;  // ... and the first of its output positions
+    const int64_t *goff;         // per interval: where its L + 2 counts start in ghist
+    int32_t *ghist;
+    int32_t *gnan;               // per interval: null windows that are not a number
+};
+
+__global__ void __launch_bounds__(kFdrSliceLanes, 8) k_fdr_slice(const fdr_slice_args sa) {
+    extern __shared__ double smem[];
+    constexpr int NT = kFdrSliceLanes, HS = 3;
+    const fdr_args &a = sa.a;
+    const int n2 = a.n2_max;
+    double *par = smem;                                   // 24
+    double *skey = par + 24;                              // n2: the interval's sorted thresholds
+    double *zq = skey + n2;                               // 2 x NT pairs: z of the pass's four samples
+    int *hist = reinterpret_cast<int *>(zq + 4 * NT);     // n2 + 2
+    int *misc = hist + n2 + 2;                            // [0] n_nan
+    uint16_t *rguide = reinterpret_cast<uint16_t *>(misc + 8);
+    const int tid = threadIdx.x;
+    const int64_t iv = sa.slice_iv[blockIdx.x];
+    if (a.ws_misc[3 * iv + 2] != 0) return;  // left to the full launch
+    const int s0 = sa.slice_start[blockIdx.x];
+    const int64_t off = a.interval_off[iv];
+    const int L = (int)(a.interval_off[iv + 1] - off);
+    int np2 = 1;
+    while (np2 < L) np2 <<= 1;
+    if (np2 > n2 || s0 >= L) return;  // (a stale host copy of the offsets: the full launch's guard reports it)
+    const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
+    const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
+    const uint32_t *alias = a.alias + ((size_t)dm * a.memo_exp << a.alias_lg);
+    const double *zt = a.zt + ((size_t)dm * a.memo_exp << a.alias_lg);
+    const uint8_t *row_lg = a.row_lg + (size_t)dm * a.memo_exp;
+    if (tid < 24) par[tid] = a.model[(size_t)dm * 24 + tid];
+    for (int i = tid; i < L; i += NT) skey[i] = a.ws_key[off + i];
+    const int m = a.ws_misc[3 * iv], rank_one = a.ws_misc[3 * iv + 1];
+    for (int i = tid; i < m + 2; i += NT) hist[i] = 0;
+    if (tid < 8) misc[tid] = 0;
+    __syncthreads();
+    // the rank guide, as in k_fdr_null
+    const double kYR = 4.5 * a.sqrt_k;
+    const int nb = fdr_guide_slices(np2);
+    const double yscale = (double)nb / (2.0 * kYR);
+    const double slice_c0 = kYR * yscale, slice_top = (double)(nb - 1);
+    auto slice_of = [&](double y) { return (int)fmin(fmax(fma(y, yscale, slice_c0), 0.0), slice_top); };
+    for (int i = tid; i <= rank_one; i += NT) {
+        const int from = i == 0 ? 0 : slice_of(skey[i - 1]) + 1;
+        const int to = i == rank_one ? nb : slice_of(skey[i]);
+        for (int b = from; b <= to; ++b) rguide[b] = (uint16_t)i;
+    }
+    __syncthreads();
+    // this lane's position (the first and last HS lanes are the halo) and whether it is an output of the slice
+    const int t = s0 - HS + tid;
+    const bool valid = t >= 0 && t < L;
+    const bool out = tid >= HS && tid < NT - HS && t < L;
+    const bool inside = out && t >= HS && t < L - HS;  // its window fits the interval
+    const int rl = valid ? alias_row_of(a.exp[off + t], a.memo_exp, row_lg) : -1;
+    const bool has_up = a.null_uniform != nullptr;
+    bool left_out = false;
+    double2 *z01 = reinterpret_cast<double2 *>(zq), *z23 = z01 + NT;
+    for (int s = 0; s < a.times; s += 4) {
+        const int ns = a.times - s < 4 ? a.times - s : 4;
+        uint32_t w4[4] = {0u, 0u, 0u, 0u};
+        double u4[4], z4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (valid) {
+            if (!has_up) {
+                const uint64_t base = (uint64_t)(a.base_index0 + off + t);
+                philox4x32_10((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)(s >> 2), 0x66707464u,
+                              (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u4[j] = fma((double)w4[j], 1.0 / 4294967296.0, 0.5 / 4294967296.0);
+            if (has_up) {  // (tests)
+                const double *up = a.null_uniform + (size_t)(off + t) * a.times + s;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u4[j] = j < ns ? up[j] : 0.5;
+                    w4[j] = fptm::uniform_word(u4[j]);
+                }
+            }
+            left_out |= nb_draw_zn<4, true>(memo, alias, zt, a.memo_obs, a.alias_lg, par, rl, a.exp + off + t, w4, u4, z4);
+        }
+        z01[tid] = make_double2(z4[0], z4[1]);
+        z23[tid] = make_double2(z4[2], z4[3]);
+        __syncthreads();
+        if (out) {
+            double x0 = fptm::kInf, x1 = fptm::kInf, x2 = fptm::kInf, x3 = fptm::kInf;
+            if (inside) {
+                const double2 *zw01 = z01 + (tid - HS), *zw23 = z23 + (tid - HS);
+                const double2 f01 = zw01[0], f23 = zw23[0];
+                double sm[4] = {f01.x, f01.y, f23.x, f23.y};
+#pragma unroll
+                for (int j = 1; j <= 2 * HS; ++j) {
+                    const double2 p01 = zw01[j], p23 = zw23[j];
+                    sm[0] += p01.x, sm[1] += p01.y, sm[2] += p23.x, sm[3] += p23.y;
+                }
+                x0 = (sm[0] - sm[0]) - sm[0];
+                x1 = (sm[1] - sm[1]) - sm[1];
+                x2 = (sm[2] - sm[2]) - sm[2];
+                x3 = (sm[3] - sm[3]) - sm[3];
+            }
+            if (a.null_out) {
+                double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
+#pragma clang loop unroll(disable)
+                for (int w = 0; w < ns; ++w) {
+                    const double xw = w == 0 ? x0 : (w == 1 ? x1 : (w == 2 ? x2 : x3));
+                    np_[w] = xw == fptm::kInf ? 1.0 : fptm::ndtr(div_invariant(xw, a.sqrt_k, a.inv_sqrt_k));
+                }
+            }
+            auto rank_pair = [&](const double y0, const double y1, const bool second) {
+                const int b0 = slice_of(y0), b1 = slice_of(y1);
+                int l0 = rguide[b0], h0 = rguide[b0 + 1], l1 = rguide[b1], h1 = rguide[b1 + 1];
+                for (int it = 0; l0 < h0 || l1 < h1; ++it) {
+                    const int m0 = it == 0 ? h0 - 1 : (it == 1 ? l0 : (l0 + h0) >> 1);
+                    const int m1 = it == 0 ? h1 - 1 : (it == 1 ? l1 : (l1 + h1) >> 1);
+                    const bool g0 = skey[m0] <= y0, g1 = skey[m1] <= y1;
+                    if (l0 < h0) {
+                        l0 = g0 ? m0 + 1 : l0;
+                        h0 = g0 ? h0 : m0;
+                    }
+                    if (l1 < h1) {
+                        l1 = g1 ? m1 + 1 : l1;
+                        h1 = g1 ? h1 : m1;
+                    }
+                }
+                atomicAdd(isnan(y0) ? &misc[0] : &hist[l0], 1);
+                if (second) atomicAdd(isnan(y1) ? &misc[0] : &hist[l1], 1);
+            };
+            rank_pair(x0, x1, ns > 1);
+            if (ns > 2) rank_pair(x2, x3, ns > 3);
+        }
+        __syncthreads();
+    }
+    if (__syncthreads_or(left_out ? 1 : 0)) {  // a draw fell into a row's rest: the whole interval goes to the full launch
+        if (tid == 0) a.ws_misc[3 * iv + 2] = 1;
+        return;
+    }
+    int32_t *gh = sa.ghist + sa.goff[iv];
+    for (int i = tid; i <= m; i += NT) {
+        const int v = hist[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+    if (tid == 0 && misc[0]) atomicAdd(&sa.gnan[iv], misc[0]);
+}
+
+// one workgroup per sliced interval: the inclusive prefix of its counts, then the efdr of every position
+// (step 3 of k_fdr_null); nothing for an interval that was marked
+__global__ void __launch_bounds__(256) k_fdr_slice_finish(const fdr_slice_args sa) {
+    extern __shared__ double smem[];
+    constexpr int NT = 256;
+    const fdr_args &a = sa.a;
+    int *hist = reinterpret_cast<int *>(smem);  // n2 + 2
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
+    if (a.ws_misc[3 * iv + 2] != 0) return;
+    const int64_t off = a.interval_off[iv];
+    const int L = (int)(a.interval_off[iv + 1] - off);
+    int np2 = 1;
+    while (np2 < L) np2 <<= 1;
+    if (L <= 0 || np2 > a.n2_max) return;
+    const int m = a.ws_misc[3 * iv];
+    const int32_t *gh = sa.ghist + sa.goff[iv];
+    for (int i = tid; i <= m; i += NT) hist[i] = gh[i];
+    __syncthreads();
+    if (tid < kWave) {
+        int carry = 0;
+        for (int base = 0; base <= m; base += kWave) {
+            const int i = base + lane;
+            int v = (i <= m) ? hist[i] : 0;
+            v = wave_scan_i32(v) + carry;
+            if (i <= m) hist[i] = v;
+            carry = __shfl(v, kWave - 1, kWave);
+        }
+    }
+    __syncthreads();
+    const int n_finite = hist[m];
+    const int n_nan = sa.gnan[iv];
+    const double denom = (double)L * (double)a.times;
+    for (int i = tid; i < L; i += NT) {
+        const int pos = (int)a.ws_idx[off + i];
+        double f = 1.0;  // NaN observed: the two-pointer walk runs to the end (utils.pyx:76)
+        if (i < m) {
+            int cnt = hist[i];
+            if (cnt == n_finite) cnt += n_nan;  // nothing finite above: the walk passes the NaNs too
+            f = (double)cnt / denom;
+            if (f > 1.0) f = 1.0;
+        }
+        a.efdr[off + pos] = f;
+    }
+}
+
 // size classes of short intervals (64, 128, 192 lanes): fewer idle lanes; 192 lanes take 129..192
 // bases in one pass and 257..384 in two
 template <int HSC, bool ONE, int MODE = 0>
@@ -2810,6 +3018,13 @@ void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_ex
                        (uint8_t *)(t + nb_alias_lg_offset(n_models, memo_exp, memo_obs)));
 }
 
+size_t fdr_slice_lds_bytes(int n2) {
+    const size_t guide = ((size_t)fdr_guide_slices(n2) + 2) * sizeof(uint16_t);
+    return (size_t)(24 + (size_t)n2 + 4 * kFdrSliceLanes) * sizeof(double) + (size_t)((size_t)n2 + 2 + 8) * sizeof(int) +
+           ((guide + 7) & ~(size_t)7);
+}
+int fdr_slice_positions() { return kFdrSliceLanes - 6; }
+
 size_t fdr_lds_bytes(int n2, bool dbuf, bool global_buffers) {
     const size_t guide = ((size_t)fdr_guide_slices(n2) + 2) * (global_buffers ? sizeof(int) : sizeof(uint16_t));
     return (size_t)(24 + (dbuf ? 9 : 5) * (size_t)n2) * sizeof(double) + (size_t)(3 * (size_t)n2 + 2 + 8) * sizeof(int) +
@@ -2885,8 +3100,35 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     // split: set-up (1), light draws (3), full draws of what the light ones left (2); without `light`: 1, 2
     const bool light = fl.light;
     const int modes_split[3] = {1, light ? 3 : 2, 2}, n_modes = split ? (light ? 3 : 2) : 1;
+    const bool sliced = split && light && fl.n_slices > 0 && fl.slice_iv && fl.ghist && fl.interval_off;
     for (int mi = 0; mi < n_modes; ++mi) {
         const int mode = split ? modes_split[mi] : 0;
+        if (mode == 3 && sliced) {  // the light draws of this class as slices, then the counts -> efdr per interval
+            fdr_slice_args sa;
+            sa.a = a;
+            sa.slice_iv = fl.slice_iv;
+            sa.slice_start = fl.slice_start;
+            sa.goff = fl.goff;
+            sa.ghist = fl.ghist;
+            sa.gnan = fl.gnan;
+            const size_t lds_s = fdr_slice_lds_bytes(fl.n2_max), lds_f = ((size_t)fl.n2_max + 2) * sizeof(int);
+            hipError_t e = hipFuncSetAttribute((const void *)k_fdr_slice, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            if (e != hipSuccess) return e;
+            for (int64_t done = 0; done < fl.n_slices; done += 0x7fffff00) {
+                fdr_slice_args b = sa;
+                b.slice_iv += done;
+                b.slice_start += done;
+                const int64_t n = fl.n_slices - done < 0x7fffff00 ? fl.n_slices - done : 0x7fffff00;
+                hipLaunchKernelGGL(k_fdr_slice, dim3((unsigned)n), dim3(kFdrSliceLanes), lds_s, st, b);
+            }
+            for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
+                fdr_slice_args b = sa;
+                if (b.a.iv_list) b.a.iv_list += done; else b.a.iv_first = done;
+                const int64_t n = n_blocks - done < 0x7fffff00 ? n_blocks - done : 0x7fffff00;
+                hipLaunchKernelGGL(k_fdr_slice_finish, dim3((unsigned)n), dim3(256), lds_f, st, b);
+            }
+            continue;
+        }
         fdr_kernel_t kern = fl.hw == 3 ? (mode == 1 ? (one ? fdr_kernel<3, true, 1>(nt) : fdr_kernel<3, false, 1>(nt))
                                           : mode == 2 ? (one ? fdr_kernel<3, true, 2>(nt) : fdr_kernel<3, false, 2>(nt))
                                           : mode == 3 ? (one ? fdr_kernel<3, true, 3>(nt) : fdr_kernel<3, false, 3>(nt))

@@ -90,6 +90,11 @@ struct fdr_launch {
     const void *alias;  // nb_alias_bytes(), filled by launch_nb_alias after launch_nb_memo
     int32_t n_models;   // models in `memo` / `alias` (1 without dm_ids)
     bool light, light_dbuf;  // split launches: the light draw instance first (see k_fdr_null MODE 3)
+    // split + light launches of intervals of more than 256 bases: their light draws as slices (k_fdr_slice)
+    const int32_t *slice_iv, *slice_start;  // DEVICE, n_slices each: interval and first output position of a slice
+    int64_t n_slices;
+    const int64_t *goff;                    // DEVICE, per interval: start of its L + 2 counts in ghist
+    int32_t *ghist, *gnan;                  // DEVICE, zeroed by the caller: counts per interval, NaN windows per interval
     int32_t memo_exp, memo_obs;
     const double *exp, *winp;
     const double *obs;  // optional (see fpt_fdr_desc.obs)
@@ -150,6 +155,8 @@ struct segment_launch {
 };
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
 size_t fdr_lds_bytes(int n2, bool dbuf = false, bool global_buffers = false);
+size_t fdr_slice_lds_bytes(int n2);
+int fdr_slice_positions();  // output positions per slice
 void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *tables);
 // the tile table of a ragged batch (three int32 arrays of n_tiles in `flat`, 32-byte records in `recs`)
 // from the device offsets: class-major, intervals in order.  block_base (device): for every

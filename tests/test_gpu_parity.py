@@ -2279,6 +2279,68 @@ def test_fdr_light_draw_launch_equals_full(fpt, orc):
     ctx1.close()
 
 
+def test_fdr_sliced_draws_equal_whole_interval(fpt, orc):
+    """in ragged batches the light draws of an interval of more than 256 bases are made by several
+    three-wavefront workgroups, each a slice of 186 output positions with the interval's thresholds and a
+    private histogram added to a global one, and a second kernel turns the counts into the efdr: the same
+    bits as one workgroup per interval (a context made under FPT_FDR_SLICES=0) -- lengths on both sides of
+    every slice boundary, marked intervals (a base off the tables), null windows handed back, given uniforms --
+    and the oracle's counts."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    os.environ["FPT_FDR_SLICES"] = "0"
+    try:
+        ctx1 = fpt.Context(0)
+        os.environ["FPT_FDR_SLICES"] = "2"   # (also for calls of fewer than 32 draws per base)
+        ctx2 = fpt.Context(0)
+    finally:
+        del os.environ["FPT_FDR_SLICES"]
+    rs = np.random.RandomState(79)
+    lens = np.concatenate([[256, 257, 186 * 2 - 1, 186 * 2, 186 * 2 + 1, 384, 385, 512, 513, 186 * 3, 186 * 3 + 1, 1000, 1024, 1025,
+                            186 * 11, 2047, 2048, 2049, 100, 3000], rs.randint(200, 900, 40)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp = np.round(rs.gamma(2.0, 3.0, off[-1]))
+    for i in (3, 9, 25):   # marked by the set-up: beyond the table, non-integer, a heavy capped row
+        exp[rs.randint(off[i], off[i + 1])] = (300.0, 2.5, 255.0)[i % 3]
+    obs = np.floor(exp * rs.uniform(0, 1.7, off[-1]))
+    winp = rs.uniform(0, 1, off[-1]) ** 2.0
+    winp[rs.randint(0, winp.size, winp.size // 30)] = np.nan
+    outs = []
+    for ctx in (ctx2, ctx1, None):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+        ef_counts = sc.fdr(exp, winp, times=13, seed=5, half_win_width=3, interval_off=off, base_index0=12345, obs=obs)
+        ef_track, nul = sc.fdr(exp, winp, times=6, seed=7, half_win_width=3, interval_off=off, base_index0=99, return_null=True)
+        ef_many = sc.fdr(exp, winp, times=37, seed=8, half_win_width=3, interval_off=off, base_index0=5, obs=obs)  # sliced by default
+        outs.append((ef_counts, ef_track, nul, ef_many))
+    for k in (0, 1, 2, 3):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+        assert np.array_equal(outs[2][k], outs[1][k], equal_nan=True), k
+    for i in (1, 4, 14, 17):   # against the oracle: the windows of every position, the counts
+        sl = slice(int(off[i]), int(off[i + 1]))
+        want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[sl], winp[sl], 3, 6, seed=7, base0=99 + int(off[i]), return_null=True)
+        assert rel_err(outs[0][2][sl], wn) < 1e-9, i
+        assert np.max(np.abs(outs[0][1][sl] - want)) <= 2.5 / (lens[i] * 6), i
+    # given uniforms, among them a word in the rest of an unmarked row in the middle of a sliced interval
+    L3 = np.array([500, 300, 700])
+    off3 = np.concatenate([[0], np.cumsum(L3)]).astype(np.int64)
+    e3 = np.round(rs.gamma(2.0, 3.0, off3[-1]))
+    u3 = rs.uniform(0, 1, (int(off3[-1]), 5))
+    e3[500 + 190] = 17.0
+    u3[500 + 190, 1] = (127 * 2.0 ** 25 + 0.5) / 2.0 ** 32
+    w3 = rs.uniform(0, 1, off3[-1])
+    for ctx in (ctx2, ctx1):
+        sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+        ef, nul = sc.fdr(e3, w3, times=5, half_win_width=3, interval_off=off3, null_uniform=u3, return_null=True)
+        for i in range(3):
+            sl = slice(int(off3[i]), int(off3[i + 1]))
+            want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], e3[sl], w3[sl], 3, 5, seed=0, uniforms=u3[sl], return_null=True)
+            assert rel_err(nul[sl], wn) < 1e-9, i
+            assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (L3[i] * 5), i
+    ctx1.close()
+    ctx2.close()
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
 def test_host_api_fuzz(fpt, orc, seed):
     """the host-buffer entry points one reference call each (predict, the five window reducers,
