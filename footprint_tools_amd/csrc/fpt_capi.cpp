@@ -884,7 +884,6 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     // intervals -- and win 0.0055 ms per draw: from 32 draws per base on, or when asked for by FPT_FDR_SLICES=2)
     const bool use_slices = d->interval_off && d->half_win_width == 3 && c->fdr_split && c->fdr_light && c->fdr_slices &&
                             (d->times >= 32 || c->fdr_slices_always);
-    const int slice_len = fptk::fdr_slice_positions();
     int64_t sl_n[kClasses + 1] = {}, sl_at[kClasses + 2] = {}, ghist_total = 0;
     size_t pin_goff = 0, pin_slice_iv = 0, pin_slice_start = 0, pin_bytes = 0;
     if (d->interval_off) {
@@ -909,7 +908,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
             const int k = L > kLdsMax ? kClasses : cls_of((int)L);
             cls[(size_t)i] = (uint8_t)k;
             cls_n[k] += 1;
-            if (use_slices && k < kClasses && L > 256) sl_n[k] += (L + slice_len - 1) / slice_len;
+            if (use_slices && k < kClasses && L > 256) sl_n[k] += fptk::fdr_slices_of((int)L, false);
         }
         for (int k = 0; k <= kClasses; ++k) cls_at[k + 1] = cls_at[k] + cls_n[k];
         for (int k = 0; k <= kClasses; ++k) sl_at[k + 1] = sl_at[k] + sl_n[k];
@@ -948,6 +947,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
                 }
                 goff[i] = ghist_total;
                 ghist_total += L + 2;
+                const int slice_len = fptk::fdr_slice_positions_of((int)L, false);
                 for (int64_t st0 = 0; st0 < L; st0 += slice_len) {
                     s_iv[scur[k]] = (int32_t)i;
                     s_start[scur[k]++] = (int32_t)st0;
@@ -1023,6 +1023,17 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     };
     if (!d->interval_off) {  // uniform batch
         if (lmax > kLdsMax) return launch_long(nullptr, 0);
+        // intervals of more than 256 bases: the light draws as slices (see the ragged batches above), interval-major
+        if (lmax > 256 && fl.ws_key && d->half_win_width == 3 && c->fdr_light && c->fdr_slices &&
+            (d->times >= 32 || c->fdr_slices_always)) {
+            void *d_counts;
+            const size_t count_bytes = (size_t)d->n_intervals * ((size_t)lmax + 3) * sizeof(int32_t);
+            if (int rc = ws_get(c, 15, count_bytes, &d_counts)) return rc;
+            HIP_TRY(hipMemsetAsync(d_counts, 0, count_bytes, c->stream));
+            fl.ghist = (int32_t *)d_counts;
+            fl.gnan = (int32_t *)d_counts + (size_t)d->n_intervals * ((size_t)lmax + 2);
+            fl.n_slices = d->n_intervals * (int64_t)fptk::fdr_slices_of(lmax, true);
+        }
         fl.n2_max = pow2(lmax);
         fl.nt = cls_nt[cls_of(lmax)];
         fl.max_len = lmax;

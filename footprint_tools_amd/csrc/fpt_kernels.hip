@@ -1263,6 +1263,15 @@ FPT_SCAN_INSTANCES(FPT_INST)
 // The null values are never stored: 100 draws per base stay on chip.
 // ===========================================================================
 __host__ __device__ inline int fdr_guide_slices(int n2) { return 4 * n2 < 4096 ? 4 * n2 : 4096; }
+// the lanes of a slice of an interval of L bases: 128, 192 or 256, whichever covers the interval's positions
+// (lanes - 6 outputs per slice) with the fewest lanes in all; of equals the widest (fewer halo positions)
+__host__ __device__ inline int fdr_slice_lanes(int L) {
+    int best = 256, cost = ((L + 249) / 250) * 256;
+    const int c192 = ((L + 185) / 186) * 192, c128 = ((L + 121) / 122) * 128;
+    if (c192 < cost) best = 192, cost = c192;
+    if (c128 < cost) best = 128;
+    return best;
+}
 
 struct fdr_args {
     int64_t n_intervals;
@@ -2246,8 +2255,9 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
 // k_fdr_slice / k_fdr_slice_finish: the light draws of an interval of more than 256 bases as SLICES.
 // An interval's null tracks are independent across positions but for the 2 hw + 1 window, and a draw
 // is a function of its position (the Philox counter): so a long interval is drawn by several workgroups of
-// the size that suits the short ones -- three wavefronts, one lane per position, kFdrSliceLanes - 2 hw output
-// positions each with hw halo positions either side drawn again -- every one holding the interval's
+// the size that suits the short ones -- three wavefronts (in a uniform batch two to four, whichever leaves the
+// fewest lanes idle over an interval: fdr_slice_lanes), one lane per position, lanes - 2 hw output positions each
+// with hw halo positions either side drawn again -- every one holding the interval's
 // thresholds, its rank guide and a private histogram that it adds to a global one at the end;
 // k_fdr_slice_finish then turns the interval's counts into its efdr like step 3 of k_fdr_null.  As one
 // workgroup an interval of 300 bases left five workgroups on a CU (its 512-entry buffers) and ran its lanes
@@ -2257,33 +2267,37 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
 // full launch that follows (MODE 2, redo_only, one workgroup per interval) does those.
 // LDS: par 24 | skey n2 | z 4 x lanes | hist n2 + 2 (int) | misc 8 (int) | guide (16-bit).
 // ===========================================================================
-constexpr int kFdrSliceLanes = 192;
+constexpr int kFdrSliceLanes = 192;  // ragged batches; a uniform batch takes 128, 192 or 256 (fdr_slice_lanes)
 struct fdr_slice_args {
     fdr_args a;
     const int32_t *slice_iv;     // per workgroup: the interval ...
     const int32_t *slice_start;  // ... and the first of its output positions
     const int64_t *goff;         // per interval: where its L + 2 counts start in ghist
+    int32_t per_interval;        // uniform batches (the three above null): slices per interval, interval-major
+    int64_t slice_first;         // ... and the slice of this launch's first workgroup
     int32_t *ghist;
     int32_t *gnan;               // per interval: null windows that are not a number
 };
 
-__global__ void __launch_bounds__(kFdrSliceLanes, 8) k_fdr_slice(const fdr_slice_args sa) {
+template <int NT>
+__global__ void __launch_bounds__(NT, 8) k_fdr_slice(const fdr_slice_args sa) {
     extern __shared__ double smem[];
-    constexpr int NT = kFdrSliceLanes, HS = 3;
+    constexpr int NTMAX = NT, HS = 3;
     const fdr_args &a = sa.a;
     const int n2 = a.n2_max;
     double *par = smem;                                   // 24
     double *skey = par + 24;                              // n2: the interval's sorted thresholds
     double *zq = skey + n2;                               // 2 x NT pairs: z of the pass's four samples
-    int *hist = reinterpret_cast<int *>(zq + 4 * NT);     // n2 + 2
+    int *hist = reinterpret_cast<int *>(zq + 4 * NTMAX);  // n2 + 2
     int *misc = hist + n2 + 2;                            // [0] n_nan
     uint16_t *rguide = reinterpret_cast<uint16_t *>(misc + 8);
     const int tid = threadIdx.x;
-    const int64_t iv = sa.slice_iv[blockIdx.x];
+    const int64_t wg = sa.slice_first + blockIdx.x;
+    const int64_t iv = sa.slice_iv ? (int64_t)sa.slice_iv[blockIdx.x] : wg / sa.per_interval;
     if (a.ws_misc[3 * iv + 2] != 0) return;  // left to the full launch
-    const int s0 = sa.slice_start[blockIdx.x];
-    const int64_t off = a.interval_off[iv];
-    const int L = (int)(a.interval_off[iv + 1] - off);
+    const int64_t off = a.interval_off ? a.interval_off[iv] : iv * (int64_t)a.interval_len;
+    const int L = a.interval_off ? (int)(a.interval_off[iv + 1] - off) : a.interval_len;
+    const int s0 = sa.slice_iv ? sa.slice_start[blockIdx.x] : (int)(wg % sa.per_interval) * (NT - 2 * HS);
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
     if (np2 > n2 || s0 >= L) return;  // (a stale host copy of the offsets: the full launch's guard reports it)
@@ -2318,7 +2332,7 @@ __global__ void __launch_bounds__(kFdrSliceLanes, 8) k_fdr_slice(const fdr_slice
     const int rl = valid ? alias_row_of(a.exp[off + t], a.memo_exp, row_lg) : -1;
     const bool has_up = a.null_uniform != nullptr;
     bool left_out = false;
-    double2 *z01 = reinterpret_cast<double2 *>(zq), *z23 = z01 + NT;
+    double2 *z01 = reinterpret_cast<double2 *>(zq), *z23 = z01 + NTMAX;
     for (int s = 0; s < a.times; s += 4) {
         const int ns = a.times - s < 4 ? a.times - s : 4;
         uint32_t w4[4] = {0u, 0u, 0u, 0u};
@@ -2396,7 +2410,7 @@ __global__ void __launch_bounds__(kFdrSliceLanes, 8) k_fdr_slice(const fdr_slice
         if (tid == 0) a.ws_misc[3 * iv + 2] = 1;
         return;
     }
-    int32_t *gh = sa.ghist + sa.goff[iv];
+    int32_t *gh = sa.ghist + (sa.goff ? sa.goff[iv] : iv * (int64_t)(L + 2));
     for (int i = tid; i <= m; i += NT) {
         const int v = hist[i];
         if (v) atomicAdd(&gh[i], v);
@@ -2414,13 +2428,13 @@ __global__ void __launch_bounds__(256) k_fdr_slice_finish(const fdr_slice_args s
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
     if (a.ws_misc[3 * iv + 2] != 0) return;
-    const int64_t off = a.interval_off[iv];
-    const int L = (int)(a.interval_off[iv + 1] - off);
+    const int64_t off = a.interval_off ? a.interval_off[iv] : iv * (int64_t)a.interval_len;
+    const int L = a.interval_off ? (int)(a.interval_off[iv + 1] - off) : a.interval_len;
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
     if (L <= 0 || np2 > a.n2_max) return;
     const int m = a.ws_misc[3 * iv];
-    const int32_t *gh = sa.ghist + sa.goff[iv];
+    const int32_t *gh = sa.ghist + (sa.goff ? sa.goff[iv] : iv * (int64_t)(L + 2));
     for (int i = tid; i <= m; i += NT) hist[i] = gh[i];
     __syncthreads();
     if (tid < kWave) {
@@ -3018,12 +3032,14 @@ void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_ex
                        (uint8_t *)(t + nb_alias_lg_offset(n_models, memo_exp, memo_obs)));
 }
 
-size_t fdr_slice_lds_bytes(int n2) {
+size_t fdr_slice_lds_bytes(int n2, int lanes) {
     const size_t guide = ((size_t)fdr_guide_slices(n2) + 2) * sizeof(uint16_t);
-    return (size_t)(24 + (size_t)n2 + 4 * kFdrSliceLanes) * sizeof(double) + (size_t)((size_t)n2 + 2 + 8) * sizeof(int) +
+    return (size_t)(24 + (size_t)n2 + 4 * (size_t)lanes) * sizeof(double) + (size_t)((size_t)n2 + 2 + 8) * sizeof(int) +
            ((guide + 7) & ~(size_t)7);
 }
-int fdr_slice_positions() { return kFdrSliceLanes - 6; }
+// (uniform: every interval of the batch has L bases and the lanes are chosen for it; ragged batches: 192)
+int fdr_slice_positions_of(int L, bool uniform) { return (uniform ? fdr_slice_lanes(L) : kFdrSliceLanes) - 6; }
+int fdr_slices_of(int L, bool uniform) { return (L + fdr_slice_positions_of(L, uniform) - 1) / fdr_slice_positions_of(L, uniform); }
 
 size_t fdr_lds_bytes(int n2, bool dbuf, bool global_buffers) {
     const size_t guide = ((size_t)fdr_guide_slices(n2) + 2) * (global_buffers ? sizeof(int) : sizeof(uint16_t));
@@ -3100,7 +3116,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     // split: set-up (1), light draws (3), full draws of what the light ones left (2); without `light`: 1, 2
     const bool light = fl.light;
     const int modes_split[3] = {1, light ? 3 : 2, 2}, n_modes = split ? (light ? 3 : 2) : 1;
-    const bool sliced = split && light && fl.n_slices > 0 && fl.slice_iv && fl.ghist && fl.interval_off;
+    const bool sliced = split && light && fl.n_slices > 0 && fl.ghist && (fl.interval_off ? fl.slice_iv != nullptr : fl.interval_len > 0);
     for (int mi = 0; mi < n_modes; ++mi) {
         const int mode = split ? modes_split[mi] : 0;
         if (mode == 3 && sliced) {  // the light draws of this class as slices, then the counts -> efdr per interval
@@ -3111,15 +3127,22 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
             sa.goff = fl.goff;
             sa.ghist = fl.ghist;
             sa.gnan = fl.gnan;
-            const size_t lds_s = fdr_slice_lds_bytes(fl.n2_max), lds_f = ((size_t)fl.n2_max + 2) * sizeof(int);
-            hipError_t e = hipFuncSetAttribute((const void *)k_fdr_slice, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            sa.per_interval = fl.interval_off ? 0 : fdr_slices_of(fl.interval_len, true);
+            sa.slice_first = 0;
+            const int lanes = fl.interval_off ? kFdrSliceLanes : fdr_slice_lanes(fl.interval_len);
+            void (*kslice)(const fdr_slice_args) = lanes == 128 ? k_fdr_slice<128> : (lanes == 256 ? k_fdr_slice<256> : k_fdr_slice<192>);
+            const size_t lds_s = fdr_slice_lds_bytes(fl.n2_max, lanes), lds_f = ((size_t)fl.n2_max + 2) * sizeof(int);
+            hipError_t e = hipFuncSetAttribute((const void *)kslice, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
             if (e != hipSuccess) return e;
             for (int64_t done = 0; done < fl.n_slices; done += 0x7fffff00) {
                 fdr_slice_args b = sa;
-                b.slice_iv += done;
-                b.slice_start += done;
+                if (b.slice_iv) {
+                    b.slice_iv += done;
+                    b.slice_start += done;
+                }
+                b.slice_first = done;
                 const int64_t n = fl.n_slices - done < 0x7fffff00 ? fl.n_slices - done : 0x7fffff00;
-                hipLaunchKernelGGL(k_fdr_slice, dim3((unsigned)n), dim3(kFdrSliceLanes), lds_s, st, b);
+                hipLaunchKernelGGL(kslice, dim3((unsigned)n), dim3(lanes), lds_s, st, b);
             }
             for (int64_t done = 0; done < n_blocks; done += 0x7fffff00) {
                 fdr_slice_args b = sa;

@@ -155,8 +155,9 @@ struct segment_launch {
 };
 void launch_segment(hipStream_t st, const segment_launch &sl, bool fill);
 size_t fdr_lds_bytes(int n2, bool dbuf = false, bool global_buffers = false);
-size_t fdr_slice_lds_bytes(int n2);
-int fdr_slice_positions();  // output positions per slice
+size_t fdr_slice_lds_bytes(int n2, int lanes);
+int fdr_slices_of(int L, bool uniform);            // slices of an interval of L bases (of a uniform / a ragged batch) ...
+int fdr_slice_positions_of(int L, bool uniform);   // ... and the output positions of each
 void launch_nb_alias(hipStream_t st, const void *memo, int n_models, int memo_exp, int memo_obs, void *tables);
 // the tile table of a ragged batch (three int32 arrays of n_tiles in `flat`, 32-byte records in `recs`)
 // from the device offsets: class-major, intervals in order.  block_base (device): for every

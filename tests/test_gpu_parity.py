@@ -2321,6 +2321,19 @@ def test_fdr_sliced_draws_equal_whole_interval(fpt, orc):
         want, wn = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[sl], winp[sl], 3, 6, seed=7, base0=99 + int(off[i]), return_null=True)
         assert rel_err(outs[0][2][sl], wn) < 1e-9, i
         assert np.max(np.abs(outs[0][1][sl] - want)) <= 2.5 / (lens[i] * 6), i
+    # uniform batches: the slices are cut interval-major without lists
+    for Lu in (300, 372, 373, 1000):
+        n_u = 9
+        eu, wu, ou = exp[:n_u * Lu].copy(), winp[:n_u * Lu], obs[:n_u * Lu]
+        eu[4 * Lu + 7] = 300.0   # one interval marked by the set-up
+        res = []
+        for ctx in (ctx2, ctx1, None):
+            sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), ctx=ctx)
+            res.append((sc.fdr(eu, wu, times=9, seed=3, half_win_width=3, interval_len=Lu, base_index0=77, obs=ou),
+                        sc.fdr(eu, wu, times=33, seed=4, half_win_width=3, interval_len=Lu)))
+        for k in (0, 1):
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), (Lu, k)
+            assert np.array_equal(res[2][k], res[1][k], equal_nan=True), (Lu, k)
     # given uniforms, among them a word in the rest of an unmarked row in the middle of a sliced interval
     L3 = np.array([500, 300, 700])
     off3 = np.concatenate([[0], np.cumsum(L3)]).astype(np.int64)
