@@ -1592,7 +1592,14 @@ __device__ __forceinline__ double from_ordered_bits(long long k) {
     const long long b = k < 0 ? (long long)(0x8000000000000000ull - (unsigned long long)k) : k;
     return __longlong_as_double(b);
 }
-__device__ __forceinline__ double ndtr_threshold_from(double y, double P);
+// ndtr(a), and for a > 0 the addend it is the sum of (ndtr(a) = base + t rounded once: fpt_math.hpp): one
+// evaluation for both
+__device__ __forceinline__ double ndtr_and_addend(double a, double &t, double &base, double &ec) {
+    t = fptm::ndtr_addend_pos(a, base, &ec);  // (any sign: 0.5 erf in the centre, -Phi(-|a|) in the tails)
+    return (base == 1.0 && a < 0.0) ? -t : base + t;
+}
+__device__ __forceinline__ double ndtr_threshold_from(double y, double P, bool have0 = false, double t0 = 0.0, double base0 = 0.0,
+                                                      double ec0 = 1.0);
 __device__ __forceinline__ double ndtr_threshold(double P) {
     if (!(P < 1.0)) return fptm::kInf;  // ndtr never exceeds 1
     if (P < 0.0) return -fptm::kInf;
@@ -1648,17 +1655,20 @@ __device__ __forceinline__ double ndtr_threshold(double P) {
 // the windows look like.  ndtr is not monotone to the last bit, so "the" end of a plateau is one of a
 // few neighbouring values whichever way it is searched: this search and the plain one differ by a
 // value or two of y in 0.3 % of the cases around y = 0 and in none in the tail.
-__device__ __forceinline__ double ndtr_threshold_from(double y, double P) {
+// have0: the caller made P as ndtr(y) from y's own addend (ndtr_and_addend): t0, base0, ec0 are the first
+// iteration's evaluation.
+__device__ __forceinline__ double ndtr_threshold_from(double y, double P, bool have0, double t0, double base0, double ec0) {
     long long lo = ordered_bits(y), hi, step = 1;  // ndtr(lo) <= P
     long long k = lo + 1;
     if (y > 0.0) {
         const bool central = fptm::ndtr_is_central(y);
         const double up = __longlong_as_double(__double_as_longlong(P) + 1) - P;  // ulp(P), P in [0.5, 1)
         double a = y;
+#pragma clang loop unroll(disable)
         for (int it = 0; it < 6; ++it) {
             if (fptm::ndtr_is_central(a) != central || !(a < 40.0)) break;
-            double base, ec = 1.0;
-            const double t = fptm::ndtr_addend_pos(a, base, &ec);
+            double base = base0, ec = ec0, t = t0;
+            if (it > 0 || !have0) t = fptm::ndtr_addend_pos(a, base, &ec);
             const double ts = (P - base) + 0.5 * up;
             const double d = central ? (ts - t) / (exp(-0.5 * a * a) * 0.3989422804014327)
                                      : log(t / ts) * ec * 1.2533141373155003;
@@ -1751,7 +1761,7 @@ __device__ unsigned long long g_fdr_phase[16];
 // marked by the set-up launch and skipped; one whose draw falls into a row's rest (2^-32 of the draws)
 // marks itself and stores nothing.  The full instance (MODE 2 with redo_only) then does the marked ones.
 template <int NT, bool GWS, int HSC, bool ONE, int MODE = 0>
-__global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || NT > 256) ? 2 : 4)) k_fdr_null(const fdr_args a) {
+__global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 1 && NT <= 256 && !GWS) ? 7 : ((GWS || NT > 256) ? 2 : 4)) k_fdr_null(const fdr_args a) {
     extern __shared__ double smem[];
     constexpr bool DRAWS = MODE == 2 || MODE == 3, LIGHT = MODE == 3;
     const int n2 = a.n2_max;
@@ -1954,9 +1964,12 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : ((GWS || 
         for (int i = tid; i < m; i += NT) {
             const double yo = skey[i];
             if (yo == kThresholdOfOne) continue;
-            const double pv = fptm::ndtr(yo);  // the observed window p-value, by the function the search uses
+            // the observed window p-value, by the function the search uses -- and for y > 0 as the sum the search
+            // starts from: its first look at the addend is this one
+            double t0 = 0.0, base0 = 0.0, ec0 = 1.0;
+            const double pv = ndtr_and_addend(yo, t0, base0, ec0);
             if (pv < 1.0) {
-                skey[i] = sum_threshold(ABL(8192) ? yo : ndtr_threshold_from(yo, pv), a.sqrt_k, a.inv_sqrt_k);
+                skey[i] = sum_threshold(ABL(8192) ? yo : ndtr_threshold_from(yo, pv, yo > 0.0, t0, base0, ec0), a.sqrt_k, a.inv_sqrt_k);
                 below += 1;
             } else {
                 skey[i] = kThresholdOfOne;
