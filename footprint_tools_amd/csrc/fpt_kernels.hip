@@ -1896,36 +1896,61 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 
             sidx[i] = i < L ? (int)a.ws_idx[off + i] : -1;
         }
     }
-    for (int i = tid; i < np2 + 2; i += NT) hist[i] = 0;
+    for (int i = tid; i < (ONE && !DRAWS && !GWS ? n2 : np2) + 2; i += NT) hist[i] = 0;
     if (tid < 4) misc[tid] = (DRAWS && tid >= 1 && tid <= 2) ? a.ws_misc[3 * iv + tid - 1] : 0;
     __syncthreads();
     FDR_MARK(1)  // keys
     if (n_num) atomicAdd(&misc[1], n_num);
     if (n_below_one) atomicAdd(&misc[2], n_below_one);
     if (ONE && !DRAWS) {
-        // One key per lane: its place in the order is the number of keys that come before it -- a
-        // walk over the interval's keys (LDS broadcast reads), a compare and an add each: 4 L
-        // instructions per wavefront where the bitonic network below issues ~2,000 for 256 slots and
-        // meets at 36 barriers.  Keys of earlier wavefronts come before an equal key of this one,
-        // keys of later ones after; inside the wavefront's own 64 the position decides.
-        const double *key = zb + n2;
-        const int w0 = __builtin_amdgcn_readfirstlane(tid) & ~(kWave - 1);
-        const int e0 = w0 < L ? w0 : L, e1 = w0 + kWave < L ? w0 + kWave : L;
-        int rank = 0;
-        // (unrolled: the reads of eight keys go out together, a read per compare is a latency chain)
-#pragma unroll 8
-        for (int j = 0; j < e0; ++j) rank += key[j] <= v_one ? 1 : 0;
-#pragma unroll 8
-        for (int j = e0; j < e1; ++j) {
-            const double kj = key[j];
-            rank += (kj < v_one || (kj == v_one && j < tid)) ? 1 : 0;
+        // One key per lane: its place in the order is the number of keys that come before it (equal keys in the
+        // order of their positions).  Counting them all -- a walk over the interval's keys, 4 L instructions per
+        // wavefront -- was a quarter of the set-up's instructions; the keys are FILED first instead: n2
+        // buckets by a monotone function of the key (window y values spread like a standard normal, p-values
+        // over [0, 1]; the last bucket takes 1.0, the edges and the NaNs), a count per bucket by LDS atomics, their
+        // prefix, every key written to its bucket's range, and a key then counts only the keys of its own
+        // bucket that come before it: one or two where there were L.  (A bucket full of equal keys -- the all-zero
+        // windows of sparse data -- is counted as before.)  The bitonic network below issues ~2,000 instructions
+        // for 256 slots and meets at 36 barriers.
+        double *tkey = zb;   // the z of step 0 are done with (every lane is past the barrier above)
+        int *tidx = nf, *cnt = hist;  // (hist is zero; it is zeroed again below)
+        const double bscale = a.obs ? (double)(n2 - 2) / 12.0 : (double)(n2 - 1);
+        int b = n2 - 1;
+        if (v_one < 1e299) {
+            const double f = a.obs ? fma(v_one, bscale, 6.0 * bscale) : v_one * bscale;
+            b = (int)fmin(fmax(f, 0.0), (double)(n2 - 2));
         }
-#pragma unroll 8
-        for (int j = e1; j < L; ++j) rank += key[j] < v_one ? 1 : 0;
+        int slot = 0;
+        if (tid < L) slot = atomicAdd(&cnt[b], 1);
+        __syncthreads();
+        if (tid < kWave) {  // exclusive prefix of the counts, in place
+            int carry = 0;
+            for (int base = 0; base < n2; base += kWave) {
+                const int c = cnt[base + lane];
+                const int incl = wave_scan_i32(c) + carry;
+                cnt[base + lane] = incl - c;
+                carry = __shfl(incl, kWave - 1, kWave);
+            }
+            if (lane == 0) cnt[n2] = carry;
+        }
+        __syncthreads();
+        const int first = cnt[b], last = cnt[b + 1];
         if (tid < L) {
+            tkey[first + slot] = v_one;
+            tidx[first + slot] = tid;
+        }
+        __syncthreads();
+        if (tid < L) {
+            int rank = first;
+            for (int j = first; j < last; ++j) {
+                const double kj = tkey[j];
+                rank += (kj < v_one || (kj == v_one && tidx[j] < tid)) ? 1 : 0;
+            }
             skey[rank] = v_one;
             sidx[rank] = tid;
         }
+        __syncthreads();
+        for (int i = tid; i < n2 + 2; i += NT) hist[i] = 0;
     }
     // (barrier-free stages for partner distances below 64 -- a wavefront owns whole 64-element
     // blocks -- were measured: 6 instead of 36 barriers for 256 elements, no change in time)
