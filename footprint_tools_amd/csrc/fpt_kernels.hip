@@ -1684,30 +1684,24 @@ __device__ __forceinline__ double ndtr_threshold_from(double y, double P, bool h
         }
         if (a > y && a < 40.0) k = ordered_bits(a);
     }
-    if (k > lo + 1 && fptm::ndtr(from_ordered_bits(k)) > P) {  // at or beyond the end: down to it
-        hi = k;
-        for (;;) {
-            const long long c = hi - step;
-            if (c <= lo) break;  // (lo itself is on the plateau)
-            if (!(fptm::ndtr(from_ordered_bits(c)) > P)) {
-                lo = c;
-                break;
-            }
-            hi = c;
-            step <<= 1;
+    // The guess lies at or beyond the end of the plateau (then: DOWN to the first value still on it, not below
+    // lo, which is) or on it (UP to the first value beyond).  One loop for both: a wavefront's lanes go either
+    // way about evenly, and as two loops each direction waited for the other's evaluations of the exact cdf.
+    const bool above = k > lo + 1 && fptm::ndtr(from_ordered_bits(k)) > P;
+    long long cur = (above || k > lo + 1) ? k : lo, oth = lo;
+    for (;;) {
+        const long long c = above ? cur - step : cur + step;
+        if (above && c <= lo) break;  // (oth = lo: lo itself is on the plateau)
+        const bool ab = fptm::ndtr(from_ordered_bits(c)) > P;
+        if (ab != above) {
+            oth = c;
+            break;
         }
-    } else {  // on the plateau: up from here
-        if (k > lo + 1) lo = k;
-        for (;;) {
-            const long long c = lo + step;
-            if (fptm::ndtr(from_ordered_bits(c)) > P) {
-                hi = c;
-                break;
-            }
-            lo = c;
-            step <<= 1;
-        }
+        cur = c;
+        step <<= 1;
     }
+    hi = above ? cur : oth;
+    lo = above ? oth : cur;
     while (hi - lo > 1) {
         const long long mid = lo + ((hi - lo) >> 1);
         if (fptm::ndtr(from_ordered_bits(mid)) > P) hi = mid; else lo = mid;
