@@ -945,7 +945,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
                     goff[i] = -1;
                     continue;
                 }
-                goff[i] = ghist_total;
+                goff[i] = ghist_total | ((L + 2) << 40);  // (offset, room)
                 ghist_total += L + 2;
                 const int slice_len = fptk::fdr_slice_positions_of((int)L, false);
                 for (int64_t st0 = 0; st0 < L; st0 += slice_len) {
@@ -1007,6 +1007,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
             fl.ws_key = (double *)ws;
             fl.ws_idx = (uint16_t *)((char *)ws + key_b);
             fl.ws_misc = (int32_t *)((char *)ws + key_b + idx_b);
+            fl.ws_total = total;
         }
     }
     // long intervals: per-workgroup buffers in a global workspace of at most 1 GiB

@@ -1307,6 +1307,7 @@ struct fdr_args {
     double *ws_key;
     uint16_t *ws_idx;
     int32_t *ws_misc;        // three per interval: m, rank_one, and "left to the full draw launch" (see MODE 3)
+    int64_t ws_total;        // positions the hand-over arrays have room for (the host's total)
     int32_t redo_only;       // MODE 2: only the intervals the light draw launch left
 };
 
@@ -1802,7 +1803,7 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 
     // The launch and its buffers were sized from the HOST copy of the offsets; these come from the device.
     // If the two disagree (a stale host array) the interval does not fit: it is not processed -- NaN in its
     // efdr says so -- rather than written past the buffers.
-    if (np2 > n2 || (ONE && L > NT)) {
+    if (np2 > n2 || (ONE && L > NT) || (MODE != 0 && off + L > a.ws_total)) {
         if (MODE != 1)
             for (int i = tid; i < L; i += NT) a.efdr[off + i] = NAN;
         return;
@@ -2308,7 +2309,8 @@ struct fdr_slice_args {
     fdr_args a;
     const int32_t *slice_iv;     // per workgroup: the interval ...
     const int32_t *slice_start;  // ... and the first of its output positions
-    const int64_t *goff;         // per interval: where its L + 2 counts start in ghist
+    const int64_t *goff;         // per interval: where its counts start in ghist (low 40 bits) and how many there
+                                 // is room for (above them: the HOST's L + 2)
     int32_t per_interval;        // uniform batches (the three above null): slices per interval, interval-major
     int64_t slice_first;         // ... and the slice of this launch's first workgroup
     int32_t *ghist;
@@ -2336,7 +2338,9 @@ __global__ void __launch_bounds__(NT, 8) k_fdr_slice(const fdr_slice_args sa) {
     const int s0 = sa.slice_iv ? sa.slice_start[blockIdx.x] : (int)(wg % sa.per_interval) * (NT - 2 * HS);
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
-    if (np2 > n2 || s0 >= L) return;  // (a stale host copy of the offsets: the full launch's guard reports it)
+    if (np2 > n2 || s0 >= L || off + L > a.ws_total) return;  // (a stale host copy of the offsets: the full launch's guard reports it)
+    const int64_t goff = sa.goff ? sa.goff[iv] : (iv * (int64_t)(L + 2)) | ((int64_t)(L + 2) << 40);
+    if ((goff >> 40) < L + 2) return;  // ... or k_fdr_slice_finish: the interval's counts have no room here
     const int dm = a.dm_ids ? a.dm_ids[iv] : 0;
     const double2 *memo = a.memo + (size_t)dm * a.memo_exp * a.memo_obs;
     const uint32_t *alias = a.alias + ((size_t)dm * a.memo_exp << a.alias_lg);
@@ -2446,7 +2450,7 @@ __global__ void __launch_bounds__(NT, 8) k_fdr_slice(const fdr_slice_args sa) {
         if (tid == 0) a.ws_misc[3 * iv + 2] = 1;
         return;
     }
-    int32_t *gh = sa.ghist + (sa.goff ? sa.goff[iv] : iv * (int64_t)(L + 2));
+    int32_t *gh = sa.ghist + (goff & ((1ll << 40) - 1));
     for (int i = tid; i <= m; i += NT) {
         const int v = hist[i];
         if (v) atomicAdd(&gh[i], v);
@@ -2463,15 +2467,21 @@ __global__ void __launch_bounds__(256) k_fdr_slice_finish(const fdr_slice_args s
     int *hist = reinterpret_cast<int *>(smem);  // n2 + 2
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int64_t iv = a.iv_list ? (int64_t)a.iv_list[blockIdx.x] : a.iv_first + blockIdx.x;
-    if (a.ws_misc[3 * iv + 2] != 0) return;
     const int64_t off = a.interval_off ? a.interval_off[iv] : iv * (int64_t)a.interval_len;
     const int L = a.interval_off ? (int)(a.interval_off[iv + 1] - off) : a.interval_len;
     int np2 = 1;
     while (np2 < L) np2 <<= 1;
-    if (L <= 0 || np2 > a.n2_max) return;
+    if (L <= 0) return;
+    if (np2 > a.n2_max || off + L > a.ws_total) {  // (as k_fdr_null's guard: the interval does not fit what the host sized)
+        for (int i = tid; i < L; i += NT) a.efdr[off + i] = NAN;
+        return;
+    }
+    if (a.ws_misc[3 * iv + 2] != 0) return;  // left to the full launch
     const int m = a.ws_misc[3 * iv];
-    const int32_t *gh = sa.ghist + (sa.goff ? sa.goff[iv] : iv * (int64_t)(L + 2));
-    for (int i = tid; i <= m; i += NT) hist[i] = gh[i];
+    const int64_t goff = sa.goff ? sa.goff[iv] : (iv * (int64_t)(L + 2)) | ((int64_t)(L + 2) << 40);
+    const bool room = (goff >> 40) >= L + 2;
+    const int32_t *gh = sa.ghist + (goff & ((1ll << 40) - 1));
+    for (int i = tid; i <= m; i += NT) hist[i] = room ? gh[i] : 0;
     __syncthreads();
     if (tid < kWave) {
         int carry = 0;
@@ -2487,6 +2497,12 @@ __global__ void __launch_bounds__(256) k_fdr_slice_finish(const fdr_slice_args s
     const int n_finite = hist[m];
     const int n_nan = sa.gnan[iv];
     const double denom = (double)L * (double)a.times;
+    // The slices were cut from the HOST copy of the offsets; this length comes from the device.  If the two
+    // disagree (a stale host array) the counts are not the interval's L * times: NaN says so, as in k_fdr_null.
+    if (!room || (long long)n_finite + n_nan != (long long)L * a.times) {
+        for (int i = tid; i < L; i += NT) a.efdr[off + i] = NAN;
+        return;
+    }
     for (int i = tid; i < L; i += NT) {
         const int pos = (int)a.ws_idx[off + i];
         double f = 1.0;  // NaN observed: the two-pointer walk runs to the end (utils.pyx:76)
@@ -3149,6 +3165,7 @@ hipError_t launch_fdr(hipStream_t st, const fdr_launch &fl) {
     a.ws_key = fl.ws_key;
     a.ws_idx = fl.ws_idx;
     a.ws_misc = fl.ws_misc;
+    a.ws_total = fl.ws_total;
     // split: set-up (1), light draws (3), full draws of what the light ones left (2); without `light`: 1, 2
     const bool light = fl.light;
     const int modes_split[3] = {1, light ? 3 : 2, 2}, n_modes = split ? (light ? 3 : 2) : 1;

@@ -93,6 +93,7 @@ struct fdr_launch {
     // split + light launches of intervals of more than 256 bases: their light draws as slices (k_fdr_slice)
     const int32_t *slice_iv, *slice_start;  // DEVICE, n_slices each: interval and first output position of a slice
     int64_t n_slices;
+    int64_t ws_total;                       // positions ws_key / ws_idx have room for
     const int64_t *goff;                    // DEVICE, per interval: start of its L + 2 counts in ghist
     int32_t *ghist, *gnan;                  // DEVICE, zeroed by the caller: counts per interval, NaN windows per interval
     int32_t memo_exp, memo_obs;

@@ -2354,6 +2354,68 @@ def test_fdr_sliced_draws_equal_whole_interval(fpt, orc):
     ctx2.close()
 
 
+def test_fdr_stale_host_offsets_are_reported(fpt, orc):
+    """fpt_fdr_dev sizes its launches, buffers and slices from the HOST copy of the offsets and processes the
+    intervals the DEVICE offsets describe: where the two disagree -- an interval too long for the buffers of the
+    class the host length put it in, or a sliced interval whose slices do not cover it -- its efdr is NaN, nothing
+    is written past a buffer, and the other intervals are the oracle's."""
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,))
+    ctx = sc.ctx
+    rs = np.random.RandomState(5)
+    lens = np.array([120, 300, 200, 400, 150, 700])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    stale = off.copy()
+    # what the host believes: interval 1 has 100 bases (it has 300: a 128-base buffer), interval 3 has 370 (it has 400:
+    # two slices that stop at 372); the offsets after them shifted alike so that only those two lengths differ
+    stale_lens = lens.copy()
+    stale_lens[1], stale_lens[3] = 100, 370
+    stale_lens[5] += 230   # (the host's total is the device's: the hand-over arrays have room; its own slices are too many, harmlessly)
+    stale = np.concatenate([[0], np.cumsum(stale_lens)]).astype(np.int64)
+    total = int(off[-1])
+    exp = np.round(rs.gamma(2.0, 3.0, total))
+    winp = rs.uniform(0, 1, total)
+    times = 40
+    bufs = [DeviceArray(ctx, total * 8).upload(exp), DeviceArray(ctx, total * 8).upload(winp), DeviceArray(ctx, total * 8),
+            DeviceArray(ctx, off.nbytes).upload(off)]
+    try:
+        bufs[2].upload(np.full(total, -7.0))
+        sc.fdr_dev(lens.size, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, times=times, seed=3, interval_off_dev=bufs[3].ptr,
+                   interval_off_host=stale)
+        ctx.synchronize()
+        ef = bufs[2].download(np.float64, total)
+    finally:
+        for b in bufs:
+            b.free()
+    for i in range(lens.size):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        if i in (1, 3):
+            assert np.all(np.isnan(ef[sl])), i
+        else:
+            want = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[sl], winp[sl], 3, times, seed=3, base0=int(off[i]))
+            assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (lens[i] * times), i
+    # a host copy whose TOTAL is short: the intervals beyond it have no room in the hand-over arrays -- NaN, no overrun
+    short = np.concatenate([[0], np.cumsum([120, 300, 200, 400, 150, 300])]).astype(np.int64)
+    bufs = [DeviceArray(ctx, total * 8).upload(exp), DeviceArray(ctx, total * 8).upload(winp), DeviceArray(ctx, total * 8),
+            DeviceArray(ctx, off.nbytes).upload(off)]
+    try:
+        bufs[2].upload(np.full(total, -7.0))
+        sc.fdr_dev(lens.size, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, times=times, seed=3, interval_off_dev=bufs[3].ptr,
+                   interval_off_host=short)
+        ctx.synchronize()
+        ef = bufs[2].download(np.float64, total)
+    finally:
+        for b in bufs:
+            b.free()
+    assert np.all(np.isnan(ef[int(off[5]):])) and not np.any(ef == -7.0)
+    for i in range(5):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        want = orc.fdr_null(lat["mu_A"], lat["r_A"], exp[sl], winp[sl], 3, times, seed=3, base0=int(off[i]))
+        assert np.max(np.abs(ef[sl] - want)) <= 2.5 / (lens[i] * times), i
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "8"))))
 def test_host_api_fuzz(fpt, orc, seed):
     """the host-buffer entry points one reference call each (predict, the five window reducers,
