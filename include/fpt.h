@@ -270,10 +270,14 @@ typedef struct fpt_fdr_desc {
 } fpt_fdr_desc;
 
 /* Enqueue the null sampling + ranking on the context's stream (no synchronisation).
- * Intervals of up to 2048 bases are processed out of LDS; longer ones (up to 2^22 bases) by the
- * same kernel over buffers in global memory, which is slower per base.  interval_off_host, when given,
- * must be the very array that was uploaded to interval_off: launches and buffers are sized from it (an
- * interval that turns out longer than its launch's buffers is not processed: its efdr is set to NaN). */
+ * Intervals of up to 2048 bases are processed out of LDS (with the `detect` width in three kinds of launches:
+ * a per-interval set-up, the draws -- an interval of more than 256 bases by several workgroups, each a slice
+ * of it --, and the draws of the few intervals that need the direct inverse cdf); longer ones (up to 2^22
+ * bases) by one kernel over buffers in global memory, which is slower per base.  interval_off_host, when
+ * given, must be the very array that was uploaded to interval_off: launches, buffers and slices are sized
+ * from it.  Where it disagrees with the device's offsets nothing is written out of bounds, and an interval it
+ * misdescribes -- longer than its launch's buffers, beyond the total the host array ends at, or not covered
+ * by its slices -- is not processed: its efdr is set to NaN. */
 int fpt_fdr_dev(fpt_ctx *ctx, const fpt_fdr_desc *desc);
 
 /* ---- the multi-dataset posterior caller (BASELINE config 5; SURVEY.md 8a row A11 + 8f row 4).
