@@ -1255,12 +1255,15 @@ FPT_SCAN_INSTANCES(FPT_INST)
 
 // ===========================================================================
 // k_fdr_null: empirical FDR of one interval per workgroup (cli/detect.py:132-135).
-//   1. the interval's observed window p-values are sorted in LDS (bitonic, NaN last)
-//   2. `times` null tracks: per base an inverse-CDF NB draw whose p-value (and z) is read off the
-//      (exp, obs) table, Stouffer window like phase E of the scan, and every null window
-//      p-value is ranked in the sorted observed values with a binary search + LDS histogram
+//   1. the interval's observed window p-values are sorted in LDS (filed and ranked, or a bitonic network; NaN
+//      last) and translated into thresholds for the null windows' raw sums
+//   2. `times` null tracks: per base an NB draw from the row's alias table (k_nb_alias; the direct inverse cdf
+//      off the tables) whose z is read off a table, Stouffer window like phase E of the scan, and every null
+//      window is ranked among the thresholds through a guide + a short search, into an LDS histogram
 //   3. a prefix sum of the histogram gives #{null <= observed} for every base
 // The null values are never stored: 100 draws per base stay on chip.
+// With the `detect` width the steps are launches of their own (MODE below), and long intervals' draws are
+// sliced (k_fdr_slice).
 // ===========================================================================
 __host__ __device__ inline int fdr_guide_slices(int n2) { return 4 * n2 < 4096 ? 4 * n2 : 4096; }
 // the lanes of a slice of an interval of L bases: 128, 192 or 256, whichever covers the interval's positions
