@@ -12,7 +12,7 @@ import csv, glob, collections
 tot = collections.defaultdict(float); n = 0
 for f in glob.glob("$OUT/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "fdr_null" in row["Kernel_Name"]:
+        if "fdr_null" in row["Kernel_Name"] or "fdr_slice" in row["Kernel_Name"]:
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
 calls = 4.0  # one warm-up + three timed
 print("ablate=$bits per call:", " ".join("%s=%.4g" % (k, v / calls) for k, v in sorted(tot.items())), open("$OUT/log.txt").read().strip().splitlines()[-1][-60:])
