@@ -2163,7 +2163,7 @@ def test_fdr_fuzz(fpt, orc, seed):
     dm = str(rs.choice(["A", "B", "C"]))
     sc = FootprintScanner(golden("kmer_probs.npz")["table"], _DM(lat["mu_" + dm], lat["r_" + dm]), 5, 50, 0.01, (3,))
     hw = int(rs.choice([0, 1, 3, 3, 10, 40]))
-    times = int(rs.choice([1, 2, 3, 8, 13]))
+    times = int(rs.choice([1, 2, 3, 8, 13, 40]))  # (40: the sliced draws of ragged batches)
     n_iv = int(rs.randint(1, 7))
     lens = rs.choice([1, 2, 7, 64, 65, 100, 128, 129, 160, 192, 193, 250, 256, 257, 300, 384, 385, 511, 512, 1000, 4096,
                       4097, 6000], n_iv)  # (every workgroup size, single-round and two-round instances, both buffer kinds)
