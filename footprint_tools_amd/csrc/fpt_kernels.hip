@@ -2221,7 +2221,7 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 
                 // of one or two thresholds costs what it did, and a bracket full of EQUAL thresholds -- the
                 // windows of sparse data: hundreds of all-zero windows share one y, and most null windows
                 // are that very window -- is settled by the ends instead of log2(size) probes (sparse
-                // counts: 8.4e8 -> 1.0e9 bases/s, tests/diag_sparse_redo.py).  (skey[-1] is inside the
+                // counts: 8.4e8 -> 1.0e9 bases/s, tools/diag_sparse_redo.py).  (skey[-1] is inside the
                 // buffer: the slot before skey belongs to `par`.)
                 // (measured and dropped: brackets of up to 8 thresholds counted front to back -- a third of a
                 // bisection step's instructions per step, but a wavefront runs as many steps as its largest

@@ -26,7 +26,7 @@
 //     inside a 64-position tile, three words of LDS per tile for those across two -- and such a tile
 //     goes to the general kernel.  (Round 2 took any aligned row of 16 equal non-zero values for
 //     the sign: sparse counts, where a single cut makes ten equal window sums, tripped it in 16-47 %
-//     of the tiles, tests/diag_sparse_redo.py; with 33 it is 0.01-0.5 %);
+//     of the tiles, tools/diag_sparse_redo.py; with 33 it is 0.01-0.5 %);
 //   * expected = round(P/Q * t/99): Q is summed in the reference's order, the two divisions are
 //     replaced by one reciprocal with one Newton step, and a base whose product lies within
 //     1e-13 (relative) of a half-integer -- where the rounding of the exact operations could

@@ -434,7 +434,7 @@ inline uint64_t hop_members(const track_file *t, int ref, int64_t start, uint64_
 // of sorted intervals goes on from there instead of through the index -- a 16 kb window of a
 // per-base track is 16,384 rows in ~14 members, and a query that starts in the middle of one inflates
 // and walks half of that before its first row (a batch of 160-base intervals spent 98 % of its time
-// there: tests/bench_post_e2e.py).
+// there: tools/bench_post_e2e.py).
 struct row_cursor {
     bool valid = false;
     int ref = -1;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds for kernel experiments: libfpt_hip_a.so = git HEAD, libfpt_hip.so = working tree.
-# Then on the GPU box: bash tests/ab_head.sh   (AB_CFGS="3 2 4" to choose bench configs)
+# Then on the GPU box: bash tools/ab_head.sh   (AB_CFGS="3 2 4" to choose bench configs)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 rm -rf /tmp/ab_a && mkdir -p /tmp/ab_a

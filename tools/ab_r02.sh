@@ -2,7 +2,7 @@
 # Same-box A/B of two ROUNDS: .ab_r02/ (git archive of round 2's final commit 22761b5, built in
 # the build container; untracked) against the working tree, config 3, alternating, one lease.
 #   mkdir .ab_r02 && git archive 22761b5 | tar -x -C .ab_r02 && make -C .ab_r02/footprint_tools_amd/csrc -j6 \
-#     && make -C .ab_r02/oracle all          (then: gpurun -- 'bash tests/ab_r02.sh'; remove .ab_r02 afterwards)
+#     && make -C .ab_r02/oracle all          (then: gpurun -- 'bash tools/ab_r02.sh'; remove .ab_r02 afterwards)
 # Attributes a round-over-round move of the driver's headline to the box or to the kernel.
 cd "${GRAFT_REPO_ROOT:-.}"
 line() { python3 -c "

@@ -4,5 +4,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 for bits in 0 512 1024 1536 4096 5632; do
-  echo -n "ablate=$bits: "; FPT_ABLATE=$bits python3 tests/bench_fdr.py 2>&1 | tail -1
+  echo -n "ablate=$bits: "; FPT_ABLATE=$bits python3 tools/bench_fdr.py 2>&1 | tail -1
 done

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 for bits in ${ABL_BITS:-0 512 1024 4096 5632}; do
   OUT=gpurun_out/pmc_fdrabl_$bits; mkdir -p $OUT
-  FPT_ABLATE=$bits rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 ${ABL_SCRIPT:-tests/bench_fdr_ragged.py 100000 ${ABL_TIMES:-100}} > $OUT/log.txt 2>&1
+  FPT_ABLATE=$bits rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 ${ABL_SCRIPT:-tools/bench_fdr_ragged.py 100000 ${ABL_TIMES:-100}} > $OUT/log.txt 2>&1
   python3 - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(float); n = 0

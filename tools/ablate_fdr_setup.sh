@@ -5,5 +5,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export FPT_LIB_PATH=$PWD/footprint_tools_amd/libfpt_hip_ablate.so
 for bits in 0 8192 16384 24576 5120 29696; do
-  echo -n "ablate=$bits: "; FPT_ABLATE=$bits python3 tests/bench_fdr_ragged.py 100000 4 2>&1 | tail -1
+  echo -n "ablate=$bits: "; FPT_ABLATE=$bits python3 tools/bench_fdr_ragged.py 100000 4 2>&1 | tail -1
 done

@@ -1,7 +1,7 @@
 """Timing of the posterior caller (fpt_posterior_dev: cli/post.py:98-124 for a whole batch in one
 launch) on whole-genome-shaped input: ragged intervals (lognormal, mean ~162 bases), D datasets
 with hotspot gaps, integer expected counts, an FDR track with ~5 % calls.  Diagnostic; prints one
-line.  Usage: python tests/bench_posterior.py [n_intervals [n_datasets]]"""
+line.  Usage: python tools/bench_posterior.py [n_intervals [n_datasets]]"""
 import sys
 import time
 

@@ -1,10 +1,10 @@
-"""Diagnostic: distribution of the observed windows' y = ndtri(win p) in tests/bench_fdr_ragged.py's input."""
+"""Diagnostic: distribution of the observed windows' y = ndtri(win p) in tools/bench_fdr_ragged.py's input."""
 import sys
 import numpy as np
 from scipy.special import ndtri
 sys.path.insert(0, ".")
 sys.argv = [sys.argv[0], "20000", "4"]
-exec(open("tests/bench_fdr_ragged.py").read().split("for times in")[0])
+exec(open("tools/bench_fdr_ragged.py").read().split("for times in")[0])
 wp = d_out.download(np.float64, total, 3 * t8)
 p = d_out.download(np.float64, total, 2 * t8)
 y = ndtri(wp[np.isfinite(wp) & (wp < 1)])

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): one seed of test_fused_scan_fuzz, with where and how much the window
-p-values differ from the oracle.  Usage: python tests/diag_fuzz_seed.py SEED"""
+p-values differ from the oracle.  Usage: python tools/diag_fuzz_seed.py SEED"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Step-by-step GPU bring-up (diagnostic, not a pytest file): each step prints before and
-after so a hang or fault is attributable.  Run:  python tests/gpu_steps.py [step ...]"""
+after so a hang or fault is attributable.  Run:  python tools/gpu_steps.py [step ...]"""
 import sys
 import time
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick PMC profile of bench.py (SQ counters only).  Usage: bash tests/prof_pmc.sh <tag> [bench args]
+# quick PMC profile of bench.py (SQ counters only).  Usage: bash tools/prof_pmc.sh <tag> [bench args]
 set -u
 TAG=${1:-x}; shift || true
 cd "${GRAFT_REPO_ROOT:-.}"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of any python command, per kernel (mean per dispatch and total).
-# Usage: bash tests/prof_pmc_cmd.sh <tag> <kernel-substring> script.py [args]
+# Usage: bash tools/prof_pmc_cmd.sh <tag> <kernel-substring> script.py [args]
 set -u
 TAG=${1:-x}; KSUB=${2:-fdr_null}; shift 2
 cd "${GRAFT_REPO_ROOT:-.}"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun):
-#   bash tests/prof_run.sh <tag> [bench args...]
+#   bash tools/prof_run.sh <tag> [bench args...]
 # 1. rocprofv3 --kernel-trace --stats of bench.py            -> gpurun_out/prof_<tag>/trace
 # 2. separate --pmc passes (never combined with a trace):    -> gpurun_out/prof_<tag>/pmc_*
 #    FETCH_SIZE | WRITE_SIZE | SQ issue/wait counters | LDS counters
