@@ -468,6 +468,7 @@ def main():
         step_once()  # leave the headline mode's outputs in the buffers for the parity check
         sync()
 
+    job = comm.job_info() if comm is not None else None  # what RCCL itself says about the job, every rank's
     if comm is not None:  # the contract: the slowest rank's time
         dt = comm.max_over_ranks(dt)
         dt_scan = comm.max_over_ranks(dt_scan)
@@ -771,7 +772,11 @@ def main():
                                                    note="every step's track assembled (%s) on the communicator's stream beside "
                                                         "the next step's scan, two track buffers in turn" % args.assembly)
                                               if dt_asm else None),
-                               bases_per_rank=counts)
+                               bases_per_rank=counts,
+                               # ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator and
+                               # the PCI bus id of its device, gathered over the communicator (fpt_comm_info)
+                               rccl_ranks=(min(j["rccl_count"] for j in job) if job else None), ranks=job,
+                               distinct_devices=(len(set(j["pci_bus_id"] for j in job)) if job else None))
                           if (world > 1 or do_gather) else None),
             "cpu_baseline": base,
             "other_nb_mode": other,

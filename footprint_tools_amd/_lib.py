@@ -25,9 +25,16 @@ EXPORTS = [
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
-    "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize",
+    "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize", "fpt_comm_info",
     "fpt_stream_pattern_dev", "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
+
+
+class CommInfo(C.Structure):
+    """struct fpt_comm_info_t of include/fpt.h"""
+    _fields_ = [("world_size", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32),
+                ("rccl_count", C.c_int32), ("rccl_user_rank", C.c_int32), ("rccl_device", C.c_int32),
+                ("pci_bus_id", C.c_char * 32)]
 
 
 class ScanDesc(C.Structure):
@@ -175,6 +182,8 @@ def load():
             L.fpt_gather_track_async.argtypes = [vp, vp, vp, vp, vp, i32]
             L.fpt_comm_wait.argtypes = [vp, vp, i32]
             L.fpt_comm_synchronize.argtypes = [vp]
+        if hasattr(L, "fpt_comm_info"):
+            L.fpt_comm_info.argtypes = [vp, C.POINTER(CommInfo)]
         L.fpt_scan_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32 * 2)]
         L.fpt_synth_hotspots_dev.argtypes = [vp, C.c_uint64, i64, i64, i32, i32, vp, vp]
         L.fpt_checksum_dev.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
@@ -312,6 +321,8 @@ class Context(object):
                 self._dm_next += 1
                 for k in [k for k, v in self._dm_slots.items() if v == slot]:
                     del self._dm_slots[k]
+                for k in [k for k, f in self._dm_lists.items() if f <= slot < f + len(k)]:
+                    del self._dm_lists[k]
                 check(self.L.fpt_set_dispersion(self.h, slot, ptr(mu), ptr(r)))
                 self._dm_slots[key] = slot
                 self._slot_key[slot] = key
@@ -343,6 +354,10 @@ class Context(object):
                 self._dm_slots[key[i]] = slot
                 self._slot_key[slot] = key[i]
             self._dm_next = first + n
+            # lists that covered an overwritten slot are dead (their check above would fail for ever): dropped,
+            # so the cache holds at most what the 64 slots can vouch for
+            for k in [k for k, f in self._dm_lists.items() if f < first + n and first < f + len(k)]:
+                del self._dm_lists[k]
             self._dm_lists[key] = first
             return first
 

@@ -886,6 +886,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
                             (d->times >= 32 || c->fdr_slices_always);
     int64_t sl_n[kClasses + 1] = {}, sl_at[kClasses + 2] = {}, ghist_total = 0;
     size_t pin_goff = 0, pin_slice_iv = 0, pin_slice_start = 0, pin_bytes = 0;
+    int64_t total_host = -1;  // ragged batch: the track length, from whichever copy of the offsets was read
     if (d->interval_off) {
         if (d->n_intervals > 0x7fffff00) return fail(FPT_ERR_INVALID, "too many intervals");
         // interval lengths: from the caller's host copy of the offsets, else back from the device
@@ -898,6 +899,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
             off = off_back.data();
         }
         lmax = 0;
+        total_host = off[d->n_intervals];
         std::vector<uint8_t> cls((size_t)d->n_intervals);
         for (int64_t i = 0; i < d->n_intervals; ++i) {
             const int64_t L = off[i + 1] - off[i];
@@ -998,8 +1000,7 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
 #endif
     // the hand-over between the set-up launch and the draw launch (the `detect` width; FPT_FDR_SPLIT=0: one launch)
     if (d->half_win_width == 3 && c->fdr_split) {
-        const int64_t total = d->interval_off ? (d->interval_off_host ? d->interval_off_host[d->n_intervals] : -1)
-                                              : d->n_intervals * (int64_t)d->interval_len;
+        const int64_t total = d->interval_off ? total_host : d->n_intervals * (int64_t)d->interval_len;
         if (total > 0) {
             void *ws;
             const size_t key_b = ((size_t)total * 8 + 255) & ~(size_t)255, idx_b = ((size_t)total * 2 + 255) & ~(size_t)255;
@@ -1157,11 +1158,15 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     pl.ll_off_out = d->ll_off_out;
     pl.status_out = d->status_out;
     // tables of the unoccupied log-pmf and of lgam(k + 1), rebuilt by every call (slot 13)
+    // -- where they pay and fit: 65,536 evaluations and 512 KiB per dataset, so a batch of fewer than 16,384
+    // bases (the tables would cost more evaluations than they save), more than 4,096 datasets (2 GiB) or a
+    // failed allocation takes the direct path -- the same records (test_posterior_batch_fuzz)
     void *d_tab = nullptr;
-    if (!c->posterior_direct) {
-        if (int rc = ws_get(c, 13, fptk::posterior_table_bytes(d->n_datasets), &d_tab)) return rc;
-        pl.off_table = (double *)d_tab;
-        pl.lgam_table = pl.off_table + (size_t)d->n_datasets * 256 * 256;
+    if (!c->posterior_direct && d->total_bases >= 16384 && d->n_datasets <= 4096) {
+        if (ws_get(c, 13, fptk::posterior_table_bytes(d->n_datasets), &d_tab) == FPT_OK) {
+            pl.off_table = (double *)d_tab;
+            pl.lgam_table = pl.off_table + (size_t)d->n_datasets * 256 * 256;
+        }
     }
     HIP_TRY(fptk::launch_posterior(c->stream, pl));
     return launch_ok("k_posterior");

@@ -53,6 +53,10 @@ struct rccl_api {
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    // what the communicator itself says about the job (fpt_comm_info); optional symbols
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    int (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -94,6 +98,9 @@ rccl_api &api() {
         a.GroupStart = (int (*)())sym("ncclGroupStart");
         a.GroupEnd = (int (*)())sym("ncclGroupEnd");
         a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+        a.CommCount = (int (*)(const ncclComm_t, int *))dlsym(a.handle, "ncclCommCount");
+        a.CommUserRank = (int (*)(const ncclComm_t, int *))dlsym(a.handle, "ncclCommUserRank");
+        a.CommCuDevice = (int (*)(const ncclComm_t, int *))dlsym(a.handle, "ncclCommCuDevice");
     });
     return a;
 }
@@ -295,6 +302,23 @@ int fpt_comm_init(fpt_ctx *c, const uint8_t id[FPT_COMM_ID_BYTES], int world_siz
     k->comm = st->comm;
     k->device = device;
     *out = k;
+    return FPT_OK;
+}
+
+int fpt_comm_info(fpt_comm *k, fpt_comm_info_t *out) {
+    if (!k || !k->comm) return fpt_internal_fail(FPT_ERR_INVALID, "null communicator");
+    if (!out) return fpt_internal_fail(FPT_ERR_INVALID, "null output");
+    std::memset(out, 0, sizeof *out);
+    out->world_size = k->world;
+    out->rank = k->rank;
+    out->device = k->device;
+    out->rccl_count = out->rccl_user_rank = out->rccl_device = -1;
+    // asked of the communicator, not echoed from the arguments of fpt_comm_init: a job whose ranks
+    // ended up in communicators of their own (or on one device) shows here
+    if (api().CommCount) NCCL_TRY(api().CommCount(k->comm, &out->rccl_count));
+    if (api().CommUserRank) NCCL_TRY(api().CommUserRank(k->comm, &out->rccl_user_rank));
+    if (api().CommCuDevice) NCCL_TRY(api().CommCuDevice(k->comm, &out->rccl_device));
+    HIP_TRY_C(hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, k->device));
     return FPT_OK;
 }
 

@@ -64,15 +64,16 @@ __device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, do
     return ((lg_kr - lg_k1) - lg_r) + r * log(p) + (double)k * fptm::log1p_fn(-p);
 }
 
-__global__ void __launch_bounds__(256) k_posterior_tables(const double *__restrict__ models, int n_datasets,
+__global__ void __launch_bounds__(256) k_posterior_tables(const double *__restrict__ models, int n_datasets, int d0,
                                                           double *__restrict__ off_table, double *__restrict__ lgam_table) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.y == (unsigned)n_datasets) {  // the extra row of workgroups: lgam(k + 1)
+    const int d = d0 + (int)blockIdx.y;  // (a launch covers at most 32,768 datasets: gridDim.y is 16 bits)
+    if (d == n_datasets) {  // the extra row of workgroups: lgam(k + 1)
         if (i < kTabLgam) lgam_table[i] = fptm::lgam((double)(i + 1));
         return;
     }
     if (i >= kTabExp * kTabObs) return;
-    const double *mu9 = models + (size_t)blockIdx.y * 24, *r15 = mu9 + 9;
+    const double *mu9 = models + (size_t)d * 24, *r15 = mu9 + 9;
     const int32_t k = i % kTabObs;
     const double x = (double)(i / kTabObs);
     bool zd = false;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) k_posterior_tables(const double *__restri
     const double mu = fptm::fit_mu(mu9, x);
     const double p = r / (r + mu);
     const double v = nb_logpmf_terms(fptm::lgam((double)k + r), fptm::lgam((double)fptm::wrap_inc(k)), fptm::lgam(r), r, p, k);
-    off_table[(size_t)blockIdx.y * kTabExp * kTabObs + i] = zd ? __longlong_as_double(kTabDirectBits) : v;
+    off_table[(size_t)d * kTabExp * kTabObs + i] = zd ? __longlong_as_double(kTabDirectBits) : v;
 }
 
 // np.max(np.vstack([a, b]), axis=0) of two values: NaN wins (posterior.py:72)
@@ -114,12 +115,6 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     const double *par = staged ? par_lds : a.models;
     const double *beta = staged ? par_lds + (size_t)D * 24 : a.betas;
     const int tid = threadIdx.x;
-    if (staged) {
-        for (int i = tid; i < D * 24; i += NT) par_lds[i] = a.models[i];
-        for (int i = tid; i < D * 2; i += NT) par_lds[(size_t)D * 24 + i] = a.betas[i];
-        __syncthreads();
-    }
-
     const int64_t iv = blockIdx.x;
     int64_t off;
     int L;
@@ -132,6 +127,15 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     }
     const int64_t T = a.total_bases;
     const int TL = NT - 2 * hw;  // output bases per tile
+    // (gridDim.y comes from the LONGEST interval of the batch: a workgroup beyond this interval's tiles
+    // leaves before it stages anything -- the same for all of its lanes, so ahead of the barrier)
+    if ((int64_t)blockIdx.y * TL >= L) return;
+    if (staged) {
+        for (int i = tid; i < D * 24; i += NT) par_lds[i] = a.models[i];
+        for (int i = tid; i < D * 2; i += NT) par_lds[(size_t)D * 24 + i] = a.betas[i];
+        __syncthreads();
+    }
+
     bool zero_div = false;
     int round = 0;               // parity of the LDS buffer across tiles and datasets
     for (int t0 = blockIdx.y * TL; t0 < L; t0 += gridDim.y * TL) {
@@ -283,8 +287,11 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     a.off_table = pl.off_table;
     a.lgam_table = pl.lgam_table;
     if (pl.off_table && pl.lgam_table)
-        hipLaunchKernelGGL(k_posterior_tables, dim3(kTabExp * kTabObs / 256, pl.n_datasets + 1), dim3(256), 0, st, pl.models,
-                           pl.n_datasets, pl.off_table, pl.lgam_table);
+        for (int d0 = 0; d0 <= pl.n_datasets; d0 += 32768) {
+            const int ny = pl.n_datasets + 1 - d0 < 32768 ? pl.n_datasets + 1 - d0 : 32768;
+            hipLaunchKernelGGL(k_posterior_tables, dim3(kTabExp * kTabObs / 256, ny), dim3(256), 0, st, pl.models,
+                               pl.n_datasets, d0, pl.off_table, pl.lgam_table);
+        }
     // Batches of short intervals (the whole-genome hotspot set averages 162 bases) run one WAVEFRONT per
     // workgroup, which walks its interval in tiles of 64 - 2 hw bases: 162 + 6 positions fill 3 x 64 lanes
     // to 88 %, where one 256-lane tile was 66 % full (SQ_THREAD_CYCLES_VALU said 39 % of the lanes idle);

@@ -203,31 +203,34 @@ class TrackComm(object):
             pass
 
     # ---- the collective
+    def _counts(self, counts):
+        """one int64 count per rank, contiguous (the library reads counts[0 .. world) unconditionally)"""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if counts.ndim != 1 or counts.size != self.world:
+            raise ValueError("need one count per rank")
+        return counts
+
     def allgather_dev(self, send_ptr, counts, recv_ptr):
         """Enqueue the all-gather of a per-base track on the context's stream: rank r contributes
         counts[r] doubles at device pointer send_ptr, every rank receives sum(counts) doubles at
         recv_ptr in rank order.  Does not synchronise."""
-        counts = np.ascontiguousarray(counts, dtype=np.int64)
-        if counts.size != self.world:
-            raise ValueError("need one count per rank")
+        counts = self._counts(counts)
         _lib.check(self.L.fpt_allgather_track(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr))
 
     def gather_dev(self, send_ptr, counts, recv_ptr, root=0):
         """The same shards to ONE rank (the writer): recv_ptr is read on `root` only (None elsewhere)."""
-        counts = np.ascontiguousarray(counts, dtype=np.int64)
-        if counts.size != self.world:
-            raise ValueError("need one count per rank")
+        counts = self._counts(counts)
         _lib.check(self.L.fpt_gather_track(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr, int(root)))
 
     def allgather_dev_async(self, send_ptr, counts, recv_ptr):
         """allgather_dev on the communicator's own stream, behind what the context's stream holds now:
         the track of one batch travels while the next is scanned (into another buffer).  `wait` /
         `synchronize` before the buffers are touched again."""
-        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        counts = self._counts(counts)
         _lib.check(self.L.fpt_allgather_track_async(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr))
 
     def gather_dev_async(self, send_ptr, counts, recv_ptr, root=0):
-        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        counts = self._counts(counts)
         _lib.check(self.L.fpt_gather_track_async(self.ctx.h, self.h, send_ptr, counts.ctypes.data, recv_ptr, int(root)))
 
     def wait(self, back=0):
@@ -249,6 +252,35 @@ class TrackComm(object):
 
     def barrier(self):
         self.allgather_host(0.0)
+
+    def info(self):
+        """this rank as the communicator sees it: world / rank as given, what RCCL itself reports
+        (ncclCommCount, ncclCommUserRank, ncclCommCuDevice; -1 where the bound library lacks them),
+        the device ordinal and its PCI bus id"""
+        ci = _lib.CommInfo()
+        _lib.check(self.L.fpt_comm_info(self.h, C.byref(ci)))
+        return dict(world_size=ci.world_size, rank=ci.rank, device=ci.device, rccl_count=ci.rccl_count,
+                    rccl_user_rank=ci.rccl_user_rank, rccl_device=ci.rccl_device,
+                    pci_bus_id=ci.pci_bus_id.decode("ascii", "replace"))
+
+    def job_info(self):
+        """`info()` of every rank, in rank order, gathered over the communicator itself (four tiny
+        all-gathers: the bus id travels as its domain / bus / device / function numbers)"""
+        me = self.info()
+        try:
+            dom, bus, rest = me["pci_bus_id"].split(":")
+            dev, fn = rest.split(".")
+            bdf = (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
+        except ValueError:
+            bdf = -1
+        cols = [self.allgather_host(v) for v in (me["rccl_count"], me["rccl_user_rank"], me["rccl_device"], bdf)]
+        out = []
+        for r in range(self.world):
+            b = int(cols[3][r])
+            out.append(dict(rank=r, rccl_count=int(cols[0][r]), rccl_user_rank=int(cols[1][r]),
+                            device=int(cols[2][r]),
+                            pci_bus_id=("%04x:%02x:%02x.%x" % (b >> 16, (b >> 8) & 0xff, (b >> 3) & 0x1f, b & 7)) if b >= 0 else None))
+        return out
 
     def max_over_ranks(self, value):
         return max(self.allgather_host(value))

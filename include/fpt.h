@@ -319,7 +319,11 @@ typedef struct fpt_posterior_desc {
     const double *models;             /* optional HOST n_datasets x 24 (mu_params 9, r_params 15 per dataset): the
                                        * datasets' dispersion models handed over with the call instead of through
                                        * slots dm_id .. -- ANY number of datasets (cli/post.py:98-124 loops over
-                                       * however many samples the sample file lists; the slots hold 64) */
+                                       * however many samples the sample file lists; the slots hold 64), up to
+                                       * 2^20.  The call's tables of the unoccupied log-pmf (512 KiB per dataset,
+                                       * rebuilt per call) are used for up to 4,096 datasets and batches of 16,384
+                                       * bases or more; beyond that, or when they cannot be allocated, every value
+                                       * is evaluated in the kernel -- the same records */
 } fpt_posterior_desc;
 int fpt_posterior_dev(fpt_ctx *ctx, const fpt_posterior_desc *desc);
 
@@ -490,6 +494,17 @@ typedef struct fpt_comm fpt_comm;
 int fpt_comm_unique_id(uint8_t id_out[FPT_COMM_ID_BYTES]);
 int fpt_comm_init(fpt_ctx *ctx, const uint8_t id[FPT_COMM_ID_BYTES], int world_size, int rank, fpt_comm **out);
 int fpt_comm_destroy(fpt_comm *comm);
+/* What the communicator says about the job it belongs to: the arguments of fpt_comm_init beside what
+ * RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where the bound library
+ * lacks the symbol) and the PCI bus id of this rank's device.  A launcher's line can then prove that
+ * RCCL saw N ranks on N different devices (bench.py gathers these with the tiny all-gather).
+ * Reference counterpart: none (cli/detect.py:394 counts worker processes). */
+typedef struct fpt_comm_info_t {
+    int32_t world_size, rank, device;                   /* as given to fpt_comm_init / the context's device */
+    int32_t rccl_count, rccl_user_rank, rccl_device;    /* as RCCL reports them */
+    char pci_bus_id[32];                                /* "0000:05:00.0" */
+} fpt_comm_info_t;
+int fpt_comm_info(fpt_comm *comm, fpt_comm_info_t *out);
 /* counts[r] = doubles contributed by rank r (world_size entries, the same on every rank); send =
  * this rank's counts[rank] doubles, recv = sum(counts) doubles (device pointers; send may lie
  * inside recv at its own offset).  Equal counts: one ncclAllGather; ragged: one ncclBroadcast per

@@ -1,6 +1,6 @@
 // fakerccl.cpp -- TEST-ONLY stand-in for librccl.so: the entry points fpt_comm.cpp binds
 // (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclBroadcast, ncclSend, ncclRecv,
-// ncclGroupStart, ncclGroupEnd, ncclGetErrorString) implemented between PROCESSES THAT SHARE ONE GPU:
+// ncclGroupStart, ncclGroupEnd, ncclGetErrorString, ncclCommCount, ncclCommUserRank, ncclCommCuDevice) implemented between PROCESSES THAT SHARE ONE GPU:
 // a rendezvous in /dev/shm keyed by the unique id, device buffers handed over as HIP IPC handles, the
 // bytes moved with hipMemcpy.  RCCL refuses two ranks on one device, and a gpurun box has one: with
 // FPT_RCCL_LIB pointing here everything around the collective -- rank > 0 rendezvous, shard offsets,
@@ -229,6 +229,23 @@ int ncclCommDestroy(void *comm) {
     }
     delete c;
     return 0;
+}
+
+int ncclCommCount(void *comm, int *count) {
+    if (!comm || !count) return fail("ncclCommCount: null argument");
+    *count = ((comm_t *)comm)->world;
+    return 0;
+}
+
+int ncclCommUserRank(void *comm, int *rank) {
+    if (!comm || !rank) return fail("ncclCommUserRank: null argument");
+    *rank = ((comm_t *)comm)->rank;
+    return 0;
+}
+
+int ncclCommCuDevice(void *comm, int *device) {
+    if (!comm || !device) return fail("ncclCommCuDevice: null argument");
+    return hipGetDevice(device) == hipSuccess ? 0 : fail("hipGetDevice failed");
 }
 
 int ncclBroadcast(const void *send, void *recv, size_t count, int type, int root, void *comm, hipStream_t st) {

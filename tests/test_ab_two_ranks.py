@@ -61,6 +61,18 @@ def test_two_ranks_one_gpu_collectives(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_many_ranks_one_gpu_collectives(world):
+    """the same at N = 4 and 8 with ragged shards: shard-offset arithmetic with eight slices, the in-place
+    offsets, gathers to every root in turn, `wait(back=1)` with seven peers, and what the communicator
+    reports about the job (ncclCommCount / ncclCommUserRank per rank)"""
+    outs = _spawn([os.path.join(ROOT, "tests", "two_rank_worker.py")], world,
+                  {"FPT_TWO_RANK_SHAPE": "ragged", "FPT_TWO_RANK_INTERVALS": "1601"})
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and ("RANK %d OK" % r) in o, "rank %d: rc %d\n%s\n%s" % (r, rc, o[-1500:], e[-3000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("assembly", ["allgather", "gather"])
 def test_bench_two_ranks_one_gpu(assembly):
     """bench.py --gpus 2 end to end (config 4: ONE global ragged list cut in two, the track assembled):
@@ -78,3 +90,6 @@ def test_bench_two_ranks_one_gpu(assembly):
     mg = d["multi_gpu"]
     assert mg["assembly"] == assembly and mg["steps"] == 3
     assert mg["scan_only"]["value"] > 0 and mg["with_assembly"]["value"] > 0 and mg["with_assembly"]["overlapped"] is True
+    # the communicator's own account of the job: two ranks, each reporting itself
+    assert mg["rccl_ranks"] == 2 and [r_["rccl_user_rank"] for r_ in mg["ranks"]] == [0, 1]
+    assert all(r_["pci_bus_id"] for r_ in mg["ranks"])

@@ -30,7 +30,7 @@ def main():
     sc = FootprintScanner(g["table"], DM, hw, shw, clip, scales, ctx=ctx, nb_mode="memo")
     comm = TrackComm(ctx, rank, world, timeout_s=120.0)
 
-    n_iv = 3001
+    n_iv = int(os.environ.get("FPT_TWO_RANK_INTERVALS", "3001"))
     if ragged:
         lens = np.clip(np.random.RandomState(11).lognormal(4.9, 0.62, n_iv), 50, 2000).astype(np.int64)
     else:
@@ -121,6 +121,14 @@ def main():
     full = comm.allgather_rows(rows, sizes)
     assert np.array_equal(full[:, 0], want, equal_nan=True) and np.array_equal(full[:, 1], 2.0 * want, equal_nan=True)
     assert comm.max_over_ranks(float(rank)) == float(world - 1)
+    # 6. what the communicator itself reports about the job (ncclCommCount / ncclCommUserRank), gathered
+    me = comm.info()
+    assert me["world_size"] == world and me["rank"] == rank, me
+    assert me["rccl_count"] == world and me["rccl_user_rank"] == rank, me
+    assert len(me["pci_bus_id"].split(":")) == 3, me
+    job = comm.job_info()
+    assert [j["rccl_user_rank"] for j in job] == list(range(world)) and all(j["rccl_count"] == world for j in job), job
+    assert all(j["pci_bus_id"] == me["pci_bus_id"] for j in job), job  # (the ranks of this test share GPU 0)
     comm.barrier()
     comm.close()
     print("RANK %d OK %d intervals, shards %s" % (rank, n_iv, sizes), flush=True)
