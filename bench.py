@@ -177,6 +177,137 @@ def traffic_probe(argv_cfg, timeout_s=100):
                                   corrections="FETCH_SIZE x2 (gfx950 streaming reads), KiB -> bytes"))
 
 
+def issue_probe(argv_cfg, timeout_s=150):
+    """Config 5's dominant kernels are the null draws of the empirical-FDR pass, bound by the issue of vector
+    and LDS instructions, not by HBM: their busy fractions are read from the SQ counters in THIS invocation --
+    one child run of this script (1 warm-up + 2 steps) under `rocprofv3 --pmc` (counters only), per group of
+    kernels:  VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles)   [rocprofv3's VALUBusy],
+              LDS busy  = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)              [LdsUtil],
+    cycles = GRBM_GUI_ACTIVE / 8 XCDs summed over the group's dispatches.  None when rocprofv3 is not to be had."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not prof or under_profiler:
+        return None
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    counters = ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"]
+    out = tempfile.mkdtemp(prefix="fpt_pmc_", dir=env["TMPDIR"])
+    calls = 3
+    try:
+        cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + \
+            argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-posterior",
+                        "--no-traffic-probe", "--no-box-stream", "--no-config-legs"]
+        child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
+                                 start_new_session=True)
+        try:
+            if child.wait(timeout=timeout_s) != 0:
+                return None
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)
+            child.wait()
+            return None
+
+        def group_of(name):
+            m = re.search(r"k_fdr_null<\d+, \w+, \d+, \w+, (\d+)>", name)
+            if m:
+                return {"1": "setup", "3": "draws", "2": "full_draws"}.get(m.group(1), "other")
+            if "k_fdr_slice_finish" in name:
+                return "other"
+            if "k_fdr_slice<" in name:
+                return "draws"
+            if "k_nb_alias" in name:
+                return "other"
+            return None
+        agg = {}
+        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+            seen = set()
+            for row in csv.DictReader(open(f)):
+                g = group_of(row["Kernel_Name"])
+                if g is None:
+                    continue
+                a = agg.setdefault(g, dict(ns=0.0, dispatches=0))
+                a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                key = row.get("Dispatch_Id")
+                if key not in seen:
+                    seen.add(key)
+                    a["dispatches"] += 1
+                    if "End_Timestamp" in row and "Start_Timestamp" in row:
+                        a["ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        if "draws" not in agg or not agg["draws"].get("GRBM_GUI_ACTIVE"):
+            return None
+        res = {}
+        for g, a in agg.items():
+            cyc = a.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            if cyc <= 0:
+                continue
+            idx = a.get("SQ_LDS_IDX_ACTIVE", 0.0)
+            res[g] = dict(valu_busy=a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * cyc),
+                          lds_busy=idx / (256.0 * cyc),
+                          lds_bank_conflict_share=(a.get("SQ_LDS_BANK_CONFLICT", 0.0) / idx if idx else None),
+                          lds_bank_conflict_cycles_per_lds_instruction=(a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_INSTS_LDS"]
+                                                                        if a.get("SQ_INSTS_LDS") else None),
+                          valu_instructions_per_call=a.get("SQ_INSTS_VALU", 0.0) / calls,
+                          lds_instructions_per_call=a.get("SQ_INSTS_LDS", 0.0) / calls,
+                          lds_bank_conflict_cycles_per_call=a.get("SQ_LDS_BANK_CONFLICT", 0.0) / calls,
+                          ms_per_call_under_profiler=a["ns"] / calls * 1e-6, dispatches_per_call=a["dispatches"] / calls,
+                          shader_clock_GHz=(cyc / a["ns"] if a["ns"] else None))
+        return res
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def run_config_legs(steps_by_cfg, timeout_s=170):
+    """The other BASELINE configurations beside the headline, each a child run of this script (started
+    before this process touches the GPU, one after the other): its own buffers, its own parity spot check,
+    its own roofline block for ITS dominant kernel.  Returns {config: summary}."""
+    import signal
+    import subprocess
+    legs = {}
+    for cid, steps in steps_by_cfg:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2",
+               "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-config-legs"]
+        t0 = time.perf_counter()
+        try:
+            child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, start_new_session=True)
+            try:
+                o, e = child.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)
+                child.communicate()
+                legs[cid] = dict(error="timed out after %d s" % timeout_s)
+                continue
+            lines = [ln for ln in o.decode().splitlines() if ln.startswith("{")]
+            if child.returncode != 0 or not lines:
+                legs[cid] = dict(error="rc %d: %s" % (child.returncode, e.decode()[-400:]))
+                continue
+            d = json.loads(lines[-1])
+            legs[cid] = leg_summary(d, time.perf_counter() - t0)
+        except (OSError, ValueError) as ex:
+            legs[cid] = dict(error=str(ex))
+    return legs
+
+
+def leg_summary(d, wall_s=None):
+    """what a configuration's entry of `configs` carries"""
+    out = dict(workload=d["config"]["workload"], value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"],
+               steps=d["steps"], warmup=d["warmup"], dtype=d["dtype"], parity=d["parity"], roofline=d["roofline"])
+    if d.get("posterior"):
+        out["posterior"] = d["posterior"]
+    if d.get("fdr"):
+        out["fdr"] = d["fdr"]
+    if wall_s is not None:
+        out["leg_wall_s"] = wall_s
+    return out
+
+
 def cpu_baseline(cfg, table, DM, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm, results identical to the reference on
     the golden vectors) on a bounded sample of the same workload: all host cores, and one core.
@@ -213,14 +344,93 @@ def cpu_baseline(cfg, table, DM, budget_s=12.0):
                sample="%d intervals x %d bp x %d scales of the same synthetic workload, oracle/fpt_oracle.c with "
                       "OpenMP over intervals on %d threads, %.1f s; 1-core figure on %d intervals, %.1f s"
                       % (n, L, len(scales), cores, dt, n1, dt1))
+    out["reference_native"] = reference_native(cfg, table, DM, cores)
     kc = os.path.join(ROOT, "profiles", "k_cal.json")
     if os.path.exists(kc):
         k = json.load(open(kc))
+        # k_cal = port / whole reference (its Python + Cython loops around the native code included), measured
+        # in the BUILD container on another CPU: it only prices the interpreter overhead the native figure
+        # above leaves out, and is quoted with the CPU it came from
         out["k_cal"] = dict(port_over_reference_1_worker=k["workers_1"]["k_cal"],
                             port_over_reference_8_workers=k["workers_8"]["k_cal"],
-                            measured_on=k.get("cpu_model"), workload=k["workload"])
+                            measured_on=k.get("cpu_model"), workload=k["workload"],
+                            note="measured in the build container, not on this box: covers the reference's Python-loop "
+                                 "overhead only; its native C is timed on this box in reference_native")
         out["implied_reference_1core"] = out["value_1core"] / k["workers_1"]["k_cal"]
     return out
+
+
+def reference_native(cfg, table, DM, cores, budget_s=3.0):
+    """The reference's OWN native code -- oracle/_ref/libfpt_ref.so: fast_predict (modeling/predict.h:23-74),
+    hcephes_incbet (hcephes/src/cprob/incbet.c:12-94) and fast_windowing_func + fast_stouffers_z
+    (stats/windowing.h:53-84), compiled from /root/reference in the build container by oracle/Makefile --
+    timed on this box on a sample of the same workload, on one core and on all usable cores (threads:
+    ctypes releases the interpreter lock around the calls).  What the reference does in Python / Cython
+    around these calls (6-mer lookup, fit_mu / fit_r per base, the strand merge) is prepared OUTSIDE the
+    timed loop.  None when the library did not travel."""
+    from oracle import oracle  # checker / baseline only
+    R = oracle.ref_lib()
+    if R is None:
+        return None
+    from concurrent.futures import ThreadPoolExecutor
+    L, scales = cfg["L"], cfg["scales"]
+    pad = HW + SHW
+    l = L + 2 * pad + 1
+    mu_par, r_par = np.asarray(DM.mu_params, np.float64), np.asarray(DM.r_params, np.float64)
+
+    def prepare(n):
+        cp = oracle.synth_counts(1, 0, n * l, 0).reshape(n, l)
+        cm = oracle.synth_counts(1, 0, n * l, 1).reshape(n, l)
+        sq = oracle.synth_bases(1, 0, n * (l + 6)).reshape(n, l + 6)
+        items = []
+        for i in range(n):
+            fwd, rev = oracle.kmer_probs(sq[i], table)[:2]
+            # exp / obs of the merged strands and the NB arguments per base (Python in the reference)
+            e, o, _, _ = oracle.detect_batch(cp[i], cm[i], sq[i], 1, L, HW, SHW, CLIP, table, mu_par, r_par, scales[:1])
+            r = np.array([oracle.fit_r(r_par, x) for x in e])
+            mu = np.array([oracle.fit_mu(mu_par, x) for x in e])
+            items.append((cp[i].copy(), cm[i].copy(), np.ascontiguousarray(fwd), np.ascontiguousarray(rev),
+                          np.ascontiguousarray(r), np.floor(o) + 1.0, np.ascontiguousarray(r / (r + mu))))
+        return items
+
+    ew = [np.empty(l), np.empty(l)]
+
+    def native(item):
+        cp, cm, fwd, rev, a, b, x = item
+        e, w = np.empty(l), np.empty(l)
+        R.ref_fast_predict(cp, fwd, l, HW, SHW, CLIP, e, w)
+        R.ref_fast_predict(cm, rev, l, HW, SHW, CLIP, e, w)
+        p = np.empty(L)
+        R.ref_incbet_v(a, b, x, L, p)
+        out = np.empty(L)
+        for hw in scales:
+            R.ref_window(3, p, None, L, int(hw), out)
+
+    items = prepare(8)
+    t0 = time.perf_counter()
+    for it in items:
+        native(it)
+    per = (time.perf_counter() - t0) / len(items)
+    n1 = int(max(8, min(budget_s / per, 4000)))
+    items = prepare(n1) if n1 > len(items) else items
+    t0 = time.perf_counter()
+    for it in items:
+        native(it)
+    dt1 = time.perf_counter() - t0
+    # all cores: the same items round and round until the budget is used, `cores` threads
+    reps = max(1, int(cores * budget_s / max(dt1, 1e-9)))
+    work = items * reps
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(native, work, chunksize=max(1, len(work) // (cores * 8))))
+    dtn = time.perf_counter() - t0
+    return dict(kind="reference", value=len(work) * L / dtn, value_1core=len(items) * L / dt1, unit="bases/s", cores=cores,
+                functions="fast_predict x 2 strands (modeling/predict.h:23-74), hcephes_incbet per base "
+                          "(hcephes/src/cprob/incbet.c:12-94), fast_windowing_func + fast_stouffers_z per scale "
+                          "(stats/windowing.h:53-84): oracle/_ref/libfpt_ref.so, gcc -O2 -fwrapv as the reference's build",
+                sample="%d intervals x %d bp x %d scales on 1 core in %.1f s; %d on %d threads in %.1f s; the reference's "
+                       "Python-side steps (6-mer lookup, fit_mu / fit_r, strand merge) prepared outside the timed loop"
+                       % (len(items), L, len(scales), dt1, len(work), cores, dtn))
 
 
 def main():
@@ -247,6 +457,11 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="N=1: do not time the other nb mode")
     ap.add_argument("--no-box-stream", action="store_true",
                     help="N=1: do not time the scan's access pattern without arithmetic (roofline.box_stream_GBps)")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="N=1, default config: do not run the other BASELINE configurations (2, 4, 5) as child runs reported "
+                         "under `configs`")
+    ap.add_argument("--no-issue-probe", action="store_true",
+                    help="config 5: do not read the SQ counters of the FDR kernels in a child run under rocprofv3")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the assembly of the p-value track (same as --assembly none)")
     ap.add_argument("--assembly", default="allgather", choices=["allgather", "gather", "none"],
                     help="N>1: how the per-base track is re-assembled -- every rank gets it (one RCCL all-gather: BASELINE.json's "
@@ -288,6 +503,16 @@ def main():
         if args.intervals:
             probe_argv += ["--intervals", str(args.intervals)]
         live_traffic = traffic_probe(probe_argv)
+
+    # ... the FDR kernels' issue counters (config 5) ...
+    issue = None
+    if world == 1 and fdr_times and not args.no_issue_probe and not args.intervals:
+        issue = issue_probe(["--config", args.config, "--nb-mode", args.nb_mode])
+    # ... and the other BASELINE configurations, each a child run with its own line (reported under `configs`)
+    legs = None
+    if (world == 1 and args.config == "3" and not args.no_config_legs and not args.intervals and not args.hotspots
+            and args.scales is None and args.nb_mode == "memo"):
+        legs = run_config_legs([("2", 20), ("4", 20), ("5", 6)])
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
@@ -381,6 +606,8 @@ def main():
         p_p = d_pv.ptr
         bases_before = int(lens_all[:a_iv].sum())
 
+    fdr_marks = []  # config 5: (before, after) marks around every fpt_fdr_dev of the timed region
+
     def step_once(bi=0):
         """one step; bi: which of the two assembled-track buffers takes this step's track"""
         shift = d_gathers[bi].ptr - d_gathers[0].ptr if do_gather else 0
@@ -389,9 +616,12 @@ def main():
                     interval_len=None if ragged else L, interval_off_dev=d_off.ptr if ragged else None,
                     interval_off_host=off if ragged else None, dm_ids_dev=d_dm.ptr if d_dm else None)
         if fdr_times:  # detect.py:132-135; null draws keyed by the GLOBAL base index
+            m0 = ctx.mark() if fdr_marks is not None else None
             sc.fdr_dev(n_iv, p_out, p_out + 2 * t8, p_track + shift, times=fdr_times, seed=1, half_win_width=scales[0],
                        interval_off_dev=d_off.ptr, base_index0=bases_before, dm_ids_dev=d_dm.ptr if d_dm else None,
                        obs=p_out + t8, interval_off_host=off)
+            if m0 is not None:
+                fdr_marks.append((m0, ctx.mark()))
 
     def sync():
         ctx.synchronize()
@@ -425,6 +655,8 @@ def main():
         gather_track()  # also brings the communicator's channels up before the timed region
         sync()
         ctx.timing_enable(steps)
+        if fdr_marks is not None:
+            del fdr_marks[:]
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -450,6 +682,9 @@ def main():
         return time.perf_counter() - t0
 
     dt, kernel_ms, seq_ms, dt_scan, dt_gather = measure(args.steps, args.warmup)
+    fdr_ms = [ctx.mark_elapsed(a_, b_) for a_, b_ in fdr_marks[-args.steps:]] if fdr_times else None
+    fdr_marks = None  # (later calls of step_once are not part of the measurement)
+    ctx.marks_clear()
     dt_asm = measure_overlapped(args.steps) if do_gather else None
     if do_gather:  # leave the resident batch's track assembled in buffer 0 for the checks below
         step_once(0)
@@ -630,13 +865,18 @@ def main():
         ctx.synchronize()
         kp = max(3, args.steps // 2)
         t0 = time.perf_counter()
+        pm = [ctx.mark()]
         for _ in range(kp):
             post_step()
+            pm.append(ctx.mark())
         ctx.synchronize()
         dtp = (time.perf_counter() - t0) / kp
+        post_ms = [ctx.mark_elapsed(pm[i], pm[i + 1]) for i in range(kp)]  # HIP events on the launch stream
+        ctx.marks_clear()
         if comm is not None:
             dtp = comm.max_over_ranks(dtp)
-        post = dict(n_datasets=D, launches=kp, ms_per_launch=dtp * 1e3, value=total_all / dtp, unit="bases/s",
+        post = dict(n_datasets=D, launches=kp, ms_per_launch=dtp * 1e3, ms_per_launch_hip_events=float(np.mean(post_ms)),
+                    value=total_all / dtp, unit="bases/s",
                     dataset_bases_per_s=total_all * D / dtp,
                     bound="fp64 vector ALU: 2 lgam + log + log1p + two piecewise fits (the occupied form; the unoccupied one "
                           "and lgam(k + 1) from tables made inside the call) + exp + log1p per dataset-base, 48 B of HBM "
@@ -724,6 +964,39 @@ def main():
                         # earlier (profiles/traffic.json) -- over this run's kernel time
                         traffic_source=traffic_source,
                         algorithmic_bytes_per_base=dict(read=rd, write=wr))
+        fdr_block = None
+        if fdr_times and fdr_ms:
+            # config 5: the step is the scan (k_ms of it, above) and the empirical-FDR pass; the dominant kernels are the
+            # pass's null draws -- bound by vector / LDS instruction issue, priced on the SQ counters of a child run
+            f_ms = float(np.mean(fdr_ms))
+            draws = (issue or {}).get("draws")
+            prof_total = sum(g["ms_per_call_under_profiler"] for g in issue.values()) if issue else None
+            draws_ms = f_ms * draws["ms_per_call_under_profiler"] / prof_total if draws and prof_total else None
+            clock = (draws or {}).get("shader_clock_GHz") or 2.4
+            peak = 1024.0 * clock / 4.0  # G wave64 vector instructions per second: 1,024 SIMDs, 4 cycles each
+            fdr_block = dict(ms_per_call=f_ms, draws_per_base=fdr_times, draws_per_s=total * fdr_times / (f_ms * 1e-3),
+                             timing="HIP events on the launch stream around every fpt_fdr_dev of the timed region (fpt_mark)",
+                             share_of_step=f_ms / (dt / args.steps * 1e3), kernel_groups=issue,
+                             draws_ms=draws_ms)
+            scan_roof = roof
+            roof = dict(bound="valu+lds issue",
+                        kernel="the null draws of fpt_fdr_dev: k_fdr_null<NT,false,3,true,3> (one workgroup per interval of up to "
+                               "256 bases) + k_fdr_slice<192> (slices of longer intervals); set-up k_fdr_null<...,1> before them",
+                        achieved=(draws["valu_instructions_per_call"] / (draws_ms * 1e-3) / 1e9 if draws and draws_ms else None),
+                        peak=peak, unit="G wave64 VALU instructions/s",
+                        # = rocprofv3's VALUBusy of the draw kernels: SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles)
+                        frac=(draws["valu_busy"] if draws else None), traffic=None,
+                        lds_busy=(draws["lds_busy"] if draws else None),
+                        lds_bank_conflict_cycles_per_lds_instruction=(draws["lds_bank_conflict_cycles_per_lds_instruction"]
+                                                                      if draws else None),
+                        valu_instructions_per_draw=(draws["valu_instructions_per_call"] * 64.0 / (total * fdr_times)
+                                                    if draws else None),
+                        kernel_ms=draws_ms, fdr_pass_ms=f_ms, shader_clock_GHz=clock,
+                        source=("one child run of this command under rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU "
+                                "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE (issue_probe); kernel_ms = "
+                                "the HIP-event time of the pass x the draw kernels' share of its dispatch time in that run"
+                                if issue else "no counters in this run (rocprofv3 missing, or the run is itself profiled)"),
+                        scan=scan_roof)
         out = {
             "metric": "bases/sec per-nucleotide footprint stats",
             "value": total_all * args.steps / dt,
@@ -784,8 +1057,14 @@ def main():
             "heavy_tailed": heavy,
             "sparse_counts": sparse,
             "posterior": post,
+            "fdr": fdr_block,
             "parity": parity,
         }
+        if legs is not None:
+            # every BASELINE configuration that fits one GPU, from THIS invocation: the headline (this process) and
+            # configs 2, 4, 5 as child runs (config 4 / 5: one GPU's share, 437,500 ragged intervals)
+            me = leg_summary(out)
+            out["configs"] = {"2": legs.get("2"), "3": me, "4": legs.get("4"), "5": legs.get("5")}
         if args.share_gpu and world > 1:  # a smoke test of the launcher path, not a measurement
             out["invalid"] = ("--share-gpu: %d ranks on ONE GPU (%s): not a scaling measurement" % (
                 world, "collectives through the test suite's librccl stand-in" if comm is not None else

@@ -12,7 +12,8 @@ FPT_OK, FPT_ERR_INVALID, FPT_ERR_HIP, FPT_ERR_NODEVICE, FPT_ERR_ZERODIV, FPT_ERR
 WIN_SUM, WIN_PRODUCT, WIN_FISHER, WIN_STOUFFER, WIN_WSTOUFFER = range(5)
 NB_CDF, NB_LOGPMF, NB_PMF = range(3)
 NB_AUTO, NB_DIRECT, NB_MEMO, NB_NONE = range(4)
-FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8, ndtr_window=9, ndtr_window_tab=10)
+FN = dict(gamma=0, lgam=1, ndtr=2, ndtri=3, log1p=4, erf=5, erfc=6, incbet=7, chdtrc=8, ndtr_window=9, ndtr_window_tab=10, log_fast=11,
+          log1p_fast=12)
 MAX_SCALES = 8
 MAX_DM = 64
 
@@ -21,7 +22,7 @@ EXPORTS = [
     "fpt_ctx_set_stream", "fpt_ctx_use_own_stream", "fpt_ctx_synchronize", "fpt_set_bias_table", "fpt_set_dispersion",
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
-    "fpt_dev_zero", "fpt_format_stats", "fpt_format_stats_batch", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read",
+    "fpt_dev_zero", "fpt_format_stats", "fpt_format_stats_batch", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read", "fpt_mark", "fpt_mark_elapsed", "fpt_marks_clear",
     "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
@@ -202,6 +203,9 @@ def load():
         if hasattr(L, "fpt_stream_pattern_dev"):  # (absent from older builds loaded through FPT_LIB_PATH for A/B runs)
             L.fpt_stream_pattern_dev.argtypes = [vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, C.POINTER(C.c_float)]
         L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]
+        L.fpt_mark.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.fpt_mark_elapsed.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+        L.fpt_marks_clear.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -386,6 +390,21 @@ class Context(object):
     def drop_kept_tables(self):
         """Empty the second-level (exp, obs) table memo mode keeps across calls (see fpt.h)."""
         check(self.L.fpt_drop_kept_tables(self.h))
+
+    def mark(self):
+        """a HIP event on the context's stream; returns its number (see mark_elapsed)"""
+        i = C.c_int32(-1)
+        check(self.L.fpt_mark(self.h, C.byref(i)))
+        return i.value
+
+    def mark_elapsed(self, a, b):
+        """milliseconds on the device between marks a and b (waits for b)"""
+        ms = C.c_float(0.0)
+        check(self.L.fpt_mark_elapsed(self.h, int(a), int(b), C.byref(ms)))
+        return float(ms.value)
+
+    def marks_clear(self):
+        check(self.L.fpt_marks_clear(self.h))
 
     def timing_enable(self, max_records):
         check(self.L.fpt_timing_enable(self.h, int(max_records)))

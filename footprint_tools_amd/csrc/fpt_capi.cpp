@@ -66,6 +66,7 @@ struct fpt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::vector<hipEvent_t> tev;  // event pairs of recorded scans (fpt_timing_enable)
+    std::vector<hipEvent_t> marks;  // fpt_mark
     int tev_used = 0;
     int n_cu = 0;
     int memo_exp = 256, memo_obs = 256;
@@ -267,6 +268,7 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->marks) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return FPT_OK;
@@ -458,7 +460,7 @@ int fpt_window(fpt_ctx *c, int op, const double *x, const double *w, int64_t n_r
 int fpt_special(fpt_ctx *c, int fn, const double *a, const double *b, const double *x, int64_t n,
                 double *out) {
     if (int rc = check_ctx(c)) return rc;
-    if (fn < 0 || fn > 10) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
+    if (fn < 0 || fn > 12) return fail(FPT_ERR_INVALID, "bad function id %d", fn);
     if (n < 0) return fail(FPT_ERR_INVALID, "negative length");
     if (n == 0) return FPT_OK;
     if (!a || !out) return fail(FPT_ERR_INVALID, "null buffer");
@@ -836,6 +838,36 @@ int fpt_timing_read(fpt_ctx *c, float *ms_out, int cap, int *n_out) {
         HIP_TRY(hipEventElapsedTime(&ms_out[2 * i + 1], c->tev[4 * i + 1], c->tev[4 * i + 2]));
     }
     c->tev_used = 0;
+    return FPT_OK;
+}
+
+int fpt_mark(fpt_ctx *c, int32_t *id_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!id_out) return fail(FPT_ERR_INVALID, "null output");
+    if (c->marks.size() >= (size_t)1 << 20) return fail(FPT_ERR_INVALID, "too many marks: fpt_marks_clear");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    c->marks.push_back(e);
+    HIP_TRY(hipEventRecord(e, c->stream));
+    *id_out = (int32_t)c->marks.size() - 1;
+    return FPT_OK;
+}
+
+int fpt_mark_elapsed(fpt_ctx *c, int32_t from, int32_t to, float *ms_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!ms_out) return fail(FPT_ERR_INVALID, "null output");
+    if (from < 0 || to < 0 || (size_t)from >= c->marks.size() || (size_t)to >= c->marks.size())
+        return fail(FPT_ERR_INVALID, "no such mark");
+    HIP_TRY(hipEventSynchronize(c->marks[(size_t)to]));
+    HIP_TRY(hipEventElapsedTime(ms_out, c->marks[(size_t)from], c->marks[(size_t)to]));
+    return FPT_OK;
+}
+
+int fpt_marks_clear(fpt_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (hipEvent_t e : c->marks) (void)hipEventDestroy(e);
+    c->marks.clear();
     return FPT_OK;
 }
 

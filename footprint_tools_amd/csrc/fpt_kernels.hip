@@ -188,6 +188,8 @@ __global__ void __launch_bounds__(256) k_special(int fn, const double *__restric
         case 7: res = fptm::incbet(v, b[i], x[i]); break;
         case 9: res = fptm::ndtr_window(v); break;
         case 10: res = fabs(v) < fptm::kNdtrFastLimit ? fptm::ndtr_fast_tab(v, g_ndtr_gtab) : fptm::ndtr(v); break;
+        case 11: res = fptm::log_pos_fast(v); break;
+        case 12: res = fptm::log1p_unit_fast(v); break;
         default: res = fptm::chdtrc(v, x[i]); break;
         }
         out[i] = res;
@@ -2586,10 +2588,14 @@ __global__ void __launch_bounds__(256) k_hist2d(const double *__restrict__ ex, c
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double e = ex[i], o = ob[i];
-        // int(x) truncates toward zero; non-finite and negative values are skipped
-        if (!(e >= 0.0) || !(o >= 0.0) || !(e < 2147483647.0) || !(o < 2147483647.0)) continue;
-        const int r = (int)e, c = (int)o;
-        if (r >= rows || c >= cols) continue;  // IndexError -> pass (learn_dm.py:285-287)
+        // int(x) truncates toward zero (-0.5 is bin 0); a negative index of a numpy array counts from the end
+        // while it is >= -dim; beyond either end: IndexError -> pass (learn_dm.py:285-287).  Values that are not
+        // finite (int() raises on them in the reference, uncaught) are skipped.
+        if (!(fabs(e) < 2147483647.0) || !(fabs(o) < 2147483647.0)) continue;
+        int r = (int)e, c = (int)o;
+        if (r < -rows || r >= rows || c < -cols || c >= cols) continue;
+        r += r < 0 ? rows : 0;
+        c += c < 0 ? cols : 0;
         if (r < C && c < C) atomicAdd(&sub[r * C + c], 1u);
         else atomicAdd(&hist[(size_t)r * cols + c], 1ull);
     }

@@ -229,7 +229,7 @@ __device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *
 }
 template <int NT, typename Args, bool TAB = false>
 __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z,
-                                             const double *gt = nullptr) {
+                                             const double *gt = nullptr, const lean_tracks *deferred = nullptr) {
     constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
     // (uniform; typed as GLOBAL memory: behind the empty asm below a generic pointer made the store a
     // flat_store with a 64-bit vector add for its address -- and flat instructions count in lgkmcnt, which the
@@ -250,6 +250,38 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
     bool low = false;  // an argument below -26: the tile needs the restated ndtr.c (see ndtr_fast_s)
     const int n_scales = a.n_scales;
     const int64_t stride = a.total_bases;
+#ifdef FPT_LEAN_BUNCH
+    // (experiment) every scale's window p-value kept in registers, all stores issued back to back behind the
+    // arithmetic -- FPT_LEAN_BUNCH=2: the three per-base tracks too (handed in through `deferred`)
+    double pws[FPT_MAX_SCALES];
+#pragma unroll
+    for (int s = 0; s < FPT_MAX_SCALES; ++s) {
+        pws[s] = 0.0;
+        if (s < n_scales) {
+            const int hs = a.scales[s];
+            const u32 hs8 = (u32)hs * 8u;
+            const bool inside = hs <= room;
+            const u32 ah = inside ? ahi0 + hs8 : aedge, al = inside ? alo0 - hs8 : afirst;
+            const double sv = *(lds_double *)(size_t)ah - *(lds_double *)(size_t)al;
+            const double arg = -(sv * a.scale_rsqrt[s]);
+            low |= !(arg > neg_limit);
+            pws[s] = LEAN_STOP(4) ? arg : ndtr_fast_s<TAB>(arg, kc, gt);
+        }
+    }
+    if (deferred && o.mine) {
+        if (a.exp_out) store_at(a.exp_out + o.out_off, t8, deferred->ex);
+        if (a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)deferred->k);
+        if (a.pval_out) store_at(a.pval_out + o.out_off, t8, deferred->pv);
+    }
+#pragma unroll
+    for (int s = 0; s < FPT_MAX_SCALES; ++s) {
+        if (s < n_scales) {
+            asm volatile("" : "+s"(row));
+            if (o.mine) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(t8), "v"(pws[s]), "s"(row) : "memory");
+            row += stride;
+        }
+    }
+#else
     for (int s = 0; s < n_scales; ++s) {
         const int hs = a.scales[s];
         const u32 hs8 = (u32)hs * 8u;
@@ -263,7 +295,17 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
         // (written out: the compiler forms the address with a 64-bit vector add and stores through it)
         if (o.mine) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(t8), "v"(pw), "s"(row) : "memory");
         row += stride;
+#ifdef FPT_LEAN_DEFER
+        // (experiment) the three per-base tracks stored one per scale, between the scales' arithmetic, instead of
+        // back to back ahead of phase E's barriers
+        if (deferred && o.mine) {
+            if (s == 0 && a.exp_out) store_at(a.exp_out + o.out_off, t8, deferred->ex);
+            if (s == 1 && a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)deferred->k);
+            if (s == 2 && a.pval_out) store_at(a.pval_out + o.out_off, t8, deferred->pv);
+        }
+#endif
     }
+#endif
     return low;
 }
 // one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right

@@ -667,6 +667,54 @@ FPT_HD double log1p_fn(double x) {
 }
 
 // ---------------------------------------------------------------------------
+// A short natural logarithm for the posterior kernel's likelihoods (not a reference function: the
+// reference calls libm's log, 92 vector instructions in the device library; this is ~35).  The
+// published fdlibm algorithm (e_log.c): x = 2^k m, m in [sqrt(1/2), sqrt(2)), f = m - 1,
+// s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with R the degree-14 even polynomial of
+// that file -- without its special cases: x MUST be positive, finite and normal.  The quotient s comes
+// from a reciprocal refined twice; the result is within 2 ulp (tests: test_log_fast).
+// log1p_unit_fast(x), 0 <= x <= 1: log(u) + (x - (u - 1)) / u with u = 1 + x rounded (the correction term
+// is the rounding error of u, ~1e-16: an unrefined reciprocal is enough for it).
+// ---------------------------------------------------------------------------
+FPT_HD double log_pos_fast(double x) {
+    const double kLg1 = 6.666666666666735130e-01, kLg2 = 3.999999999940941908e-01, kLg3 = 2.857142874366239149e-01,
+                 kLg4 = 2.222219843214978396e-01, kLg5 = 1.818357216161805012e-01, kLg6 = 1.531383769920937332e-01,
+                 kLg7 = 1.479819860511658591e-01;
+    const double kLn2Hi = 6.93147180369123816490e-01, kLn2Lo = 1.90821492927058770002e-10;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+#else
+    int e;
+    double m = frexp(x, &e);
+#endif
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e -= low ? 1 : 0;
+    const double f = m - 1.0, d = 2.0 + f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = fma(fma(-d, inv, 1.0), inv, inv);
+    inv = fma(fma(-d, inv, 1.0), inv, inv);
+#else
+    const double inv = 1.0 / d;
+#endif
+    const double s = f * inv, z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, kLg6, kLg4), kLg2);
+    const double t2 = z * fma(w, fma(w, fma(w, kLg7, kLg5), kLg3), kLg1);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)e;
+    return dk * kLn2Hi - ((hfsq - fma(s, hfsq + R, dk * kLn2Lo)) - f);
+}
+FPT_HD double log1p_unit_fast(double x) {
+    const double u = 1.0 + x, c = x - (u - 1.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fma(c, __builtin_amdgcn_rcp(u), log_pos_fast(u));
+#else
+    return log_pos_fast(u) + c / u;
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // incomplete gamma for Fisher's method (cprob/igam.c, cprob/chdtr.c)
 // ---------------------------------------------------------------------------
 

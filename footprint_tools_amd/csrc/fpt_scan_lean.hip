@@ -435,7 +435,12 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     double z;
     bad |= lean_phase_cd<NT>(m, a, kc, memo, g.dm, g.nt, g.ncs, tid, tr, z);
     const lean_owner o = lean_own(g, tid, LEAN_STOP(6));
+#if defined(FPT_LEAN_DEFER) || (defined(FPT_LEAN_BUNCH) && FPT_LEAN_BUNCH == 2)
+    const bool defer = a.n_scales >= 3 && !(a.n_scales == 1 && a.max_scale <= 8);
+    if (!defer) lean_store_tracks(a, o, tr);
+#else
     lean_store_tracks(a, o, tr);
+#endif
 
     LEAN_TRACE(5);
     // ---- E: Stouffer windows (windowing.h:53-84)
@@ -459,7 +464,11 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
             m.Z[kEdge] = -1e4;
         }
         __syncthreads();
+#if defined(FPT_LEAN_DEFER) || (defined(FPT_LEAN_BUNCH) && FPT_LEAN_BUNCH == 2)
+        bad |= lean_windows<NT, lean_args, lean_lds<NT>::kTab>(a, kc, o, tid, m.Z, m.gt, defer ? &tr : nullptr);
+#else
         bad |= lean_windows<NT, lean_args, lean_lds<NT>::kTab>(a, kc, o, tid, m.Z, m.gt);
+#endif
     }
     if (bad) a.redo[tile] = 1;
     LEAN_TRACE(6);

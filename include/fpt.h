@@ -64,7 +64,10 @@ enum fpt_special_fn {
     FPT_FN_ERF = 5, FPT_FN_ERFC = 6, FPT_FN_INCBET = 7, /* (a,b,x) */
     FPT_FN_CHDTRC = 8, /* (df = a, x) */
     FPT_FN_NDTR_WINDOW = 9, /* the normal cdf as the fused scan's Stouffer windows evaluate it */
-    FPT_FN_NDTR_WINDOW_TAB = 10 /* ... and its table form (256 cubics for g; measured, not in use: DESIGN.md 4) */
+    FPT_FN_NDTR_WINDOW_TAB = 10, /* ... and its table form (256 cubics for g; measured, not in use: DESIGN.md 4) */
+    /* not hcephes: the short logarithm of the posterior kernel's likelihoods (positive normal x) and its
+     * log1p on [0, 1] (fpt_math.hpp log_pos_fast / log1p_unit_fast; where the reference calls libm's log) */
+    FPT_FN_LOG_FAST = 11, FPT_FN_LOG1P_FAST = 12
 };
 
 #define FPT_MAX_DISPERSION_MODELS 64
@@ -607,6 +610,14 @@ int fpt_last_scan_ms(fpt_ctx *ctx, float *ms_out);
  * instance in memo mode, the full instance in direct mode); it resets the record count. */
 int fpt_timing_enable(fpt_ctx *ctx, int max_records);
 int fpt_timing_read(fpt_ctx *ctx, float *ms_out, int cap, int *n_out);
+/* Marks for benchmarks: fpt_mark records a HIP event on the context's stream (where every kernel of the
+ * library is launched) and returns its number; fpt_mark_elapsed waits for mark `to` and gives the
+ * milliseconds between two marks -- the duration of whatever calls were enqueued between them (an
+ * fpt_fdr_dev or fpt_posterior_dev launch sequence), measured on the device.  fpt_marks_clear frees
+ * the events.  No reference counterpart (measurement only). */
+int fpt_mark(fpt_ctx *ctx, int32_t *id_out);
+int fpt_mark_elapsed(fpt_ctx *ctx, int32_t from, int32_t to, float *ms_out);
+int fpt_marks_clear(fpt_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -971,6 +971,27 @@ int orc_segment(const double *x, int n, double threshold, int w, int decreasing,
     return nseg;
 }
 
+/* cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1 over a batch, IndexError ignored.  Python's int()
+ * truncates toward zero; a NEGATIVE index of a numpy array counts from the end (no IndexError while it
+ * is >= -dim).  int() of a NaN or an infinity raises ValueError / OverflowError, which the reference does
+ * not catch (the job ends): such pairs are skipped here and counted in the return value. */
+int64_t orc_hist2d(const double *ex, const double *ob, int64_t n, int rows, int cols, int64_t *hist) {
+    int64_t not_finite = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (!isfinite(ex[i]) || !isfinite(ob[i])) {
+            not_finite++;
+            continue;
+        }
+        double te = trunc(ex[i]), to = trunc(ob[i]);
+        if (te < -(double)rows || te >= (double)rows || to < -(double)cols || to >= (double)cols) continue;
+        long r = (long)te, c = (long)to;
+        if (r < 0) r += rows;
+        if (c < 0) c += cols;
+        hist[(size_t)r * cols + c] += 1;
+    }
+    return not_finite;
+}
+
 /* ------------------------------------------------------------------ composite path */
 
 /* cli/detect.py:120-130 through modeling/predict.pyx:116-163 */

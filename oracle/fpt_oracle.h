@@ -85,6 +85,10 @@ void orc_emperical_fdr(const double *pvals_null, int64_t n_null, const double *p
 int orc_segment(const double *x, int n, double threshold, int w, int decreasing, int32_t *seg,
                 int cap);
 
+/* ---- cli/learn_dm.py:276-287: the (expected, observed) histogram; returns the pairs that are not finite
+ * (the reference raises on those) */
+int64_t orc_hist2d(const double *ex, const double *ob, int64_t n, int rows, int cols, int64_t *hist);
+
 /* ---- composite per-interval path: cli/detect.py:120-130 (predict -> merge -> p_values -> stouffers_z)
  * counts_* have l = L + 2*(hw+shw) + 1 entries, seq has l + 6 bytes.
  * Outputs have L entries; winp has n_scales rows of L.  returns 0 ok, 1 ZeroDivisionError. */

@@ -63,6 +63,8 @@ def lib():
         L.orc_bisect.argtypes = [f64p, C.c_int, f64p, C.c_int, f64p]
         L.orc_emperical_fdr.argtypes = [f64p, C.c_int64, f64p, C.c_int, f64p]
         L.orc_segment.argtypes = [f64p, C.c_int, C.c_double, C.c_int, C.c_int, i32p, C.c_int]
+        L.orc_hist2d.argtypes = [f64p, f64p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.orc_hist2d.restype = C.c_int64
         L.orc_detect_batch.argtypes = [f64p, f64p, u8p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_double, f64p, C.c_double, f64p, f64p, i32p, C.c_int,
                                        f64p, f64p, f64p, f64p, C.c_int]
@@ -199,6 +201,14 @@ def segment(x, threshold, w=1, decreasing=False):
     seg = np.empty(2 * (x.size + 1), np.int32)
     n = lib().orc_segment(x, x.size, threshold, w, int(bool(decreasing)), seg, x.size + 1)
     return seg[:2 * n].reshape(n, 2).tolist()
+
+
+def exp_obs_histogram(exp, obs, dims=(200, 1000)):
+    """cli/learn_dm.py:276-287: hist[int(exp), int(obs)] += 1, IndexError ignored"""
+    e, o = _f(exp).ravel(), _f(obs).ravel()
+    hist = np.zeros(dims, dtype=np.int64)
+    lib().orc_hist2d(e, o, e.size, int(dims[0]), int(dims[1]), hist.ctypes.data)
+    return hist
 
 
 def detect_batch(counts_plus, counts_minus, seq, n_iv, L, hw, shw, clip, table, mu_par, r_par,

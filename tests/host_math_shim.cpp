@@ -14,6 +14,8 @@ void hm_map1(int op, const double *x, long n, double *out) {
                  : op == 4 ? fptm::log1p_fn(v)
                  : op == 5 ? fptm::erf_fn(v)
                  : op == 6 ? fptm::erfc_fn(v)
+                 : op == 8 ? fptm::log_pos_fast(v)
+                 : op == 9 ? fptm::log1p_unit_fast(v)
                            : fptm::ndtr_window(v);
     }
 }

@@ -66,10 +66,21 @@ def test_many_ranks_one_gpu_collectives(world):
     """the same at N = 4 and 8 with ragged shards: shard-offset arithmetic with eight slices, the in-place
     offsets, gathers to every root in turn, `wait(back=1)` with seven peers, and what the communicator
     reports about the job (ncclCommCount / ncclCommUserRank per rank)"""
-    outs = _spawn([os.path.join(ROOT, "tests", "two_rank_worker.py")], world,
-                  {"FPT_TWO_RANK_SHAPE": "ragged", "FPT_TWO_RANK_INTERVALS": "1601"})
-    for r, (rc, o, e) in enumerate(outs):
-        assert rc == 0 and ("RANK %d OK" % r) in o, "rank %d: rc %d\n%s\n%s" % (r, rc, o[-1500:], e[-3000:])
+    bad = None
+    for attempt in range(2):
+        outs = _spawn([os.path.join(ROOT, "tests", "two_rank_worker.py")], world,
+                      {"FPT_TWO_RANK_SHAPE": "ragged", "FPT_TWO_RANK_INTERVALS": "1601"})
+        bad = ["rank %d: rc %d\n%s\n%s" % (r, rc, o[-300:], e[-700:]) for r, (rc, o, e) in enumerate(outs)
+               if rc != 0 or ("RANK %d OK" % r) not in o]
+        if not bad:
+            break
+        # One more try, and only for the stand-in's own rendezvous: eight processes opening each other's HIP IPC
+        # handles on one GPU have been seen to miss its 60 s barrier once (a test-infrastructure timeout, every
+        # rank's tail is printed); anything else -- a wrong track, a failed assertion -- fails at once
+        print("attempt %d failed:\n%s" % (attempt, "\n".join(bad)))
+        if not any("fakerccl" in b and "timed out" in b for b in bad):
+            break
+    assert not bad, "\n".join(bad)  # (every failing rank: the first to give up is rarely the one that went wrong)
 
 
 @pytest.mark.gpu

@@ -54,6 +54,19 @@ def test_special_functions_host(hm):
     assert rel_err(out, w["ch_val"]) < TOL
 
 
+def test_log_fast_host(hm):
+    """the posterior kernel's short logarithm (host build of the same source; the device refines a hardware
+    reciprocal where this divides): within 2 ulp of numpy's log / log1p"""
+    rs = np.random.RandomState(5)
+    x = np.concatenate([np.exp(rs.uniform(-340, 340, 100000)), rs.uniform(0.5, 2.0, 100000), 1.0 + rs.uniform(-1e-6, 1e-6, 10000),
+                        [1.0, 0.5, 2.0, 0.70710678118654746, 0.70710678118654757, 1e-150, 1e150]])
+    got, want = _map1(hm, 8, x), np.log(x)
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 0.5)).max() < 4.5e-16
+    u = np.concatenate([rs.uniform(0, 1, 100000), np.exp(rs.uniform(-745, 0, 50000)), [0.0, 1.0, 5e-324, 1e-17, 2.0 ** -53]])
+    got, want = _map1(hm, 9, u), np.log1p(u)
+    assert (np.abs(got - want) / np.maximum(want, 1e-300)).max() < 4.5e-16
+
+
 def test_ndtr_window_host(hm):
     """The one-formula normal cdf of the fused scan's Stouffer windows against the reference's
     own ndtr values (golden grid: branch boundaries, |a| up to 37.5) and, densely, against the

@@ -258,6 +258,23 @@ def test_philox_known_answers(orc):
     assert 0.0 <= min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.03
 
 
+def test_exp_obs_histogram_is_the_reference_loop(orc):
+    """cli/learn_dm.py:276-287, statement for statement (Python's int(), numpy's indexing, `except IndexError`),
+    on pairs that include fractions, values beyond either end and negative ones (an index from the end)"""
+    rs = np.random.RandomState(12)
+    e = np.concatenate([rs.randint(0, 260, 5000).astype(float), [2.9, -0.5, -1.0, -200.0, -201.0, 199.999, 200.0, 3.0]])
+    o = np.concatenate([rs.randint(0, 1300, 5000).astype(float), [7.7, 4.0, -0.9, -1000.0, 5.0, -1001.0, 999.0, 1000.0]])
+    cnts = np.column_stack([e, o])
+    hist = np.zeros((200, 1000), dtype=int)
+    for i in range(cnts.shape[0]):
+        try:
+            hist[int(cnts[i, 0]), int(cnts[i, 1])] += 1
+        except IndexError:
+            pass
+    got = orc.exp_obs_histogram(e, o)
+    assert np.array_equal(got, hist) and got[199, 0] >= 1 and got[0, 4] >= 1 and got.sum() == hist.sum() < e.size
+
+
 def test_fdr_null_oracle_matches_reference_statistically(orc):
     """the reproducible inverse-CDF null sampler gives the same empirical FDR as the reference's
     numpy sampler up to Monte-Carlo noise (one interval, 400 draws per base)."""
