@@ -272,7 +272,8 @@ def run_config_legs(steps_by_cfg, timeout_s=170):
     import subprocess
     legs = {}
     for cid, steps in steps_by_cfg:
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2",
+        # (a 1 - 2 ms step rides on the clock's ramp: ten untimed steps first; config 5's 30 ms steps need two)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2" if cid == "5" else "10",
                "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-config-legs"]
         t0 = time.perf_counter()
         try:
@@ -512,7 +513,7 @@ def main():
     legs = None
     if (world == 1 and args.config == "3" and not args.no_config_legs and not args.intervals and not args.hotspots
             and args.scales is None and args.nb_mode == "memo"):
-        legs = run_config_legs([("2", 20), ("4", 20), ("5", 6)])
+        legs = run_config_legs([("2", 40), ("4", 40), ("5", 6)])
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals

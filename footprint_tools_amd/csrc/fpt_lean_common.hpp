@@ -55,6 +55,7 @@ struct lean_args {
     const double2 *memo2;
     const int32_t *memo2_have;
     const int32_t *dm_ids;
+    int32_t prefetch;  // > 0: a workgroup touches the input rows of the tile this many places after its own (see lean_prefetch)
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
     int64_t *trace;  // -DFPT_ABLATE builds: per-workgroup timestamps (FPT_LEAN_TRACE)
     lean_coef c;
@@ -360,6 +361,7 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.memo2 = (const double2 *)sl.memo2;
     a.memo2_have = sl.memo2_have;
     a.dm_ids = sl.dm_ids;
+    a.prefetch = 0;
     a.stop = sl.ablate;
     a.trace = nullptr;
     const double g[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST}, e[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};

@@ -86,10 +86,13 @@ __device__ __forceinline__ double nb_logpmf_any(double r, double mu, int32_t k, 
         inv = fma(fma(-d, inv, 1.0), inv, inv);
         const double p = r * inv, q = mu * inv, c = r * q;
         double prod = 1.0, fj = 0.0;
-        for (int j = 0; j < k; ++j) {  // (r + j) q = fma(j, q, r q)
-            prod *= fma(fj, q, c);
-            fj += 1.0;
+        int j = 0;
+        for (; j + 1 < k; j += 2) {  // two factors a trip: (r + j) q = fma(j, q, r q), and the next one is that + q
+            const double t = fma(fj, q, c);
+            prod *= t * (t + q);
+            fj += 2.0;
         }
+        if (j < k) prod *= fma(fj, q, c);
         // (the product lies in [1e-150, 1e150] and p in [1e-15, 1): normal positive numbers, what log_pos_fast asks for)
         return (fptm::log_pos_fast(prod) - lg_k1) + r * fptm::log_pos_fast(p);
     }
@@ -184,17 +187,26 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                 const double f = a.fdr[j], ww = a.w[j], o = a.obs[j], e = a.exp[j];
                 if (f <= a.cutoff) k_called += 1.0;
                 n_cov += ww;
-                // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean and variance
+                // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean a / s and variance a b / (s^2 (s + 1)),
+                // s = a + b, by the reference's own operations -- delta = sum(w mu) / sum(w) must come out as the
+                // reference's to the bit: with one dataset called it is exactly that dataset's mean (w mu / w), often
+                // a short fraction, and exp x delta then falls ON a breakpoint of the piecewise dispersion fits,
+                // which jump there (a closed form one division shorter moved delta by an ulp and the posterior by
+                // 1e-2: test_posterior_driver_against_the_reference_driver).  What IS left out: a dataset that is not
+                // called here (fdr above the cutoff: weight 0) adds exactly nothing, so its three divisions and
+                // square root are skipped.  scipy returns NaN outside the domain, and 0 x NaN stays NaN
+                // (posterior.py:72-88)
                 const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
-                double mu = NAN, var = NAN;  // scipy returns NaN for arguments outside the domain
-                if (al > 0.0 && be > 0.0) {
-                    const double s = al + be;
-                    mu = al / s;
-                    var = al * be / ((s * s) * (s + 1.0));
+                double wt = 0.0, wm = 0.0;
+                if (!(al > 0.0 && be > 0.0)) {
+                    wm = NAN;
+                    wt = f > a.cutoff ? 0.0 : NAN;
+                } else if (!(f > a.cutoff)) {
+                    const double s = al + be, mu = al / s, var = al * be / ((s * s) * (s + 1.0));
+                    wt = 1.0 / sqrt(var);
+                    wm = wt * mu;
                 }
-                double wt = 1.0 / sqrt(var);
-                if (f > a.cutoff) wt = 0.0;
-                swm += wt * mu;
+                swm += wm;
                 sw += wt;
             }
             const double unocc = n_cov - k_called + a.pseudocount, occ = k_called + a.pseudocount;
@@ -224,8 +236,12 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     v_off = a.off_table[((size_t)d * kTabExp + ei) * kTabObs + k];
                     need_off = __double_as_longlong(v_off) == kTabDirectBits;
                 }
+                // delta is exactly 1 wherever no dataset is called at the base (most of a real track): the occupied
+                // form is then the unoccupied one, value for value -- the same expression on the same arguments
+                const bool same = delta == 1.0 && !need_off;
+                if (same) v_on = v_off;
                 FPT_NOUNROLL
-                for (int s = 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
+                for (int s = same ? 2 : 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
                     if (s == 1 && !need_off) break;
                     const double x = s == 0 ? e * delta : e;
                     const double r = fptm::fit_r(r15, x, &zero_div);

@@ -173,6 +173,29 @@ __device__ __forceinline__ void lean_load(const lean_tile &g, int tid, lean_inpu
     }
 }
 
+// The input rows of a LATER tile pulled into the L2 of this XCD: one byte per 128-byte line of its two count rows
+// and its sequence row -- a single load instruction for an interval of up to ~1,000 bases.  A workgroup of a
+// short interval lives ~7 us, 2.6 of them waiting for its inputs to come from HBM; the tile
+// `a.prefetch` places on (a multiple of 8: workgroups go round the 8 XCDs) starts about one generation of
+// resident workgroups later, on the same XCD, and finds them in its L2.  The value is consumed by the
+// caller at the very end of the kernel, so the wait for it sits behind everything else.
+template <int NT>
+__device__ __forceinline__ u32 lean_prefetch(const lean_tile &g2, int tid) {
+    u32 acc = 0;
+    const char *rows[3] = {(const char *)g2.gcp, (const char *)g2.gcm, (const char *)g2.gsq};
+    const int bytes[3] = {g2.nc * 8, g2.nc * 8, g2.nc + 6};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const size_t p = (size_t)rows[r], a0 = p & ~(size_t)127;
+        const int n_lines = (int)((p + (size_t)bytes[r] - a0 + 127) >> 7);
+        for (int i = tid; i < n_lines; i += NT) {
+            const size_t at = a0 + ((size_t)i << 7);
+            acc += *(const uint8_t *)(at < p ? p : at);  // (the first line's byte: the row's own first one)
+        }
+    }
+    return acc;
+}
+
 // phase A of one tile: counts -> packed 16-bit integers, sequence -> two bit planes (LDS).
 // Returns true if this lane saw an input outside the case the kernel handles.
 template <int NT>
@@ -225,7 +248,7 @@ struct lean_mem {
 // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums.
 // Returns true where an aligned row of 16 equal non-zero window sums shows up (see the header).
 template <int NT>
-__device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double2 *table2, int ncs, int tid) {
+__device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double2 *table2, int ncs, int nt, int tid) {
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     bool bad = false;
     // the table gathers of both of a lane's positions go out first: one trip to L2 instead of two
@@ -235,10 +258,17 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
     for (int i = 0; i < 2; ++i) {
         if (i * NT + wave * kWave >= ncs) break;
         const int v = i * NT + tid;
-        const int w32 = v >> 5, sh = v & 31;
-        const u32 f0 = __builtin_amdgcn_alignbit(m.bits0[w32 + 1], m.bits0[w32], sh) & 63u;
-        const u32 f1 = __builtin_amdgcn_alignbit(m.bits1[w32 + 1], m.bits1[w32], sh) & 63u;
-        tt[i] = table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+        // The propensities are read by phase C at the positions [pad + 1 - hw, pad + nt + hw] only -- the 2 hw window
+        // of every base that gets a value -- while the positions beyond them, the 50 either side that only the
+        // smoothing window reaches, are needed as COUNTS: their 16-byte gathers (the dearest instruction of the
+        // vector-memory path: 40 cycles of the CU each, tools/micro/vmem_issue.hip) are left out
+        tt[i] = make_double2(0.0, 0.0);
+        if (v >= kPad + 1 - kHW && v <= kPad + nt + kHW) {
+            const int w32 = v >> 5, sh = v & 31;
+            const u32 f0 = __builtin_amdgcn_alignbit(m.bits0[w32 + 1], m.bits0[w32], sh) & 63u;
+            const u32 f1 = __builtin_amdgcn_alignbit(m.bits1[w32 + 1], m.bits1[w32], sh) & 63u;
+            tt[i] = table2[f0 | (f1 << 6)];  // (P+[v], P-[v-1]); consumed at the end of the iteration
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -418,6 +448,9 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
     lean_inputs in;
     lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    u32 touched = 0;  // (behind the tile's own loads: the memory counter is in order, and these are not waited for)
+    if (a.prefetch > 0 && blockIdx.x + (unsigned)a.prefetch < gridDim.x)
+        touched = lean_prefetch<NT>(lean_geometry(a, tile + a.prefetch), tid);
     if (lean_lds<NT>::kTab && a.n_scales > 1)  // (read four barriers from here)
         for (int i = tid; i < 4 * FPT_NDTR_GTAB_N; i += NT) m.gt[i] = g_lean_gtab[i] * kc->inv_g0;
     bool bad = lean_stage<NT>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
@@ -426,7 +459,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     LEAN_TRACE(3);
     if (LEAN_STOP(1)) return;
 
-    bad |= lean_phase_b<NT>(m, a.table2, g.ncs, tid);
+    bad |= lean_phase_b<NT>(m, a.table2, g.ncs, g.nt, tid);
     __syncthreads();
     LEAN_TRACE(4);
     if (LEAN_STOP(2)) return;
@@ -471,6 +504,7 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
 #endif
     }
     if (bad) a.redo[tile] = 1;
+    if (touched == 0xffffffffu) a.redo[tile] = 1;  // (never: 1,024 lanes x 3 rows x 255; keeps the touching loads alive)
     LEAN_TRACE(6);
 }
 
@@ -523,6 +557,14 @@ bool scan_lean_applies(const scan_launch &sl) {
 void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     lean_args a;
     fill_lean_args(sl, a);
+    // FPT_LEAN_PREFETCH=<f>: the touching distance as a multiple of the workgroups resident on the device
+    // (by wavefront slots and LDS), rounded to the 8 XCDs; unset / 0: off
+    static const double pf = getenv("FPT_LEAN_PREFETCH") ? atof(getenv("FPT_LEAN_PREFETCH")) : 0.0;
+    if (pf > 0.0) {
+        const int by_waves = 32 / (nt / 64), by_lds = (int)(160 * 1024 / scan_lean_lds_bytes(nt));
+        const int resident = (sl.n_cu > 0 ? sl.n_cu : 256) * (by_waves < by_lds ? by_waves : by_lds);
+        a.prefetch = ((int)(pf * resident) + 7) & ~7;
+    }
 #ifdef FPT_ABLATE
     static int64_t *d_trace = nullptr;
     const char *trace_path = getenv("FPT_LEAN_TRACE");

@@ -52,11 +52,17 @@ struct op_t {
     hipStream_t stream;
 };
 
+struct opened_t {  // a peer's allocation mapped into this process (kept until the communicator goes)
+    hipIpcMemHandle_t handle;
+    void *base;
+};
+
 struct comm_t {
     int world = 1, rank = 0;
     shared_t *sh = nullptr;
     std::string path;
     std::vector<op_t> ops;
+    std::vector<opened_t> opened;
 };
 
 thread_local int g_group_depth = 0;
@@ -108,13 +114,32 @@ bool offer(comm_t *c, int i, const void *p, size_t bytes, int peer) {
     return true;
 }
 
+// A peer's allocation is mapped ONCE and stays mapped: a barrier of the job is a tiny all-gather, and opening and
+// closing seven handles for each of them -- with the copy possibly still in flight when the handle was closed: a
+// device-to-device hipMemcpy need not have finished when it returns -- made ranks fail to open a handle now and
+// then ("cannot read a broadcast source of another rank", the others then waiting out the barrier's 60 s).
 bool take(comm_t *c, int from, int i, void *dst, size_t bytes) {
     const slot_t &sl = c->sh->slots[from][i];
     if (!sl.valid || sl.bytes != bytes) return false;
     void *base = nullptr;
-    if (hipIpcOpenMemHandle(&base, sl.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return false;
-    const hipError_t e = hipMemcpy(dst, (const char *)base + sl.offset, bytes, hipMemcpyDeviceToDevice);
-    (void)hipIpcCloseMemHandle(base);
+    for (const opened_t &o : c->opened)
+        if (memcmp(&o.handle, &sl.handle, sizeof sl.handle) == 0) base = o.base;
+    if (!base) {
+        hipError_t e = hipIpcOpenMemHandle(&base, sl.handle, hipIpcMemLazyEnablePeerAccess);
+        for (int tries = 0; e != hipSuccess && tries < 50; ++tries) {  // (the exporter may be busy in the driver)
+            (void)hipGetLastError();
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            e = hipIpcOpenMemHandle(&base, sl.handle, hipIpcMemLazyEnablePeerAccess);
+        }
+        if (e != hipSuccess) {
+            fprintf(stderr, "fakerccl: hipIpcOpenMemHandle (rank %d reading rank %d): %s\n", c->rank, from, hipGetErrorString(e));
+            return false;
+        }
+        c->opened.push_back(opened_t{sl.handle, base});
+    }
+    hipError_t e = hipMemcpy(dst, (const char *)base + sl.offset, bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // the copy is done before anybody is told so
+    if (e != hipSuccess) fprintf(stderr, "fakerccl: copy from rank %d failed: %s\n", from, hipGetErrorString(e));
     return e == hipSuccess;
 }
 
@@ -223,6 +248,7 @@ int ncclCommInitRank(void **comm_out, int nranks, ncclUniqueId_ id, int rank) {
 int ncclCommDestroy(void *comm) {
     comm_t *c = (comm_t *)comm;
     if (!c) return 0;
+    for (const opened_t &o : c->opened) (void)hipIpcCloseMemHandle(o.base);
     if (c->sh) {
         if (c->sh->left.fetch_add(1) + 1 == c->world) unlink(c->path.c_str());
         munmap(c->sh, sizeof(shared_t));

@@ -285,6 +285,47 @@ def test_piecewise_fit():
     assert g.x_data[0] == 0.0 and g.n_segments == 3
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_piecewise_fit_properties_on_noisy_data(seed):
+    """pwlf cannot be had here (absent from /root/reference and from the image), so the fitter is pinned by what
+    the published method guarantees, on noisy data and through the calls the reference makes
+    (dispersion.pyx:446-458): `optimize.minimize(fit.fit_with_breaks_opt, guess)` recovers the interior
+    breakpoints of a continuous piecewise-linear truth within a tolerance the noise sets; the fitted curve is
+    CONTINUOUS at every breakpoint; its residual sum of squares is not above that of the true curve; a forced
+    point is met; the objective does not depend on the order of the interior breakpoints."""
+    from scipy import optimize
+    from footprint_tools_amd.modeling.piecewise import PiecewiseLinFit
+    rs = np.random.RandomState(seed)
+    breaks = np.array([0.0, 3.0 + rs.uniform(0, 1), 8.0 + rs.uniform(0, 2), 16.0 + rs.uniform(0, 3), 26.0 + rs.uniform(0, 3), 60.0])
+    slopes = np.array([0.06, 0.02, 0.008, 0.003, 0.001]) * (1 + 0.2 * rs.uniform(-1, 1, 5))
+    knots = np.concatenate([[0.05], 0.05 + np.cumsum(slopes * np.diff(breaks))])
+    x = np.arange(0.0, 60.5, 0.5)
+    truth = np.interp(x, breaks, knots)
+    sigma = 2e-3
+    y = truth + rs.normal(0, sigma, x.size)
+    f = PiecewiseLinFit(x, y)
+    res = optimize.minimize(f.fit_with_breaks_opt, [3.0, 7.0, 15.0, 25.0])  # the reference's call and its guess
+    got = np.sort(res.x)
+    # a kink of slope change d is located to about sigma / d x (a few points): the sharp ones well, the faint ones loosely
+    kink = np.abs(np.diff(slopes))
+    tol = np.maximum(1.0, 12.0 * sigma / kink)
+    assert np.all(np.abs(got - breaks[1:-1]) < tol), (got, breaks[1:-1], tol)
+    full = np.concatenate([[x[0]], got, [x[-1]]])
+    f.fit_with_breaks(full)
+    true_ssr = float(((truth - y) ** 2).sum())
+    assert f.ssr <= true_ssr * (1 + 1e-9)            # least squares over a family that holds the truth (up to its breaks)
+    assert f.ssr > 0.5 * true_ssr                    # ... and no over-fit: ten parameters on 121 points
+    for c in got:                                    # continuity: both one-sided limits agree at every breakpoint
+        lo, hi = f.predict(np.array([c - 1e-9]))[0], f.predict(np.array([c + 1e-9]))[0]
+        assert abs(lo - hi) < 1e-7
+    seg_val = f.intercepts + f.slopes * full[:-1]    # ... and the per-segment lines the model stores meet there too
+    assert np.allclose(seg_val[1:], f.intercepts[:-1] + f.slopes[:-1] * full[1:-1], atol=1e-9)
+    assert np.allclose(f.slopes, slopes, atol=8 * sigma)
+    assert abs(f.fit_with_breaks_opt(got) - f.fit_with_breaks_opt(got[::-1])) < 1e-15
+    f.fit_with_breaks_force_points(full, [1.0], [y[2]])   # dispersion.pyx:458 forces the point at x = 1
+    assert abs(f.predict(np.array([1.0]))[0] - y[2]) < 1e-12 and f.ssr >= true_ssr * 0.5
+
+
 def test_learn_dispersion_model_recovers_truth():
     """histogram simulated from a known mu(x), r(x) -> learn_dispersion_model -> the model
     reproduces them (dispersion.pyx:357-469 flow with the pwlf-free fitter)."""

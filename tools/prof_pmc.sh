@@ -10,7 +10,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-30)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-probe "$@" > $OUT/$name.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-probe --no-config-legs --no-issue-probe "$@" > $OUT/$name.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, re

@@ -7,7 +7,7 @@
 # 3. a text summary                                           -> gpurun_out/prof_<tag>/summary.txt
 set -u
 TAG=${1:-r01}; shift || true
-ARGS="--no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy $@"
+ARGS="--no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy --no-config-legs --no-issue-probe $@"
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
