@@ -144,7 +144,7 @@ def traffic_probe(argv_cfg, timeout_s=100):
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row["Kernel_Name"]
-                    if row["Counter_Name"] == counter and ("scan_lean" in name or "scan_fused" in name or "scan_wave" in name):
+                    if row["Counter_Name"] == counter and ("scan_lean" in name or "scan_fused" in name):
                         key = (name, int(row.get("Dispatch_Id", 0) or 0))
                         per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
                         if "End_Timestamp" in row and "Start_Timestamp" in row:
@@ -272,8 +272,9 @@ def run_config_legs(steps_by_cfg, timeout_s=170):
     import subprocess
     legs = {}
     for cid, steps in steps_by_cfg:
-        # (a 1 - 2 ms step rides on the clock's ramp: ten untimed steps first; config 5's 30 ms steps need two)
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2" if cid == "5" else "10",
+        # (a 1 - 2 ms step rides on the clock's ramp out of idle -- the same leg gave 1.8 to 2.5 ms with ten untimed
+        # steps: a quarter of a second of them first; config 5's 30 ms steps need two)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2" if cid == "5" else "150",
                "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-config-legs"]
         t0 = time.perf_counter()
         try:
@@ -513,7 +514,7 @@ def main():
     legs = None
     if (world == 1 and args.config == "3" and not args.no_config_legs and not args.intervals and not args.hotspots
             and args.scales is None and args.nb_mode == "memo"):
-        legs = run_config_legs([("2", 40), ("4", 40), ("5", 6)])
+        legs = run_config_legs([("2", 100), ("4", 100), ("5", 6)])
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
@@ -946,7 +947,7 @@ def main():
                         # north_star's wording is the HBM-READ roofline: the same launch priced on
                         # its algorithmic read bytes only (frac above counts reads + writes)
                         achieved_read=achieved_read, frac_read=achieved_read / HBM_PEAK_GBS,
-                        kernel=("k_scan_lean<NT> (first pass of the step; tiles outside its case are redone by "
+                        kernel=("k_scan_lean<NT, BPL> (first pass of the step; tiles outside its case are redone by "
                                 "k_scan_fused<NT,5,50,table=L2,full>)"
                                 if args.nb_mode == "memo" else "k_scan_fused<NT,HW,SHW,table=L2,full>"),
                         # the same loads and stores with no arithmetic between them, on this box, in this

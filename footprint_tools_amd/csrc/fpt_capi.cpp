@@ -95,10 +95,8 @@ struct fpt_ctx {
     bool fdr_slices = true;   // ... and, in ragged batches, intervals of more than 256 bases drawn as slices (FPT_FDR_SLICES=0: one workgroup each)
     bool fdr_light_dbuf = false;  // the light instance with two sets of z buffers (FPT_FDR_LIGHT_DBUF=1)
     bool use_lean = true;  // first pass of memo mode by k_scan_lean (FPT_SCAN_LEAN=0: the general memo-only instance)
-    // size classes of a batch's tiles; FPT_SCAN_WAVE = 4 / 5 / 6 (read at creation): whole intervals of up to
-    // 139 / 203 / 267 bases go to the one-wavefront-per-interval kernel (fpt_scan_wave.hip).  Off by
-    // default: measured level with k_scan_lean's 128- and 192-lane classes, not ahead of them
-    fptk::lean_class_set classes = fptk::make_lean_classes(0);
+    // size classes of a batch's tiles (k_scan_lean's workgroup sizes)
+    fptk::lean_class_set classes = fptk::make_lean_classes();
     bool table_lds = false;  // general kernel: bias table staged in LDS per workgroup (FPT_TABLE_LDS=1), read at creation
     // The null sampler's table reaches further in obs: a draw beyond the table costs a gallop +
     // bisection on the direct cdf (tens of incbet evaluations), and with 100 draws per base even
@@ -223,7 +221,6 @@ int fpt_ctx_create(int device_id, fpt_ctx **out) {
     if (const char *e = getenv("FPT_FDR_LIGHT")) c->fdr_light = atoi(e) != 0;
     if (const char *e = getenv("FPT_FDR_SLICES")) c->fdr_slices = atoi(e) != 0, c->fdr_slices_always = atoi(e) == 2;
     if (const char *e = getenv("FPT_FDR_LIGHT_DBUF")) c->fdr_light_dbuf = atoi(e) != 0;
-    if (const char *e = getenv("FPT_SCAN_WAVE")) c->classes = fptk::make_lean_classes(atoi(e));
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     // any failure below releases what was created so far (fpt_ctx_destroy skips null members)
@@ -543,7 +540,6 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         int nt;
         int64_t first, count;
         int tile_len;
-        int wave_rp;  // > 0: the one-wavefront-per-interval kernel (first pass of memo mode only)
     };
     const fptk::lean_class_set &CS = c->classes;
     std::vector<launch_t> launches, lean_launches;
@@ -564,9 +560,9 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         int tpi = (L + tile_len - 1) / tile_len;
         sl.tiles_per_interval = tpi;
         int nt_needed = tpi == 1 ? L : std::min(L, tile_len + 2 * H);
-        launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len, 0});
+        launches.push_back({nt_class(nt_needed), 0, d->n_intervals * (int64_t)tpi, tile_len});
         const int ucls = tpi == 1 ? lean_class(nt_needed) : std::max(lean_class(nt_needed), CS.first_split);
-        lean_launches.push_back({CS.nt[ucls], 0, d->n_intervals * (int64_t)tpi, tile_len, tpi == 1 ? CS.wave_rp[ucls] : 0});
+        lean_launches.push_back({CS.nt[ucls], 0, d->n_intervals * (int64_t)tpi, tile_len});
     } else {
         // ragged batch: tile table binned by workgroup size
         std::vector<int64_t> off_host;
@@ -662,10 +658,10 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
         for (int cls = 0; cls < fptk::kLeanClasses; ++cls) {
             const int64_t n = c->plan_cls_count[cls];
             if (n > 0) {
-                lean_launches.push_back({CS.nt[cls], first, n, split_len, CS.wave_rp[cls]});
+                lean_launches.push_back({CS.nt[cls], first, n, split_len});
                 const int nt = nt_class(CS.lmax[cls]);
                 if (!launches.empty() && launches.back().nt == nt) launches.back().count += n;
-                else launches.push_back({nt, first, n, split_len, 0});
+                else launches.push_back({nt, first, n, split_len});
             }
             first += n;
         }
@@ -762,21 +758,16 @@ int fpt_scan_dev(fpt_ctx *c, const fpt_scan_desc *d) {
             // count and cursor of the second pass: a pair of d_flags[10..15] per workgroup size
             s2.redo_cursor = c->d_flags + 10 + 2 * (ln.nt <= 256 ? 0 : (ln.nt <= 512 ? 1 : 2));
             const bool lean = lean_pass;
-            const int wave_rp = lean ? ln.wave_rp : 0;
-            size_t lds = wave_rp ? fptk::scan_wave_lds_bytes(wave_rp)
-                         : lean  ? fptk::scan_lean_lds_bytes(ln.nt)
-                                 : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
+            size_t lds = lean ? fptk::scan_lean_lds_bytes(ln.nt) : fptk::scan_lds_bytes(s2.nc_max, s2.table_global != 0, memo_only);
             if (lds > 160 * 1024)
                 return fail(FPT_ERR_INVALID, "window padding too large for LDS (%zu bytes needed)", lds);
-            if (wave_rp) {
-            } else if (lean) HIP_TRY(fptk::scan_lean_set_lds(ln.nt));
+            if (lean) HIP_TRY(fptk::scan_lean_set_lds(ln.nt));
             else HIP_TRY(fptk::scan_set_lds(ln.nt, hw, shw, s2.table_global != 0, memo_only, !memo_only && d_redo, lds));
             for (int64_t done = 0; done < ln.count; done += 0x7fffff00) {
                 int64_t n = std::min<int64_t>(ln.count - done, 0x7fffff00);
                 s2.tile_first = ln.first + done;
                 s2.redo_cursor_clear = done > 0 ? 1 : 0;  // a second chunk of the same size class reuses the pair
-                if (wave_rp) fptk::launch_scan_wave(c->stream, wave_rp, (int)n, s2);
-                else if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
+                if (lean) fptk::launch_scan_lean(c->stream, ln.nt, (int)n, s2);
                 else fptk::launch_scan(c->stream, ln.nt, (int)n, lds, s2, memo_only);
                 if (int rc = launch_ok("k_scan_fused")) return rc;
             }

@@ -3033,24 +3033,10 @@ __global__ void __launch_bounds__(kPlanBlock) k_plan_tiles(const plan_args a) {
     }
 }
 
-lean_class_set make_lean_classes(int wave_rp_max) {
+lean_class_set make_lean_classes() {
     lean_class_set c{};
-    for (int i = 0; i < kLeanClasses; ++i) {
-        c.lmax[i] = c.nt[i] = kLeanNT[i];
-        c.wave_rp[i] = 0;
-    }
+    for (int i = 0; i < kLeanClasses; ++i) c.lmax[i] = c.nt[i] = kLeanNT[i];
     c.first_split = 0;
-    // wave classes: whole intervals of up to 139 (RP 4), 203 (RP 5), 267 (RP 6) bases
-    for (int rp = 4, i = 0; rp <= wave_rp_max && rp <= 6; ++rp, ++i) {
-        c.lmax[i] = scan_wave_max_len(rp);
-        c.wave_rp[i] = rp;
-        c.first_split = i + 1;
-    }
-    for (int i = 0; i < kLeanClasses; ++i) {  // k_scan_lean's size for a class: the smallest that holds it
-        int k = 0;
-        while (kLeanNT[k] < c.lmax[i]) ++k;
-        c.nt[i] = kLeanNT[k];
-    }
     return c;
 }
 

@@ -58,19 +58,15 @@ struct lean_tile_rec {  // a tile of a ragged batch, read by the kernel with one
 static_assert(sizeof(lean_tile_rec) == 32, "one s_load_dwordx8");
 constexpr int kLeanClasses = 7;
 constexpr int kLeanNT[kLeanClasses] = {128, 192, 256, 384, 512, 768, 1024};  // its workgroup sizes
-// The tiles of a ragged batch are binned into kLeanClasses classes by the bases (+ halo) they hold.
-// Without the wave kernel the classes are k_scan_lean's workgroup sizes; with it (fpt_scan_wave.hip: one
-// wavefront per whole interval of up to 139 / 203 / 267 bases) the first classes end at those lengths.
+// The tiles of a ragged batch are binned into kLeanClasses classes by the bases (+ halo) they hold: k_scan_lean's
+// workgroup sizes.  (Rounds 4-5 also had one-wavefront-per-interval kernels for the first three classes --
+// fpt_scan_wave.hip, in the history up to 9f0b6e1 -- which landed level with these and were removed.)
 struct lean_class_set {
     int lmax[kLeanClasses];     // class c holds tiles of (lmax[c-1], lmax[c]] bases incl. halo
     int nt[kLeanClasses];       // k_scan_lean's workgroup size for the class
-    int wave_rp[kLeanClasses];  // > 0: k_scan_wave<rp> takes the class in the first pass (whole intervals only)
-    int first_split;            // the first class a PIECE of a split interval may go to (never a wave class)
+    int first_split;            // the first class a PIECE of a split interval may go to
 };
-lean_class_set make_lean_classes(int wave_rp_max);  // 0 (none), 4, 5 or 6
-int scan_wave_max_len(int rp);
-size_t scan_wave_lds_bytes(int rp);
-void launch_scan_wave(hipStream_t st, int rp, int grid, const scan_launch &sl);
+lean_class_set make_lean_classes();
 bool scan_lean_applies(const scan_launch &sl);
 bool scan_lean_applies_hw(int hw, int shw, int k_trim);
 size_t scan_lean_lds_bytes(int nt);

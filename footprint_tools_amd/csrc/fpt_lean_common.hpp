@@ -1,7 +1,6 @@
-// fpt_lean_common.hpp -- what the first-pass kernels of memo mode share (fpt_scan_lean.hip: one
-// workgroup per tile; fpt_scan_wave.hip: one wavefront per short interval): the kernel arguments,
-// fp64 arithmetic with scalar-register operands, the one-formula normal cdf, the Stouffer-window
-// phase and the track stores.  gfx950 only.
+// fpt_lean_common.hpp -- the pieces of the first-pass kernel of memo mode (fpt_scan_lean.hip: one workgroup per
+// tile) that do not depend on its LDS layout: the kernel arguments, fp64 arithmetic with scalar-register
+// operands, the one-formula normal cdf, the Stouffer-window phase and the track stores.  gfx950 only.
 #pragma once
 #include "fpt_kernels.hpp"
 
@@ -33,8 +32,6 @@ struct lean_args {
     const fptk::lean_tile_rec *tile_recs;  // ragged: one 32-byte record per tile (ONE scalar load: a short
                                            // workgroup lives ~7 us, and every dependent load is ~5 % of it)
     int64_t tile_first;
-    int64_t tile_count;       // k_scan_wave: tiles of this launch, tiles_per_wave consecutive ones per wavefront
-    int32_t tiles_per_wave;
     int32_t tiles_per_interval, tile_len;
     int32_t n_scales;
     int32_t scales[FPT_MAX_SCALES];
@@ -55,7 +52,6 @@ struct lean_args {
     const double2 *memo2;
     const int32_t *memo2_have;
     const int32_t *dm_ids;
-    int32_t prefetch;  // > 0: a workgroup touches the input rows of the tile this many places after its own (see lean_prefetch)
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
     int64_t *trace;  // -DFPT_ABLATE builds: per-workgroup timestamps (FPT_LEAN_TRACE)
     lean_coef c;
@@ -230,7 +226,7 @@ __device__ __forceinline__ void lean_z_finish(double zr, int tid, const double *
 }
 template <int NT, typename Args, bool TAB = false>
 __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z,
-                                             const double *gt = nullptr, const lean_tracks *deferred = nullptr) {
+                                             const double *gt = nullptr) {
     constexpr int kEdge = NT + 32 + 15;  // beyond every lane's slot
     // (uniform; typed as GLOBAL memory: behind the empty asm below a generic pointer made the store a
     // flat_store with a 64-bit vector add for its address -- and flat instructions count in lgkmcnt, which the
@@ -251,38 +247,6 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
     bool low = false;  // an argument below -26: the tile needs the restated ndtr.c (see ndtr_fast_s)
     const int n_scales = a.n_scales;
     const int64_t stride = a.total_bases;
-#ifdef FPT_LEAN_BUNCH
-    // (experiment) every scale's window p-value kept in registers, all stores issued back to back behind the
-    // arithmetic -- FPT_LEAN_BUNCH=2: the three per-base tracks too (handed in through `deferred`)
-    double pws[FPT_MAX_SCALES];
-#pragma unroll
-    for (int s = 0; s < FPT_MAX_SCALES; ++s) {
-        pws[s] = 0.0;
-        if (s < n_scales) {
-            const int hs = a.scales[s];
-            const u32 hs8 = (u32)hs * 8u;
-            const bool inside = hs <= room;
-            const u32 ah = inside ? ahi0 + hs8 : aedge, al = inside ? alo0 - hs8 : afirst;
-            const double sv = *(lds_double *)(size_t)ah - *(lds_double *)(size_t)al;
-            const double arg = -(sv * a.scale_rsqrt[s]);
-            low |= !(arg > neg_limit);
-            pws[s] = LEAN_STOP(4) ? arg : ndtr_fast_s<TAB>(arg, kc, gt);
-        }
-    }
-    if (deferred && o.mine) {
-        if (a.exp_out) store_at(a.exp_out + o.out_off, t8, deferred->ex);
-        if (a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)deferred->k);
-        if (a.pval_out) store_at(a.pval_out + o.out_off, t8, deferred->pv);
-    }
-#pragma unroll
-    for (int s = 0; s < FPT_MAX_SCALES; ++s) {
-        if (s < n_scales) {
-            asm volatile("" : "+s"(row));
-            if (o.mine) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(t8), "v"(pws[s]), "s"(row) : "memory");
-            row += stride;
-        }
-    }
-#else
     for (int s = 0; s < n_scales; ++s) {
         const int hs = a.scales[s];
         const u32 hs8 = (u32)hs * 8u;
@@ -296,17 +260,7 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
         // (written out: the compiler forms the address with a 64-bit vector add and stores through it)
         if (o.mine) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(t8), "v"(pw), "s"(row) : "memory");
         row += stride;
-#ifdef FPT_LEAN_DEFER
-        // (experiment) the three per-base tracks stored one per scale, between the scales' arithmetic, instead of
-        // back to back ahead of phase E's barriers
-        if (deferred && o.mine) {
-            if (s == 0 && a.exp_out) store_at(a.exp_out + o.out_off, t8, deferred->ex);
-            if (s == 1 && a.obs_out) store_at(a.obs_out + o.out_off, t8, (double)deferred->k);
-            if (s == 2 && a.pval_out) store_at(a.pval_out + o.out_off, t8, deferred->pv);
-        }
-#endif
     }
-#endif
     return low;
 }
 // one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right
@@ -329,8 +283,6 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.interval_off = sl.interval_off;
     a.tile_recs = (const fptk::lean_tile_rec *)sl.tile_recs;
     a.tile_first = sl.tile_first;
-    a.tile_count = 0;
-    a.tiles_per_wave = 1;
     a.tiles_per_interval = sl.tiles_per_interval;
     a.tile_len = sl.tile_len;
     a.n_scales = sl.n_scales;
@@ -361,7 +313,6 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.memo2 = (const double2 *)sl.memo2;
     a.memo2_have = sl.memo2_have;
     a.dm_ids = sl.dm_ids;
-    a.prefetch = 0;
     a.stop = sl.ablate;
     a.trace = nullptr;
     const double g[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST}, e[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};

@@ -49,7 +49,8 @@ namespace {
 // the table of fptm::ndtr_fast_tab (this translation unit's copy: staged in LDS per workgroup)
 __device__ const double g_lean_gtab[4 * FPT_NDTR_GTAB_N + 1] = {FPT_NDTR_GTAB_LIST};
 
-// LDS carve-up for a workgroup of NT lanes: positions are padded up to NCR = NT + 128
+// LDS carve-up for a tile of up to NT bases (NT = lanes x bases per lane: one base per lane in every class but
+// the two-bases-per-lane instance of the largest): positions are padded up to NCR = NT + 128
 // (NT output bases + 2*pad + 1 padded positions + 6 sequence bases, in whole 64-position tiles)
 template <int NT>
 struct lean_lds {
@@ -147,15 +148,18 @@ __device__ __forceinline__ lean_tile lean_geometry(const Args &a, int64_t tile) 
 }
 
 // the inputs of one tile as they sit in a lane's registers between the load and phase A
+template <int NI>
 struct lean_inputs {
-    double cp[2], cm[2];
-    u32 ch[2];
+    double cp[NI], cm[NI];
+    u32 ch[NI];
 };
 
-template <int NT>
-__device__ __forceinline__ void lean_load(const lean_tile &g, int tid, lean_inputs &in, bool fake = false) {
+// (NI trips of the workgroup's NT lanes cover the NP + 128 staged positions: two with a base per lane, three
+// with two)
+template <int NT, int NI>
+__device__ __forceinline__ void lean_load(const lean_tile &g, int tid, lean_inputs<NI> &in, bool fake = false) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {  // every load of a lane in flight before the first is used
+    for (int i = 0; i < NI; ++i) {  // every load of a lane in flight before the first is used
         const int v = i * NT + tid;
         in.cp[i] = in.cm[i] = 0.0;
         in.ch[i] = 'A';
@@ -173,33 +177,10 @@ __device__ __forceinline__ void lean_load(const lean_tile &g, int tid, lean_inpu
     }
 }
 
-// The input rows of a LATER tile pulled into the L2 of this XCD: one byte per 128-byte line of its two count rows
-// and its sequence row -- a single load instruction for an interval of up to ~1,000 bases.  A workgroup of a
-// short interval lives ~7 us, 2.6 of them waiting for its inputs to come from HBM; the tile
-// `a.prefetch` places on (a multiple of 8: workgroups go round the 8 XCDs) starts about one generation of
-// resident workgroups later, on the same XCD, and finds them in its L2.  The value is consumed by the
-// caller at the very end of the kernel, so the wait for it sits behind everything else.
-template <int NT>
-__device__ __forceinline__ u32 lean_prefetch(const lean_tile &g2, int tid) {
-    u32 acc = 0;
-    const char *rows[3] = {(const char *)g2.gcp, (const char *)g2.gcm, (const char *)g2.gsq};
-    const int bytes[3] = {g2.nc * 8, g2.nc * 8, g2.nc + 6};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const size_t p = (size_t)rows[r], a0 = p & ~(size_t)127;
-        const int n_lines = (int)((p + (size_t)bytes[r] - a0 + 127) >> 7);
-        for (int i = tid; i < n_lines; i += NT) {
-            const size_t at = a0 + ((size_t)i << 7);
-            acc += *(const uint8_t *)(at < p ? p : at);  // (the first line's byte: the row's own first one)
-        }
-    }
-    return acc;
-}
-
 // phase A of one tile: counts -> packed 16-bit integers, sequence -> two bit planes (LDS).
 // Returns true if this lane saw an input outside the case the kernel handles.
-template <int NT>
-__device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int tid, u32 *pk, u32 *bits0, u32 *bits1) {
+template <int NT, int NI>
+__device__ __forceinline__ bool lean_stage(const lean_inputs<NI> &in, int ncs, int tid, u32 *pk, u32 *bits0, u32 *bits1) {
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     bool bad = false;
     if (tid < 8) {
@@ -211,7 +192,7 @@ __device__ __forceinline__ bool lean_stage(const lean_inputs &in, int ncs, int t
         bits1[(ncs >> 5) + tid] = 0;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (i * NT + wave * kWave >= ncs) break;  // whole tiles: wavefront-uniform
         const int v = i * NT + tid;
         const int ip = (int)in.cp[i], im = (int)in.cm[i];
@@ -247,15 +228,15 @@ struct lean_mem {
 
 // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums.
 // Returns true where an aligned row of 16 equal non-zero window sums shows up (see the header).
-template <int NT>
-__device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double2 *table2, int ncs, int nt, int tid) {
+template <int NT, int NP, int NI>
+__device__ __forceinline__ bool lean_phase_b(const lean_mem<NP> &m, const double2 *table2, int ncs, int nt, int tid) {
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     bool bad = false;
     // the table gathers of both of a lane's positions go out first: one trip to L2 instead of two
     // in a row (a short workgroup lives ~7 us, most of it such trips)
-    double2 tt[2];
+    double2 tt[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (i * NT + wave * kWave >= ncs) break;
         const int v = i * NT + tid;
         // The propensities are read by phase C at the positions [pad + 1 - hw, pad + nt + hw] only -- the 2 hw window
@@ -271,7 +252,7 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (i * NT + wave * kWave >= ncs) break;
         const int v = i * NT + tid;
         const u32 *pw = m.pk + 8 + v - kHW;
@@ -317,18 +298,72 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NT> &m, const double
     return bad;
 }
 
-// ---- C: trimmed-mean smoothing + expected counts of this lane's base, both strands ('+' at padded
+// ---- C: trimmed-mean smoothing + expected counts of base t of the tile, both strands ('+' at padded
 // position pad+1+t, '-' at pad+t; detect.py:121-122); D: observed count, p-value and z from the
-// (exp, obs) table.  Lanes beyond nt return z = 0.
-template <int NT>
-__device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_args &a, kcoef *kc, const double2 *memo,
-                                              int dm, int nt, int ncs, int tid, lean_tracks &tr, double &z) {
+// (exp, obs) table.  Bases beyond nt return z = 0.  A lane has BPL bases: t = tid, tid + NT, ...
+template <int NP>
+__device__ __forceinline__ bool lean_cd_base(const lean_mem<NP> &m, const lean_args &a, kcoef *kc, const double2 *memo,
+                                             int dm, int nt, int t, lean_tracks &tr, double &z, bool &miss, u32 &miss_e) {
     bool bad = false;
     z = 0.0;
     tr.ex = tr.pv = 0.0;
     tr.k = 0;
-    bool miss = false;  // a lane whose (exp, obs) pair lies outside the table but inside the second-level bounds
-    u32 miss_e = 0;
+    if (t < nt) {
+        double e2[2];
+#pragma unroll
+        for (int strand = 0; strand < 2; ++strand) {
+            const int v = kPad + t + (strand ? 0 : 1);
+            const int lo = v - kSHW, hi = v + kSHW;
+            const u32 S = window_sum(strand ? m.psM : m.psP, lo, hi);
+            const u32 *xp = strand ? m.xM : m.xP, *xs = strand ? m.xMs : m.xPs;
+            const int mid = (lo | 63) + 64;  // last position of the tile after lo's
+            const u32 x1 = xs[lo], x2 = xp[hi], x3 = xp[(hi >> 6) == (lo >> 6) + 2 ? mid : hi];
+            const u32 cmin = max(max(x1 & 0xffffu, x2 & 0xffffu), x3 & 0xffffu);  // 0xffff - min
+            const u32 mx = max(max(x1 >> 16, x2 >> 16), x3 >> 16);
+            const double tsum = (double)((S + cmin) - mx - 0xffffu);  // S - min - max
+            const double *P = (strand ? m.PM : m.PP) + (kPad + t + 1 - kHW);  // P[v-hw .. v+hw-1]
+            double q = P[0];
+#pragma unroll
+            for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
+            const double q99 = mul_vs(q, kc->c99);
+            double r = __builtin_amdgcn_rcp(q99);  // 2^-24; one Newton step: 2e-15, far inside the band
+            r = fma(fma(-q99, r, 1.0), r, r);
+            const double x = (P[kHW] * tsum) * r;  // ~ P/Q * t/99
+            const double e = floor(x + 0.5);
+            // too close to a tie (or not a number)?  |x - e| = 1/2 - (distance of x to the nearest half-integer)
+            bad |= !(fabs(x - e) < fma(x, -kc->band, 0.5));
+            e2[strand] = e;
+        }
+        tr.ex = e2[0] + e2[1];
+        tr.k = (m.pk[8 + kPad + 1 + t] & 0xffffu) + (m.pk[8 + kPad + t] >> 16);
+        const u32 ei = (u32)(int)tr.ex;
+        bool hit = ei < (u32)a.memo_exp && tr.k < (u32)a.memo_obs;
+        double2 pz = memo[hit ? ei * (u32)a.memo_obs + tr.k : 0u];
+        if (!hit && a.memo2) {  // (rare: hotspots) the kept second-level table, as far as it is filled
+            const int h0 = a.memo2_have[0], h1 = a.memo2_have[1];
+            if (h0 >= 0 && h1 >= 0 && ei <= (u32)h0 && tr.k <= (u32)h1) {
+                pz = a.memo2[((size_t)dm * a.miss_rows + ei) * a.miss_stride + tr.k];
+                hit = true;
+            }
+        }
+        tr.pv = pz.x;
+        z = pz.y;
+        bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
+        // a pair outside the table but inside the second-level bounds
+        if (!hit && a.miss_max && ei < (u32)a.miss_rows && tr.k < (u32)a.miss_stride) {
+            miss_e = miss ? max(miss_e, ei) : ei;
+            miss = true;
+        }
+    }
+    return bad;
+}
+
+template <int NT, int NP, int BPL>
+__device__ __forceinline__ bool lean_phase_cd(const lean_mem<NP> &m, const lean_args &a, kcoef *kc, const double2 *memo,
+                                              int dm, int nt, int ncs, int tid, lean_tracks (&tr)[BPL], double (&z)[BPL]) {
+    bool bad = false;
+    bool miss = false;  // a lane with a base whose (exp, obs) pair lies outside the table but inside the second-level bounds
+    u32 miss_e = 0, miss_k = 0;
     if (tid + 1 < (ncs >> 6)) {  // a run of equal non-zero window sums across the boundary of tiles tid, tid + 1
         const u32 *e0 = m.edge + 8 * tid;
         const u32 last = e0[1], first = e0[8];
@@ -343,55 +378,22 @@ __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_
             bad |= (sameP && trailP + leadP >= 33u) | (sameM && trailM + leadM >= 33u);
         }
     }
-    if (tid < nt) {
-        double e2[2];
 #pragma unroll
-        for (int strand = 0; strand < 2; ++strand) {
-            const int v = kPad + tid + (strand ? 0 : 1);
-            const int lo = v - kSHW, hi = v + kSHW;
-            const u32 S = window_sum(strand ? m.psM : m.psP, lo, hi);
-            const u32 *xp = strand ? m.xM : m.xP, *xs = strand ? m.xMs : m.xPs;
-            const int mid = (lo | 63) + 64;  // last position of the tile after lo's
-            const u32 x1 = xs[lo], x2 = xp[hi], x3 = xp[(hi >> 6) == (lo >> 6) + 2 ? mid : hi];
-            const u32 cmin = max(max(x1 & 0xffffu, x2 & 0xffffu), x3 & 0xffffu);  // 0xffff - min
-            const u32 mx = max(max(x1 >> 16, x2 >> 16), x3 >> 16);
-            const double tsum = (double)((S + cmin) - mx - 0xffffu);  // S - min - max
-            const double *P = (strand ? m.PM : m.PP) + (kPad + tid + 1 - kHW);  // P[v-hw .. v+hw-1]
-            double q = P[0];
-#pragma unroll
-            for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
-            const double q99 = mul_vs(q, kc->c99);
-            double r = __builtin_amdgcn_rcp(q99);  // 2^-24; one Newton step: 2e-15, far inside the band
-            r = fma(fma(-q99, r, 1.0), r, r);
-            const double x = (P[kHW] * tsum) * r;  // ~ P/Q * t/99
-            const double e = floor(x + 0.5);
-            // too close to a tie (or not a number)?  |x - e| = 1/2 - (distance of x to the nearest half-integer)
-            bad |= !(fabs(x - e) < fma(x, -kc->band, 0.5));
-            e2[strand] = e;
+    for (int b = 0; b < BPL; ++b) {
+        bool mb = false;
+        u32 me_b = 0;
+        bad |= lean_cd_base<NP>(m, a, kc, memo, dm, nt, b * NT + tid, tr[b], z[b], mb, me_b);
+        if (mb) {
+            miss_e = miss ? max(miss_e, me_b) : me_b;
+            miss_k = miss ? max(miss_k, tr[b].k) : tr[b].k;
+            miss = true;
         }
-        tr.ex = e2[0] + e2[1];
-        tr.k = (m.pk[8 + kPad + 1 + tid] & 0xffffu) + (m.pk[8 + kPad + tid] >> 16);
-        const u32 ei = (u32)(int)tr.ex;
-        bool hit = ei < (u32)a.memo_exp && tr.k < (u32)a.memo_obs;
-        double2 pz = memo[hit ? ei * (u32)a.memo_obs + tr.k : 0u];
-        if (!hit && a.memo2) {  // (rare: hotspots) the kept second-level table, as far as it is filled
-            const int h0 = a.memo2_have[0], h1 = a.memo2_have[1];
-            if (h0 >= 0 && h1 >= 0 && ei <= (u32)h0 && tr.k <= (u32)h1) {
-                pz = a.memo2[((size_t)dm * a.miss_rows + ei) * a.miss_stride + tr.k];
-                hit = true;
-            }
-        }
-        tr.pv = pz.x;
-        z = pz.y;
-        bad |= !hit | ((__double2hiint(z) & 0x7ff00000) == 0x7ff00000);  // a miss, or a non-finite z
-        miss = !hit && a.miss_max && ei < (u32)a.miss_rows && tr.k < (u32)a.miss_stride;
-        miss_e = ei;
     }
     // the largest missed pair sizes the second-level table of the redo pass: one pair of atomics per
     // wavefront that has a miss (a hotspot tile has hundreds of missing lanes; one atomic per lane
     // on the same two words cost 1.4 ms of the 24.9 ms heavy-tailed launch)
     if (__builtin_amdgcn_ballot_w64(miss)) {
-        int me = miss ? (int)miss_e : -1, mk = miss ? (int)tr.k : -1;
+        int me = miss ? (int)miss_e : -1, mk = miss ? (int)miss_k : -1;
 #pragma unroll
         for (int d = 32; d; d >>= 1) {
             me = max(me, __shfl_xor(me, d));
@@ -405,12 +407,12 @@ __device__ __forceinline__ bool lean_phase_cd(const lean_mem<NT> &m, const lean_
     return bad;
 }
 
-__device__ __forceinline__ lean_owner lean_own(const lean_tile &g, int tid, bool no_stores) {
+__device__ __forceinline__ lean_owner lean_own(const lean_tile &g, int t, bool no_stores) {  // t: the base's index in the tile
     lean_owner o;
-    o.t = g.ta + tid;
+    o.t = g.ta + t;
     o.L = g.L;
     o.out_off = g.out_off;
-    o.mine = tid < g.nt && o.t >= g.t0 && o.t < g.t0 + g.tl && !no_stores;
+    o.mine = t < g.nt && o.t >= g.t0 && o.t < g.t0 + g.tl && !no_stores;
     return o;
 }
 
@@ -429,11 +431,17 @@ __device__ __forceinline__ lean_owner lean_own(const lean_tile &g, int tid, bool
 // 18.6 against 18.9): all correct on the whole GPU suite, none faster.  The memory time that is
 // not hidden is spread over the phases -- gathers and store issue take longer while 3.4 TB/s
 // stream through the same L2 -- not concentrated at a workgroup's two ends.
-template <int NT>
-__global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
+// BPL: bases per lane.  1 in every size class but the largest, whose 1,024-base tiles are taken by 512 lanes with
+// two bases each (the same tile, the same 52.7 KB of LDS): three workgroups of eight wavefronts share a CU where
+// two of sixteen did -- 1.6 % on config 3 (24.38 -> 23.98 ms, alternating on one lease).
+// FPT_LEAN_BPL2=0 brings the 1,024-lane instance back.
+template <int NT, int BPL>
+__global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_args a) {
+    constexpr int NP = NT * BPL;                     // bases (and output positions) of a tile
+    constexpr int NI = (NP + 128 + NT - 1) / NT;     // trips of the lanes over the staged positions
     extern __shared__ double smem[];
-    const lean_mem<NT> m(smem);
-    constexpr int kEdge = NT + 32 + 15;
+    const lean_mem<NP> m(smem);
+    constexpr int kEdge = NP + 32 + 15;
 
     typedef const __attribute__((address_space(4))) lean_args kargs;
     kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
@@ -446,78 +454,84 @@ __global__ void __launch_bounds__(NT, 8) k_scan_lean(const lean_args a) {
     const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
 
     // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
-    lean_inputs in;
-    lean_load<NT>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
-    u32 touched = 0;  // (behind the tile's own loads: the memory counter is in order, and these are not waited for)
-    if (a.prefetch > 0 && blockIdx.x + (unsigned)a.prefetch < gridDim.x)
-        touched = lean_prefetch<NT>(lean_geometry(a, tile + a.prefetch), tid);
-    if (lean_lds<NT>::kTab && a.n_scales > 1)  // (read four barriers from here)
+    lean_inputs<NI> in;
+    lean_load<NT, NI>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
+    if (lean_lds<NP>::kTab && a.n_scales > 1)  // (read four barriers from here)
         for (int i = tid; i < 4 * FPT_NDTR_GTAB_N; i += NT) m.gt[i] = g_lean_gtab[i] * kc->inv_g0;
-    bool bad = lean_stage<NT>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
+    bool bad = lean_stage<NT, NI>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
     LEAN_TRACE(2);
     __syncthreads();
     LEAN_TRACE(3);
     if (LEAN_STOP(1)) return;
 
-    bad |= lean_phase_b<NT>(m, a.table2, g.ncs, g.nt, tid);
+    bad |= lean_phase_b<NT, NP, NI>(m, a.table2, g.ncs, g.nt, tid);
     __syncthreads();
     LEAN_TRACE(4);
     if (LEAN_STOP(2)) return;
 
-    lean_tracks tr;
-    double z;
-    bad |= lean_phase_cd<NT>(m, a, kc, memo, g.dm, g.nt, g.ncs, tid, tr, z);
-    const lean_owner o = lean_own(g, tid, LEAN_STOP(6));
-#if defined(FPT_LEAN_DEFER) || (defined(FPT_LEAN_BUNCH) && FPT_LEAN_BUNCH == 2)
-    const bool defer = a.n_scales >= 3 && !(a.n_scales == 1 && a.max_scale <= 8);
-    if (!defer) lean_store_tracks(a, o, tr);
-#else
-    lean_store_tracks(a, o, tr);
-#endif
+    lean_tracks tr[BPL];
+    double z[BPL];
+    bad |= lean_phase_cd<NT, NP, BPL>(m, a, kc, memo, g.dm, g.nt, g.ncs, tid, tr, z);
+    lean_owner o[BPL];
+    // (the tracks are stored HERE, ahead of phase E's barriers: a store issued later holds the workgroup's slot
+    // longer -- moved into phase E they cost 15-19 % on config 3)
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+        o[b] = lean_own(g, b * NT + tid, LEAN_STOP(6));
+        lean_store_tracks(a, o[b], tr[b]);
+    }
 
     LEAN_TRACE(5);
     // ---- E: Stouffer windows (windowing.h:53-84)
     if (a.n_scales == 0 || LEAN_STOP(3)) {
     } else if (a.n_scales == 1 && a.max_scale <= 8) {
         __syncthreads();  // Z takes the place of the scan arrays: every lane is through phase C
-        m.Z[16 + tid] = z;
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) m.Z[16 + b * NT + tid] = z[b];
         __syncthreads();
-        bad |= lean_window_narrow<NT>(a, kc, o, tid, m.Z);
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) bad |= lean_window_narrow<NP>(a, kc, o[b], b * NT + tid, m.Z);
     } else {
         // one workgroup-wide prefix sum of z in two levels: rows of 16 lanes on the DPP path, the
-        // NT/16 row totals scanned by the first wavefront, the carries added once behind a third
+        // NP/16 row totals scanned by the first wavefront, the carries added once behind a third
         // barrier (measured 24.7 -> 24.5 ms against adding them in every scale)
-        const double zr = lean_z_rows<NT>(z, tid, m.rowtot);
+        double zr[BPL];
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) zr[b] = lean_z_rows<NP>(z[b], b * NT + tid, m.rowtot);
         __syncthreads();
-        lean_z_carries<NT>(tid, m.rowtot, m.C);
+        lean_z_carries<NP>(tid, m.rowtot, m.C);
         __syncthreads();
-        lean_z_finish<NT>(zr, tid, m.C, m.Z);  // two barriers behind phase C: the scan arrays are free
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) lean_z_finish<NP>(zr[b], b * NT + tid, m.C, m.Z);  // two barriers behind phase C: the scan arrays are free
         if (tid == 0) {
             m.Z[15] = 0.0;
             m.Z[kEdge] = -1e4;
         }
         __syncthreads();
-#if defined(FPT_LEAN_DEFER) || (defined(FPT_LEAN_BUNCH) && FPT_LEAN_BUNCH == 2)
-        bad |= lean_windows<NT, lean_args, lean_lds<NT>::kTab>(a, kc, o, tid, m.Z, m.gt, defer ? &tr : nullptr);
-#else
-        bad |= lean_windows<NT, lean_args, lean_lds<NT>::kTab>(a, kc, o, tid, m.Z, m.gt);
-#endif
+#pragma unroll
+        for (int b = 0; b < BPL; ++b)
+            bad |= lean_windows<NP, lean_args, lean_lds<NP>::kTab>(a, kc, o[b], b * NT + tid, m.Z, m.gt);
     }
     if (bad) a.redo[tile] = 1;
-    if (touched == 0xffffffffu) a.redo[tile] = 1;  // (never: 1,024 lanes x 3 rows x 255; keeps the touching loads alive)
     LEAN_TRACE(6);
 }
 
 typedef void (*lean_kernel_t)(const lean_args);
+// The tiles of the 1,024-base class are taken by 512 lanes with two bases each (FPT_LEAN_BPL2=0, read once:
+// 1,024 lanes with one)
+bool lean_bpl2() {
+    static const bool on = !getenv("FPT_LEAN_BPL2") || atoi(getenv("FPT_LEAN_BPL2")) != 0;
+    return on;
+}
 lean_kernel_t lean_kernel(int nt) {
     switch (nt) {
-        case 128: return k_scan_lean<128>;
-        case 192: return k_scan_lean<192>;
-        case 256: return k_scan_lean<256>;
-        case 384: return k_scan_lean<384>;
-        case 512: return k_scan_lean<512>;
-        case 768: return k_scan_lean<768>;
-        default: return k_scan_lean<1024>;
+        case 128: return k_scan_lean<128, 1>;
+        case 192: return k_scan_lean<192, 1>;
+        case 256: return k_scan_lean<256, 1>;
+        case 384: return k_scan_lean<384, 1>;
+        case 512: return k_scan_lean<512, 1>;
+        case 768: return k_scan_lean<768, 1>;
+        default: return lean_bpl2() ? k_scan_lean<512, 2> : k_scan_lean<1024, 1>;
     }
 }
 
@@ -557,14 +571,7 @@ bool scan_lean_applies(const scan_launch &sl) {
 void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
     lean_args a;
     fill_lean_args(sl, a);
-    // FPT_LEAN_PREFETCH=<f>: the touching distance as a multiple of the workgroups resident on the device
-    // (by wavefront slots and LDS), rounded to the 8 XCDs; unset / 0: off
-    static const double pf = getenv("FPT_LEAN_PREFETCH") ? atof(getenv("FPT_LEAN_PREFETCH")) : 0.0;
-    if (pf > 0.0) {
-        const int by_waves = 32 / (nt / 64), by_lds = (int)(160 * 1024 / scan_lean_lds_bytes(nt));
-        const int resident = (sl.n_cu > 0 ? sl.n_cu : 256) * (by_waves < by_lds ? by_waves : by_lds);
-        a.prefetch = ((int)(pf * resident) + 7) & ~7;
-    }
+
 #ifdef FPT_ABLATE
     static int64_t *d_trace = nullptr;
     const char *trace_path = getenv("FPT_LEAN_TRACE");
@@ -573,7 +580,8 @@ void launch_scan_lean(hipStream_t st, int nt, int grid, const scan_launch &sl) {
         if (grid <= (1 << 20)) a.trace = d_trace;
     }
 #endif
-    hipLaunchKernelGGL(lean_kernel(nt), dim3(grid), dim3(nt), scan_lean_lds_bytes(nt), st, a);
+    const int lanes = (nt > 768 && lean_bpl2()) ? 512 : nt;
+    hipLaunchKernelGGL(lean_kernel(nt), dim3(grid), dim3(lanes), scan_lean_lds_bytes(nt), st, a);
 #ifdef FPT_ABLATE
     if (a.trace) {  // the last launch's record: 8 words per workgroup (see LEAN_TRACE)
         std::vector<int64_t> h((size_t)grid * 8);

@@ -2093,38 +2093,17 @@ def test_lean_kernel_fuzz(fpt, orc, seed):
     _first_pass_fuzz_case(fpt, orc, 7000 + seed, _LEAN_LENS, None)
 
 
-_wave_ctx = {}
-
-
-def _ctx_with_wave(fpt, rp):
-    """a context of its own whose short-interval classes go to k_scan_wave<4..rp> (0: none); the switch is
-    read when a context is made"""
-    if rp not in _wave_ctx:
-        old = os.environ.get("FPT_SCAN_WAVE")
-        os.environ["FPT_SCAN_WAVE"] = str(rp)
-        try:
-            _wave_ctx[rp] = fpt.Context(0)
-        finally:
-            if old is None:
-                del os.environ["FPT_SCAN_WAVE"]
-            else:
-                os.environ["FPT_SCAN_WAVE"] = old
-    return _wave_ctx[rp]
-
-
-@pytest.mark.parametrize("rp", [4, 5, 6, 0])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FPT_FUZZ_SEEDS", "12"))))
-def test_wave_kernel_fuzz(fpt, orc, seed, rp):
-    """The same cases on SHORT intervals, where the first pass is one wavefront per interval
-    (fpt_scan_wave.hip, k_scan_wave<4 / 5 / 6>: up to 139 / 203 / 267 bases): every length at which the
-    kernel adds or drops a row, the class limits and one past them, with each set of wave classes
-    switched on (rp = 0: none -- the same batches through k_scan_lean)."""
-    _first_pass_fuzz_case(fpt, orc, 9000 + seed, _WAVE_LENS, _ctx_with_wave(fpt, rp), n_iv_max=40)
+def test_short_interval_fuzz(fpt, orc, seed):
+    """The same cases on SHORT intervals (the whole-genome shape's lengths: 50 .. 270 bases, every length at which
+    a 64-position row is added or dropped and the limits of the 128- / 192- / 256-lane classes, one short and one
+    past), forty to a batch."""
+    _first_pass_fuzz_case(fpt, orc, 9000 + seed, _WAVE_LENS, None, n_iv_max=40)
 
 
-def test_wave_kernel_uniform_and_models(fpt, orc):
-    """uniform batches (no offset array) of short intervals through the wave kernel, with per-interval
-    dispersion models, one narrow scale / five scales / none"""
+def test_short_uniform_batches_and_models(fpt, orc):
+    """uniform batches (no offset array) of short intervals, with per-interval dispersion models, one narrow
+    scale / five scales / none"""
     from footprint_tools_amd.scan import FootprintScanner
     lat = golden("nb_lattice.npz")
     table = golden("kmer_probs.npz")["table"]
@@ -2136,7 +2115,7 @@ def test_wave_kernel_uniform_and_models(fpt, orc):
         cp, cm = orc.synth_counts(5, 0, n_iv * l, 0), orc.synth_counts(5, 0, n_iv * l, 1)
         sq = orc.synth_bases(5, 0, n_iv * (l + 6))
         ids = (np.arange(n_iv) % 3).astype(np.int32)
-        sc = FootprintScanner(table, models, hw, shw, clip, scales, nb_mode="memo", ctx=_ctx_with_wave(fpt, 6))
+        sc = FootprintScanner(table, models, hw, shw, clip, scales, nb_mode="memo")
         out = sc.scan(cp, cm, sq, interval_len=L, dm_ids=ids)
         for i in range(n_iv):
             m = models[ids[i]]
@@ -2149,7 +2128,7 @@ def test_wave_kernel_uniform_and_models(fpt, orc):
                 assert rel_err(out["winp"][s_i, sl], wp[s_i]) < P_TOL, (L, i, s_i)
         # (models B and C have pairs with a non-finite z inside the table: those intervals go to the general
         # kernel.)  Model A alone on these counts: nothing is handed on
-        sc1 = FootprintScanner(table, models[0], hw, shw, clip, scales, nb_mode="memo", ctx=_ctx_with_wave(fpt, 6))
+        sc1 = FootprintScanner(table, models[0], hw, shw, clip, scales, nb_mode="memo")
         out1 = sc1.scan(cp, cm, sq, interval_len=L)
         assert sc1.ctx.scan_stats()[1] == 0, L
         keep = np.repeat(ids == 0, L)
