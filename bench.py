@@ -123,11 +123,13 @@ def traffic_probe(argv_cfg, timeout_s=100):
     if not prof or under_profiler:  # (a run that is itself being profiled does not start profilers)
         return None
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-    got, clock = {}, None
+    got, clock, issue = {}, None, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
         out = tempfile.mkdtemp(prefix="fpt_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         try:
-            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+            # (the clock pass also reads how busy the vector and LDS pipes were: same block of counters, same run)
+            pmc = [counter] if counter != "GRBM_GUI_ACTIVE" else [counter, "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE"]
+            cmd = [prof, "--pmc"] + pmc + ["--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.abspath(__file__)] + argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                                                             "--no-other-mode", "--no-heavy", "--no-posterior",
                                                             "--no-traffic-probe", "--no-box-stream"]
@@ -140,10 +142,12 @@ def traffic_probe(argv_cfg, timeout_s=100):
                 os.killpg(child.pid, signal.SIGKILL)  # the profiler AND the program under it
                 child.wait()
                 raise
-            per, spans = {}, {}
+            per, spans, extra = {}, {}, {}
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row["Kernel_Name"]
+                    if row["Counter_Name"] in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE") and "scan_lean" in name:
+                        extra[row["Counter_Name"]] = extra.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                     if row["Counter_Name"] == counter and ("scan_lean" in name or "scan_fused" in name):
                         key = (name, int(row.get("Dispatch_Id", 0) or 0))
                         per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
@@ -164,6 +168,10 @@ def traffic_probe(argv_cfg, timeout_s=100):
             got[counter] = total
             if counter == "GRBM_GUI_ACTIVE" and ns > 0:
                 clock = cyc / 8.0 / ns  # GHz: cycles summed over the 8 XCDs / duration of the first-pass kernels
+                all_cyc = sum(per[k_] for k_ in per if "scan_lean" in k_[0]) / 8.0
+                if all_cyc > 0 and extra:  # rocprofv3's VALUBusy / LdsUtil of the first-pass kernels (all their dispatches)
+                    issue = dict(valu_busy=extra.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * all_cyc),
+                                 lds_busy=extra.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * all_cyc))
         except (OSError, subprocess.SubprocessError, KeyError, ValueError):
             if counter == "GRBM_GUI_ACTIVE" and "FETCH_SIZE" in got and "WRITE_SIZE" in got:
                 break  # the traffic stands without the clock
@@ -171,7 +179,7 @@ def traffic_probe(argv_cfg, timeout_s=100):
         finally:
             shutil.rmtree(out, ignore_errors=True)
     rd, wr = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
-    return dict(read_bytes=rd, write_bytes=wr, bytes_per_launch=rd + wr, shader_clock_GHz=clock,
+    return dict(read_bytes=rd, write_bytes=wr, bytes_per_launch=rd + wr, shader_clock_GHz=clock, issue=issue,
                 raw_counters=dict(FETCH_SIZE_KiB=got.get("FETCH_SIZE"), WRITE_SIZE_KiB=got.get("WRITE_SIZE"),
                                   GRBM_GUI_ACTIVE=got.get("GRBM_GUI_ACTIVE"),
                                   corrections="FETCH_SIZE x2 (gfx950 streaming reads), KiB -> bytes"))
@@ -957,6 +965,11 @@ def main():
                         # GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the first-pass kernel in a child run
                         # under rocprofv3 --pmc (traffic_probe)
                         shader_clock_GHz=(live_traffic or {}).get("shader_clock_GHz"),
+                        # how busy the vector and the LDS pipes were under the first-pass kernel (the same child run:
+                        # SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles), SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)): the
+                        # HBM fraction above cannot pass what vector issue leaves
+                        valu_busy=((live_traffic or {}).get("issue") or {}).get("valu_busy"),
+                        lds_busy=((live_traffic or {}).get("issue") or {}).get("lds_busy"),
                         raw_counters=(live_traffic or {}).get("raw_counters"),
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),

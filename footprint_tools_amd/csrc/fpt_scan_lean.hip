@@ -56,10 +56,14 @@ template <int NT>
 struct lean_lds {
     static constexpr int NCR = NT + 128;
     static constexpr int NROW = NT / 16;
-    // doubles
+    // doubles.  The propensities are kept for the positions phase C reads them at only -- [pad + 1 - hw, pad + nt + hw],
+    // stored from kPOff on: NT + 16 slots instead of NCR (the 128-lane class then fits sixteen workgroups on a CU,
+    // as many as its wavefront slots hold, instead of thirteen)
+    static constexpr int kPOff = kPad + 1 - kHW - 3;   // position v sits in slot v - kPOff (slot 3 is the first in use)
+    static constexpr int NPP = NT + 16;
     static constexpr int oPP = 0;                  // P+[v]
-    static constexpr int oPM = oPP + NCR;          // P-[v-1] (slot 0 is a dummy)
-    static constexpr int oRT = oPM + NCR + 2;      // row totals (NROW), then row carries (NROW + 4)
+    static constexpr int oPM = oPP + NPP;          // P-[v-1]
+    static constexpr int oRT = oPM + NPP;          // row totals (NROW), then row carries (NROW + 4)
     // The table form of the normal cdf's g (fptm::ndtr_fast_tab: 256 cubics staged in 8 KB of LDS, two
     // 16-byte reads and 9 instructions in place of the 15 fp64 ones of the Horner chain) is built and
     // OFF: config 3 23.7 / 23.7 / 24.6 ms with it against 23.6 / 23.7 without (same box, same lease) --
@@ -292,8 +296,10 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NP> &m, const double
                 *reinterpret_cast<uint4 *>(eg + 4) = make_uint4((u32)eP, (u32)(eP >> 32), (u32)eM, (u32)(eM >> 32));
             }
         }
-        m.PP[v] = tt[i].x;
-        m.PM[v] = tt[i].y;
+        if (v >= kPad + 1 - kHW && v <= kPad + nt + kHW) {
+            m.PP[v - lean_lds<NP>::kPOff] = tt[i].x;
+            m.PM[v - lean_lds<NP>::kPOff] = tt[i].y;
+        }
     }
     return bad;
 }
@@ -321,7 +327,7 @@ __device__ __forceinline__ bool lean_cd_base(const lean_mem<NP> &m, const lean_a
             const u32 cmin = max(max(x1 & 0xffffu, x2 & 0xffffu), x3 & 0xffffu);  // 0xffff - min
             const u32 mx = max(max(x1 >> 16, x2 >> 16), x3 >> 16);
             const double tsum = (double)((S + cmin) - mx - 0xffffu);  // S - min - max
-            const double *P = (strand ? m.PM : m.PP) + (kPad + t + 1 - kHW);  // P[v-hw .. v+hw-1]
+            const double *P = (strand ? m.PM : m.PP) + (kPad + t + 1 - kHW - lean_lds<NP>::kPOff);  // P[v-hw .. v+hw-1]
             double q = P[0];
 #pragma unroll
             for (int j = 1; j < 2 * kHW; ++j) q += P[j];  // left to right, like predict.h:43-47
