@@ -132,7 +132,8 @@ def traffic_probe(argv_cfg, timeout_s=100):
             cmd = [prof, "--pmc"] + pmc + ["--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.abspath(__file__)] + argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                                                             "--no-other-mode", "--no-heavy", "--no-posterior",
-                                                            "--no-traffic-probe", "--no-box-stream"]
+                                                            "--no-traffic-probe", "--no-box-stream", "--no-config-legs",
+                                                            "--no-issue-probe"]
             child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
                                      start_new_session=True)
             try:
@@ -272,7 +273,7 @@ def issue_probe(argv_cfg, timeout_s=150):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def run_config_legs(steps_by_cfg, timeout_s=170):
+def run_config_legs(steps_by_cfg, timeout_s=170, extra_args=()):
     """The other BASELINE configurations beside the headline, each a child run of this script (started
     before this process touches the GPU, one after the other): its own buffers, its own parity spot check,
     its own roofline block for ITS dominant kernel.  Returns {config: summary}."""
@@ -283,7 +284,7 @@ def run_config_legs(steps_by_cfg, timeout_s=170):
         # (a 1 - 2 ms step rides on the clock's ramp out of idle -- the same leg gave 1.8 to 2.5 ms with ten untimed
         # steps: a quarter of a second of them first; config 5's 30 ms steps need two)
         cmd = [sys.executable, os.path.abspath(__file__), "--config", cid, "--steps", str(steps), "--warmup", "2" if cid == "5" else "150",
-               "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-config-legs"]
+               "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-config-legs"] + list(extra_args)
         t0 = time.perf_counter()
         try:
             child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, start_new_session=True)
@@ -470,6 +471,8 @@ def main():
     ap.add_argument("--no-config-legs", action="store_true",
                     help="N=1, default config: do not run the other BASELINE configurations (2, 4, 5) as child runs reported "
                          "under `configs`")
+    ap.add_argument("--leg-intervals", type=int, default=0,
+                    help="tests: run the configuration legs on this many intervals each (and allow them beside --intervals)")
     ap.add_argument("--no-issue-probe", action="store_true",
                     help="config 5: do not read the SQ counters of the FDR kernels in a child run under rocprofv3")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the assembly of the p-value track (same as --assembly none)")
@@ -520,9 +523,12 @@ def main():
         issue = issue_probe(["--config", args.config, "--nb-mode", args.nb_mode])
     # ... and the other BASELINE configurations, each a child run with its own line (reported under `configs`)
     legs = None
-    if (world == 1 and args.config == "3" and not args.no_config_legs and not args.intervals and not args.hotspots
-            and args.scales is None and args.nb_mode == "memo"):
-        legs = run_config_legs([("2", 100), ("4", 100), ("5", 6)])
+    if (world == 1 and args.config == "3" and not args.no_config_legs and (not args.intervals or args.leg_intervals)
+            and not args.hotspots and args.scales is None and args.nb_mode == "memo"):
+        extra = []
+        if args.leg_intervals:  # (tests: small legs, no counter passes)
+            extra = ["--intervals", str(args.leg_intervals), "--no-traffic-probe", "--no-issue-probe"]
+        legs = run_config_legs([("2", 100), ("4", 100), ("5", 6)], extra_args=extra)
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
@@ -974,6 +980,8 @@ def main():
                         kernel_ms=k_ms, launch_sequence_ms=float(np.mean(seq_ms)),
                         algorithmic_bytes_per_launch=total * (rd + wr),
                         traffic_bytes_per_launch=traffic_bytes,
+                        # measured HBM bytes over the algorithmic ones: ~1.0 says nothing is read or written twice
+                        traffic_over_algorithmic=(traffic_bytes / (total * (rd + wr)) if traffic_bytes else None),
                         # HBM bytes per launch from the PMC counters -- read by this invocation in two
                         # child runs under rocprofv3 (traffic_probe), else the same measurement made
                         # earlier (profiles/traffic.json) -- over this run's kernel time

@@ -49,3 +49,23 @@ def test_bench_config5_allgather_and_posterior_one_rank():
     post = d["posterior"]
     assert post["n_datasets"] == 8 and post["parity_ok"] is True and post["zero_division_flags"] == 0
     assert post["value"] > 1e7
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_every_configuration():
+    """the default invocation's line (here on small interval counts): config 3 at the top level and a `configs`
+    object with configs 2, 3, 4 and 5, each with its own step time, parity check and a roofline block for its own
+    dominant kernel -- config 5's names the FDR draw kernels and an issue bound, not the scan's HBM bytes"""
+    d = _bench(["--intervals", "20000", "--leg-intervals", "20000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                "--no-other-mode", "--no-heavy", "--no-traffic-probe"], {})
+    assert d["config"]["workload"].startswith("20000x1kb_5scales") and set(d["configs"]) == {"2", "3", "4", "5"}
+    for cid, leg in d["configs"].items():
+        assert "error" not in leg, (cid, leg)
+        assert leg["ms_per_step"] > 0 and leg["value"] > 1e8 and leg["parity"]["exp_bit_exact"] is True, cid
+        assert leg["parity"]["p_max_rel_err"] < 1e-6 and leg["roofline"]["bound"] in ("hbm", "valu+lds issue"), cid
+    assert d["configs"]["3"]["ms_per_step"] == d["ms_per_step"]
+    c5 = d["configs"]["5"]
+    assert c5["roofline"]["bound"] == "valu+lds issue" and "k_fdr" in c5["roofline"]["kernel"]
+    assert c5["roofline"]["scan"]["bound"] == "hbm" and c5["fdr"]["ms_per_call"] > 0 and c5["parity"]["efdr_max_abs_err"] <= 2.5 / (50 * 100)
+    assert c5["posterior"]["parity_ok"] is True
+    assert d["configs"]["4"]["workload"].startswith("20000xragged")
