@@ -668,6 +668,101 @@ def test_full_size_config3_properties(fpt, orc):
         d.free()
 
 
+def test_full_size_config4_config5_properties(fpt, orc):
+    """BASELINE configs 4 and 5 at one GPU's full share -- 437,500 ragged intervals (lognormal lengths, 50 .. 2000
+    bases, 7.1e7 bases: what bench.py times), config 5 with four per-interval dispersion models and the
+    empirical FDR at 100 null draws per base.  Size-independent properties: (1) sampled intervals -- the
+    shortest, the longest, the limits of the size classes, random ones -- equal the oracle (exp / obs bit for
+    bit, p and window p to 1e-6; the efdr equal to the oracle's restatement of the sampler, count for count);
+    (2) the launches are idempotent; (3) the batch cut in two where `shard_intervals` cuts it for two ranks
+    checksums, track by track, to the whole -- the scan's four tracks and, the null draws being keyed by the
+    GLOBAL base index, the FDR track too."""
+    from footprint_tools_amd import _lib
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = fpt.get_ctx()
+    hw, shw, clip, scales, times, n_models = 5, 50, 0.01, (3,), 100, 4
+    pad2 = 2 * (hw + shw)
+
+    def variant(k):  # bench.py's per-interval models: DM-SYNTH-A with scaled 1/r
+        r = np.array(lat["r_A"], dtype=np.float64)
+        r[5:] *= 1.0 + 0.15 * k
+        return _DM(lat["mu_A"], r)
+    models = [variant(k) for k in range(n_models)]
+    n_iv = 437500
+    lens = np.clip(np.random.RandomState(4).lognormal(4.9, 0.62, n_iv), 50, 2000).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(off[-1])
+    t8 = total * 8
+    ids = (((np.arange(n_iv, dtype=np.int64) * 2654435761) >> 7) % n_models).astype(np.int32)
+    for cfg, mods in (("4", models[0]), ("5", models)):
+        sc = FootprintScanner(table, mods, hw, shw, clip, scales, nb_mode="memo")
+        n_c, n_s = sc.input_sizes(n_iv, total)
+        d_cp, d_cm, d_sq = DeviceArray(ctx, n_c * 8), DeviceArray(ctx, n_c * 8), DeviceArray(ctx, n_s)
+        _lib.check(ctx.L.fpt_synth_dev(ctx.h, 1, 0, n_c, d_cp.ptr, d_cm.ptr, 0, n_s, d_sq.ptr))
+        d_off = DeviceArray(ctx, off.nbytes).upload(off)
+        d_dm = DeviceArray(ctx, ids.nbytes).upload(ids) if cfg == "5" else None
+        n_tr = 5 if cfg == "5" else 4   # exp, obs, p, winp (+ efdr)
+        d_out = DeviceArray(ctx, n_tr * t8)
+
+        def run(a, b, dst, tot8, base0):
+            """intervals [a, b) of the job into tracks of tot8 bytes each at dst"""
+            o = (off[a:b + 1] - off[a]).astype(np.int64)
+            d_o = d_off if (a, b) == (0, n_iv) else DeviceArray(ctx, o.nbytes).upload(o)
+            c0, s0 = int(off[a]) + a * (pad2 + 1), int(off[a]) + a * (pad2 + 7)
+            dm = d_dm.ptr + a * 4 if d_dm else None
+            sc.scan_dev(b - a, d_cp.ptr + c0 * 8, d_cm.ptr + c0 * 8, d_sq.ptr + s0, dst, dst + tot8, dst + 2 * tot8,
+                        dst + 3 * tot8, interval_off_dev=d_o.ptr, interval_off_host=o, dm_ids_dev=dm)
+            if cfg == "5":
+                sc.fdr_dev(b - a, dst, dst + 3 * tot8, dst + 4 * tot8, times=times, seed=1, half_win_width=3,
+                           interval_off_dev=d_o.ptr, base_index0=base0, dm_ids_dev=dm, obs=dst + tot8, interval_off_host=o)
+            ctx.synchronize()
+            if d_o is not d_off:
+                d_o.free()
+
+        run(0, n_iv, d_out.ptr, t8, 0)
+        sums = [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(n_tr)]
+        # (1) sampled intervals against the oracle
+        rs = np.random.RandomState(9)
+        picks = {0, n_iv - 1, int(np.argmin(lens)), int(np.argmax(lens))}
+        for target in (128, 129, 192, 193, 256, 257, 512, 513, 1024):  # an interval at / just past a class limit
+            hit = np.where(lens == target)[0]
+            if hit.size:
+                picks.add(int(hit[0]))
+        picks |= set(int(x) for x in rs.randint(0, n_iv, 6))
+        for iv in sorted(picks):
+            Li, li = int(lens[iv]), int(lens[iv]) + pad2 + 1
+            c0, s0, o0 = int(off[iv]) + iv * (pad2 + 1), int(off[iv]) + iv * (pad2 + 7), int(off[iv])
+            cp, cm, sq = orc.synth_counts(1, c0, li, 0), orc.synth_counts(1, c0, li, 1), orc.synth_bases(1, s0, li + 6)
+            m = models[int(ids[iv])] if cfg == "5" else models[0]
+            e, o, p, wp = orc.detect_batch(cp, cm, sq, 1, Li, hw, shw, clip, table, m.mu_params, m.r_params, np.array(scales, np.int32))
+            assert np.array_equal(d_out.download(np.float64, Li, o0 * 8), e), (cfg, iv)
+            assert np.array_equal(d_out.download(np.float64, Li, t8 + o0 * 8), o), (cfg, iv)
+            assert rel_err(d_out.download(np.float64, Li, 2 * t8 + o0 * 8), p) < P_TOL, (cfg, iv)
+            assert rel_err(d_out.download(np.float64, Li, 3 * t8 + o0 * 8), wp[0]) < P_TOL, (cfg, iv)
+            if cfg == "5" and Li <= 600:  # (the oracle draws L x 100 values per interval on one core)
+                want = orc.fdr_null(m.mu_params, m.r_params, e, wp[0], 3, times, seed=1, base0=o0)
+                got = d_out.download(np.float64, Li, 4 * t8 + o0 * 8)
+                assert np.max(np.abs(got - want)) <= 2.5 / (Li * times), (cfg, iv, float(np.max(np.abs(got - want))))
+        # (2) idempotence
+        run(0, n_iv, d_out.ptr, t8, 0)
+        assert [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(n_tr)] == sums, cfg
+        # (3) the two shards of a two-rank job checksum to the whole
+        bounds = shard_intervals(lens, 2, hw + shw)
+        part = [0] * n_tr
+        for a, b in bounds:
+            tot = int(off[b] - off[a])
+            d_h = DeviceArray(ctx, n_tr * tot * 8)
+            run(a, b, d_h.ptr, tot * 8, int(off[a]))
+            for k in range(n_tr):
+                part[k] = (part[k] + sc.checksum_dev(d_h.ptr + k * tot * 8, tot)) % (1 << 64)
+            d_h.free()
+        assert part == sums, cfg
+        for d in (d_cp, d_cm, d_sq, d_off, d_out) + ((d_dm,) if d_dm else ()):
+            d.free()
+
+
 def test_heavy_tailed_workload(fpt, orc):
     """Hotspot bursts (observed counts up to ~1000, expected counts in the hundreds: far outside the
     256 x 256 first-level table): the first pass hands those tiles to the general kernel, which reads
