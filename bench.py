@@ -211,7 +211,7 @@ def issue_probe(argv_cfg, timeout_s=150):
     try:
         cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + \
             argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-posterior",
-                        "--no-traffic-probe", "--no-box-stream", "--no-config-legs"]
+                        "--no-traffic-probe", "--no-box-stream", "--no-config-legs", "--no-issue-probe"]
         child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
                                  start_new_session=True)
         try:
@@ -403,8 +403,6 @@ def reference_native(cfg, table, DM, cores, budget_s=3.0):
             items.append((cp[i].copy(), cm[i].copy(), np.ascontiguousarray(fwd), np.ascontiguousarray(rev),
                           np.ascontiguousarray(r), np.floor(o) + 1.0, np.ascontiguousarray(r / (r + mu))))
         return items
-
-    ew = [np.empty(l), np.empty(l)]
 
     def native(item):
         cp, cm, fwd, rev, a, b, x = item
