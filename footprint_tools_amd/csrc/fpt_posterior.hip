@@ -71,8 +71,8 @@ __device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, do
 // lane (a wavefront runs the longest).  The factors carry q = mu / (r + mu) with them, so that
 // k log1p(-p) = k log q is part of the same logarithm:
 //     log pmf = log( prod_{j<k} (r + j) q ) - lgam(k + 1) + r log p,     p = r / (r + mu)
-// Every factor lies between q r and (r + k) (with r and mu in [1e-3, 1e12] nothing over- or underflows for
-// k <= kProdMax), the
+// Every factor lies between q r and min(r, mu) + k (with r and mu in [1e-3, 1e12] and one of them below 1e6 nothing
+// over- or underflows for k <= kProdMax), the
 // product is good to k ulps, and where gamma.c's two lgam values cancel (r large) this form is the
 // more accurate one.  Against the reference's expression it differs by ~1e-14 absolute per value
 // (the contract on the posterior is 1e-6 relative; tests/test_gpu_parity.py).  Counts beyond
@@ -80,19 +80,22 @@ __device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, do
 constexpr int kProdMax = 48;
 __device__ __forceinline__ double nb_logpmf_any(double r, double mu, int32_t k, double lg_k1) {
     const double d = r + mu;
-    if ((uint32_t)k <= (uint32_t)kProdMax && r >= 1e-3 && r <= 1e12 && mu >= 1e-3 && mu <= 1e12) {
+    if ((uint32_t)k <= (uint32_t)kProdMax && r >= 1e-3 && r <= 1e12 && mu >= 1e-3 && mu <= 1e12 && (r <= 1e6 || mu <= 1e6)) {
         double inv = __builtin_amdgcn_rcp(d);  // 2^-24, two Newton steps: below an ulp
         inv = fma(fma(-d, inv, 1.0), inv, inv);
         inv = fma(fma(-d, inv, 1.0), inv, inv);
         const double p = r * inv, q = mu * inv, c = r * q;
         double prod = 1.0, fj = 0.0;
         int j = 0;
-        for (; j + 1 < k; j += 2) {  // two factors a trip: (r + j) q = fma(j, q, r q), and the next one is that + q
-            const double t = fma(fj, q, c);
-            prod *= t * (t + q);
-            fj += 2.0;
+        for (; j + 3 < k; j += 4) {  // four factors a trip: (r + j) q = fma(j, q, r q), the next ones that + q each
+            const double t0 = fma(fj, q, c), t1 = t0 + q, t2 = t1 + q, t3 = t2 + q;
+            prod *= (t0 * t1) * (t2 * t3);
+            fj += 4.0;
         }
-        if (j < k) prod *= fma(fj, q, c);
+        for (; j < k; ++j) {
+            prod *= fma(fj, q, c);
+            fj += 1.0;
+        }
         // (the product lies in [1e-150, 1e150] and p in [1e-15, 1): normal positive numbers, what log_pos_fast asks for)
         return (fptm::log_pos_fast(prod) - lg_k1) + r * fptm::log_pos_fast(p);
     }
@@ -117,6 +120,29 @@ __global__ void __launch_bounds__(256) k_posterior_tables(const double *__restri
     const double mu = fptm::fit_mu(mu9, x);
     const double v = nb_logpmf_any(r, mu, k, fptm::lgam((double)fptm::wrap_inc(k)));
     off_table[(size_t)d * kTabExp * kTabObs + i] = zd ? __longlong_as_double(kTabDirectBits) : v;
+}
+
+// The piecewise fits of dispersion.pyx:26-57 are sums of mask x (y + k x) over the segments.  With finite
+// parameters, ascending breakpoints and a finite x exactly one mask is 1 and every other term is an exact zero, so
+// the sum IS the active segment's y + k x (the same two roundings): the segment's index is the number of
+// breakpoints x has reached, and its two parameters are read by that index -- 14 instructions where the sum over
+// five segments is ~70.  A NaN x reaches no breakpoint and gives NaN through segment 0, as the sum does.  Whether
+// a dataset's parameters allow this is decided once per workgroup (`simple_model`); an infinite x (whose inactive
+// terms are 0 x inf = NaN in the reference) sends the wavefront through the sum.
+template <int NSEG>
+__device__ __forceinline__ double piecewise_active(const double *par, double x) {
+#pragma clang fp contract(off)
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < NSEG; ++i) s += x >= par[i] ? 1 : 0;
+    return par[NSEG + s] + par[2 * NSEG + s] * x;
+}
+__device__ __forceinline__ bool simple_model(const double *par24) {
+    bool ok = true;
+    for (int i = 0; i < 24; ++i) ok = ok && fabs(par24[i]) < fptm::kInf;
+    ok = ok && par24[0] <= par24[1];                                                        // mu: x0 <= x1 (x2 unused)
+    ok = ok && par24[9] <= par24[10] && par24[10] <= par24[11] && par24[11] <= par24[12];   // r: x0 .. x3 (x4 unused)
+    return ok;
 }
 
 // np.max(np.vstack([a, b]), axis=0) of two values: NaN wins (posterior.py:72)
@@ -146,9 +172,10 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     const bool staged = D <= kPostLdsModels;
     double *lp = smem;                              // [2 buffers][on, off][NT]
     double *stage = lp + 4 * NT;                    // [NT][kPostChunk + 1]: the posteriors of a chunk of datasets
-    double *par_lds = stage + NT * (kPostChunk + 1);// D x 24, D x 2 (when staged)
+    double *par_lds = stage + NT * (kPostChunk + 1);// D x 24, D x 2, then D flags (when staged)
     const double *par = staged ? par_lds : a.models;
     const double *beta = staged ? par_lds + (size_t)D * 24 : a.betas;
+    int *simple_lds = reinterpret_cast<int *>(par_lds + (size_t)D * 26);  // (only when staged)
     const int tid = threadIdx.x;
     const int64_t iv = blockIdx.x;
     int64_t off;
@@ -168,6 +195,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     if (staged) {
         for (int i = tid; i < D * 24; i += NT) par_lds[i] = a.models[i];
         for (int i = tid; i < D * 2; i += NT) par_lds[(size_t)D * 24 + i] = a.betas[i];
+        for (int i = tid; i < D; i += NT) simple_lds[i] = simple_model(a.models + (size_t)i * 24) ? 1 : 0;
         __syncthreads();
     }
 
@@ -222,6 +250,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
         for (int d = 0; d < D; ++d, ++round) {
             double *lp_on = lp + (size_t)(round & 1) * 2 * NT, *lp_off = lp_on + NT;
             double v_on = 0.0, v_off = 0.0;
+            const bool simple_d = staged && simple_lds[d] != 0;  // (the same for every lane)
             if (valid) {
                 const int64_t j = (int64_t)d * T + g;
                 const double o = a.obs[j], e = a.exp[j];
@@ -244,8 +273,21 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                 for (int s = same ? 2 : 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
                     if (s == 1 && !need_off) break;
                     const double x = s == 0 ? e * delta : e;
-                    const double r = fptm::fit_r(r15, x, &zero_div);
-                    const double mu = fptm::fit_mu(mu9, x);
+                    double r, mu;
+                    if (simple_d && __builtin_amdgcn_ballot_w64(!(fabs(x) < fptm::kInf) && x == x) == 0ull) {
+                        const double vr = piecewise_active<5>(r15, x);  // fit_r / fit_mu (dispersion.pyx:127-163) on it
+                        const double ir = 1.0 / vr;
+                        r = ir > 0.0 ? ir : 1e-6;
+                        if (vr == 0.0) {
+                            zero_div = true;
+                            r = NAN;
+                        }
+                        const double vm = piecewise_active<3>(mu9, x);
+                        mu = vm > 0.0 ? vm : 0.1;
+                    } else {
+                        r = fptm::fit_r(r15, x, &zero_div);
+                        mu = fptm::fit_mu(mu9, x);
+                    }
                     const double v = nb_logpmf_any(r, mu, k, lg_k1);
                     if (s == 0) v_on = v; else v_off = v;
                 }
@@ -306,7 +348,7 @@ size_t posterior_table_bytes(int n_datasets) {
 }
 
 size_t posterior_lds_bytes(int n_datasets, int nt) {
-    return (size_t)((n_datasets <= kPostLdsModels ? n_datasets * 26 : 0) + 4 * nt + nt * (kPostChunk + 1)) * sizeof(double);
+    return (size_t)((n_datasets <= kPostLdsModels ? n_datasets * 27 : 0) + 4 * nt + nt * (kPostChunk + 1)) * sizeof(double);
 }
 
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
