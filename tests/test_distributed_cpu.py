@@ -124,6 +124,47 @@ def test_shard_and_allgather_two_ranks_gloo(tmp_path, mode):
     assert "OK " + mode in out.stdout
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_shard_and_allgather_many_ranks_gloo(tmp_path, world):
+    """the same with 4 and 8 ranks (the node's N = 4 and N = 8): ragged shards, the all-gather, a gather to every
+    root in turn, and the sharded driver's records -- 41 intervals over 8 ranks leaves shards of 4 - 6 intervals"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FPT_ROOT=ROOT, FPT_MODE="ragged", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "OK ragged" in out.stdout
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_shard_intervals_properties(world):
+    """`scan.shard_intervals` on the whole-genome shape (3.5 M lognormal lengths) and on degenerate lists: the
+    ranges are contiguous, in order and cover the list; every rank's padded bases are within one interval of the
+    ideal share; fewer intervals than ranks leaves the surplus ranks empty; offsets and sizes agree with them"""
+    from footprint_tools_amd.distributed import shard_offsets, shard_track_sizes
+    from footprint_tools_amd.scan import shard_intervals
+    pad = 55
+    lens = np.clip(np.random.RandomState(4).lognormal(4.9, 0.62, 3500000), 50, 2000).astype(np.int64)
+    b = shard_intervals(lens, world, pad)
+    assert len(b) == world and b[0][0] == 0 and b[-1][1] == lens.size
+    assert all(b[r][1] == b[r + 1][0] for r in range(world - 1)) and all(x <= y for x, y in b)
+    cost = lens + 2 * pad + 1
+    share = cost.sum() / world
+    got = np.array([cost[x:y].sum() for x, y in b])
+    assert np.all(np.abs(got - share) <= 2 * cost.max()), (got - share)
+    sizes = shard_track_sizes(lens, b)
+    off = shard_offsets(sizes)
+    assert sum(sizes) == lens.sum() and off[0] == 0 and off[-1] == lens.sum() and np.all(np.diff(off) == sizes)
+    # a uniform batch given as (n, L), and lists shorter than the number of ranks
+    bu = shard_intervals((1000003, 500), world, pad)
+    assert bu[-1][1] == 1000003 and max(y - x for x, y in bu) - min(y - x for x, y in bu) <= 1
+    for n in (0, 1, world - 1):
+        bs = shard_intervals(np.full(max(n, 0), 100), world, pad)
+        assert len(bs) == world and bs[-1][1] == n and sum(y - x for x, y in bs) == n
+
+
 def test_id_rendezvous_ignores_leftovers(tmp_path):
     """The file rendezvous of TrackComm (rank 0 offers the 128-byte communicator id, the others wait
     for it): a leftover of an aborted run under the same name is never taken for the id -- an
