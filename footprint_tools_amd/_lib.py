@@ -23,7 +23,7 @@ EXPORTS = [
     "fpt_kmer_probs", "fpt_predict", "fpt_nb_values", "fpt_nb_scalar", "fpt_window", "fpt_special",
     "fpt_scan_dev", "fpt_scan_stats", "fpt_synth_dev", "fpt_synth_hotspots_dev", "fpt_checksum_dev", "fpt_dev_alloc", "fpt_dev_free",
     "fpt_dev_zero", "fpt_format_stats", "fpt_format_stats_batch", "fpt_memcpy_h2d", "fpt_memcpy_d2h", "fpt_last_scan_ms", "fpt_timing_enable", "fpt_timing_read", "fpt_mark", "fpt_mark_elapsed", "fpt_marks_clear",
-    "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
+    "fpt_bam_open", "fpt_bam_close", "fpt_bam_n_refs", "fpt_bam_ref", "fpt_bam_read", "fpt_bam_has_index", "fpt_bam_seek_region", "fpt_bam_read_raw", "fpt_cut_counts_dev", "fpt_seq_gather_dev",
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
     "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize", "fpt_comm_info",

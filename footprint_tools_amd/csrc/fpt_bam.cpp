@@ -390,5 +390,46 @@ int fpt_bam_read(fpt_bam *b, int64_t max_reads, int32_t *ref_id, int32_t *ref_st
     return FPT_OK;
 }
 
+// The records themselves (SAM/BAM specification 4.2: every record behind its 4-byte block_size), for what needs
+// more of an alignment than its coordinates -- the allelically resolved counts (cutcounts.py:315-488) read a
+// read's name, mate flags, template length, bases, base qualities and its NM / XM tag.  Same walk, same region
+// rule and the same checks as fpt_bam_read; a record is handed over whole or not at all.
+int fpt_bam_read_raw(fpt_bam *b, int64_t max_reads, uint8_t *buf, int64_t cap, int64_t *n_out, int64_t *bytes_out) {
+    if (!b || !n_out || !bytes_out || max_reads < 0 || cap < 0 || (cap > 0 && !buf))
+        return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
+    int64_t n = 0, used = 0;
+    while (n < max_reads) {
+        if (b->in_region && b->region_done) break;
+        if (!b->need(4)) break;
+        int32_t block;  // (looked at, not consumed: need() drops consumed bytes when it inflates more)
+        std::memcpy(&block, b->out.data() + b->out_pos, 4);
+        if (block < 32 || block > (1 << 28) || !b->need(4 + (size_t)block)) {
+            if (b->error.empty()) b->error = "truncated or damaged alignment record";
+            break;
+        }
+        const unsigned char *rec = b->out.data() + b->out_pos;
+        int32_t rid, pos;
+        std::memcpy(&rid, rec + 4, 4);
+        std::memcpy(&pos, rec + 8, 4);
+        if (b->in_region && (rid != b->region_rid || (int64_t)pos >= b->region_end)) {
+            b->region_done = true;
+            b->out_pos += 4 + (size_t)block;
+            break;
+        }
+        if (used + 4 + (int64_t)block > cap) {  // no room: the record stays for the next call
+            if (n == 0) return fpt_internal_fail(FPT_ERR_INVALID, "buffer of %lld bytes cannot hold a record of %d", (long long)cap, block);
+            break;
+        }
+        std::memcpy(buf + used, rec, 4 + (size_t)block);
+        used += 4 + (int64_t)block;
+        b->out_pos += 4 + (size_t)block;
+        ++n;
+    }
+    *n_out = n;
+    *bytes_out = used;
+    if (!b->error.empty()) return fpt_internal_fail(FPT_ERR_INVALID, "%s", b->error.c_str());
+    return FPT_OK;
+}
+
 #pragma GCC visibility pop
 }

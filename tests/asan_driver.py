@@ -22,6 +22,7 @@ L.fpt_last_error.restype = C.c_char_p
 L.fpt_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
 L.fpt_bam_close.argtypes = [vp]
 L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+L.fpt_bam_read_raw.argtypes = [vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
 L.fpt_format_stats.argtypes = [C.c_char_p, i64, vp, i64, i32, vp, i64, C.c_char, i32, vp, i64, C.POINTER(i64)]
 L.fpt_track_open.argtypes = [C.c_char_p, C.POINTER(vp)]
 L.fpt_track_close.argtypes = [vp]
@@ -60,6 +61,27 @@ def read_all(path, batch=500):
         if rc2 or got.value == 0:
             break
     L.fpt_bam_close(h)
+    # the same file once more through the whole-record reader, into a buffer that holds a few records at a time
+    # (every record must come out whole: its block_size says how many bytes follow)
+    h = vp()
+    if L.fpt_bam_open(path.encode(), C.byref(h)) == 0:
+        buf = (C.c_uint8 * 700)()
+        raw_total = 0
+        while True:
+            got, used = i64(), i64()
+            rc3 = L.fpt_bam_read_raw(h, batch, buf, 700, C.byref(got), C.byref(used))
+            if rc3 or got.value == 0:
+                break
+            at = 0
+            for _ in range(got.value):
+                block = struct.unpack_from("<i", buf, at)[0]
+                assert block >= 32 and at + 4 + block <= used.value
+                at += 4 + block
+            assert at == used.value
+            raw_total += got.value
+        if rc2 == 0 and rc3 == 0:
+            assert raw_total == total, (raw_total, total)
+        L.fpt_bam_close(h)
     return 0, rc2, total
 
 

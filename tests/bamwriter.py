@@ -17,7 +17,7 @@ def _bgzf_block(data):
 
 def write_bam(path, references, reads, block_bytes=3000, index=False):
     """references: [(name, length)]; reads: dicts with ref (index), pos, cigar ("50M2D10M"), flag, mapq
-    and optionally name.  index=True also writes <path>.bai (reads must be sorted by (ref, pos)): the
+    and optionally name, next_ref / next_pos / tlen, seq (bases), qual (one value or a list) and tags ({"NM": 1}).  index=True also writes <path>.bai (reads must be sorted by (ref, pos)): the
     linear index of the SAM specification 5.2, and per reference one bin holding one chunk that covers
     all of its alignments -- a reader that walks the bins finds every alignment, just not quickly."""
     rec_at = []  # (uncompressed offset of the record, ref, pos, end)
@@ -40,7 +40,17 @@ def write_bam(path, references, reads, block_bytes=3000, index=False):
         rec = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), r["mapq"], 4680, len(ops), r["flag"], l_seq,
                           r.get("next_ref", -1), r.get("next_pos", -1), r.get("tlen", 0))
         rec += name + b"".join(struct.pack("<I", v) for v in ops)
-        rec += b"\x11" * ((l_seq + 1) // 2) + b"\x28" * l_seq
+        if "seq" in r:  # bases (4 bits each: "=ACMGRSVTWYHKDBN"), qualities, integer tags
+            seq = r["seq"]
+            assert len(seq) == l_seq, "seq does not match the CIGAR"
+            codes = ["=ACMGRSVTWYHKDBN".index(ch) for ch in seq] + [0]
+            rec += bytes((codes[2 * i] << 4) | codes[2 * i + 1] for i in range((l_seq + 1) // 2))
+            q = r.get("qual", 40)
+            rec += bytes([q] * l_seq) if isinstance(q, int) else bytes(q)
+        else:
+            rec += b"\x11" * ((l_seq + 1) // 2) + b"\x28" * l_seq
+        for tag, val in (r.get("tags") or {}).items():
+            rec += tag.encode() + (b"C" + struct.pack("<B", val) if 0 <= val < 256 else b"i" + struct.pack("<i", val))
         span = sum(v >> 4 for v in ops if (v & 0xf) in (0, 2, 3, 7, 8))
         rec_at.append((len(out), r["ref"], r["pos"], r["pos"] + max(span, 1)))
         out += struct.pack("<i", len(rec)) + rec
