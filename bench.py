@@ -206,21 +206,29 @@ def issue_probe(argv_cfg, timeout_s=150):
         return None
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     counters = ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"]
+    # (a pass of its own for the texture addresser -- the sampler's table gathers go through it: counters of
+    # another block, and a pass that fails takes only its own figure with it)
+    ta_counters = ["TA_TA_BUSY_sum", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
     out = tempfile.mkdtemp(prefix="fpt_pmc_", dir=env["TMPDIR"])
+    out_ta = tempfile.mkdtemp(prefix="fpt_pmc_ta_", dir=env["TMPDIR"])
     calls = 3
-    try:
-        cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + \
+
+    def counter_run(ctrs, where, limit):
+        cmd = [prof, "--pmc"] + ctrs + ["--output-format", "csv", "-d", where, "--", sys.executable, os.path.abspath(__file__)] + \
             argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-posterior",
                         "--no-traffic-probe", "--no-box-stream", "--no-config-legs", "--no-issue-probe"]
         child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
                                  start_new_session=True)
         try:
-            if child.wait(timeout=timeout_s) != 0:
-                return None
+            return child.wait(timeout=limit) == 0
         except subprocess.TimeoutExpired:
             os.killpg(child.pid, signal.SIGKILL)
             child.wait()
+            return False
+    try:
+        if not counter_run(counters, out, timeout_s):
             return None
+        have_ta = counter_run(ta_counters, out_ta, 60)
 
         def group_of(name):
             m = re.search(r"k_fdr_null<\d+, \w+, \d+, \w+, (\d+)>", name)
@@ -233,21 +241,25 @@ def issue_probe(argv_cfg, timeout_s=150):
             if "k_nb_alias" in name:
                 return "other"
             return None
-        agg = {}
-        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
-            seen = set()
-            for row in csv.DictReader(open(f)):
-                g = group_of(row["Kernel_Name"])
-                if g is None:
-                    continue
-                a = agg.setdefault(g, dict(ns=0.0, dispatches=0))
-                a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                key = row.get("Dispatch_Id")
-                if key not in seen:
-                    seen.add(key)
-                    a["dispatches"] += 1
-                    if "End_Timestamp" in row and "Start_Timestamp" in row:
-                        a["ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        def collect(where):
+            agg = {}
+            for f in glob.glob(os.path.join(where, "**", "*_counter_collection.csv"), recursive=True):
+                seen = set()
+                for row in csv.DictReader(open(f)):
+                    g = group_of(row["Kernel_Name"])
+                    if g is None:
+                        continue
+                    a = agg.setdefault(g, dict(ns=0.0, dispatches=0))
+                    a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    key = row.get("Dispatch_Id")
+                    if key not in seen:
+                        seen.add(key)
+                        a["dispatches"] += 1
+                        if "End_Timestamp" in row and "Start_Timestamp" in row:
+                            a["ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            return agg
+        agg = collect(out)
+        agg_ta = collect(out_ta) if have_ta else {}
         if "draws" not in agg or not agg["draws"].get("GRBM_GUI_ACTIVE"):
             return None
         res = {}
@@ -266,11 +278,18 @@ def issue_probe(argv_cfg, timeout_s=150):
                           lds_bank_conflict_cycles_per_call=a.get("SQ_LDS_BANK_CONFLICT", 0.0) / calls,
                           ms_per_call_under_profiler=a["ns"] / calls * 1e-6, dispatches_per_call=a["dispatches"] / calls,
                           shader_clock_GHz=(cyc / a["ns"] if a["ns"] else None))
+            # texture addresser (one per CU): busy cycles / (256 x cycles of ITS run), and per vector-memory read instruction
+            t = agg_ta.get(g, {})
+            cyc_ta = t.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            res[g]["ta_busy"] = t.get("TA_TA_BUSY_sum", 0.0) / (256.0 * cyc_ta) if cyc_ta > 0 else None
+            res[g]["ta_busy_cycles_per_vmem_read_instruction"] = (t.get("TA_TA_BUSY_sum", 0.0) / t["SQ_INSTS_VMEM_RD"]
+                                                                  if t.get("SQ_INSTS_VMEM_RD") else None)
         return res
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+        shutil.rmtree(out_ta, ignore_errors=True)
 
 
 def run_config_legs(steps_by_cfg, timeout_s=170, extra_args=()):
@@ -1000,7 +1019,11 @@ def main():
                              share_of_step=f_ms / (dt / args.steps * 1e3), kernel_groups=issue,
                              draws_ms=draws_ms)
             scan_roof = roof
+            # (three units near their limits at once, none alone: the vector pipes, LDS, and the texture addresser that
+            # the sampler's two table gathers per draw go through -- `frac` stays the vector pipes' as the review of
+            # round 4 defined it, the other two ride beside it)
             roof = dict(bound="valu+lds issue",
+                        also_near_its_limit="the texture addresser (the sampler's two table gathers per draw): ta_busy",
                         kernel="the null draws of fpt_fdr_dev: k_fdr_null<NT,false,3,true,3> (one workgroup per interval of up to "
                                "256 bases) + k_fdr_slice<192> (slices of longer intervals); set-up k_fdr_null<...,1> before them",
                         achieved=(draws["valu_instructions_per_call"] / (draws_ms * 1e-3) / 1e9 if draws and draws_ms else None),
@@ -1008,13 +1031,16 @@ def main():
                         # = rocprofv3's VALUBusy of the draw kernels: SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles)
                         frac=(draws["valu_busy"] if draws else None), traffic=None,
                         lds_busy=(draws["lds_busy"] if draws else None),
+                        ta_busy=(draws.get("ta_busy") if draws else None),
+                        ta_busy_cycles_per_gather_instruction=(draws.get("ta_busy_cycles_per_vmem_read_instruction") if draws else None),
                         lds_bank_conflict_cycles_per_lds_instruction=(draws["lds_bank_conflict_cycles_per_lds_instruction"]
                                                                       if draws else None),
                         valu_instructions_per_draw=(draws["valu_instructions_per_call"] * 64.0 / (total * fdr_times)
                                                     if draws else None),
                         kernel_ms=draws_ms, fdr_pass_ms=f_ms, shader_clock_GHz=clock,
                         source=("one child run of this command under rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU "
-                                "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE (issue_probe); kernel_ms = "
+                                "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE, a second one with TA_TA_BUSY_sum "
+                                "SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE (issue_probe); kernel_ms = "
                                 "the HIP-event time of the pass x the draw kernels' share of its dispatch time in that run"
                                 if issue else "no counters in this run (rocprofv3 missing, or the run is itself profiled)"),
                         scan=scan_roof)

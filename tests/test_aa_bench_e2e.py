@@ -68,4 +68,6 @@ def test_bench_default_line_carries_every_configuration():
     assert c5["roofline"]["bound"] == "valu+lds issue" and "k_fdr" in c5["roofline"]["kernel"]
     assert c5["roofline"]["scan"]["bound"] == "hbm" and c5["fdr"]["ms_per_call"] > 0 and c5["parity"]["efdr_max_abs_err"] <= 2.5 / (50 * 100)
     assert c5["posterior"]["parity_ok"] is True
+    # (with --leg-intervals the counters are not collected: the fractions are None there, the keys are in the line)
+    assert "ta_busy" in c5["roofline"] and "lds_busy" in c5["roofline"]
     assert d["configs"]["4"]["workload"].startswith("20000xragged")

@@ -9,11 +9,10 @@ OUT=gpurun_out/mempipe_$TAG
 mkdir -p $OUT
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy --no-config-legs --no-issue-probe --no-posterior --no-box-stream $@"
 i=0
+# (the TA stall and flat-wavefront counters are not collectable on this pool: those passes were dropped)
 # (few counters of one block per pass: a request beyond what the hardware collects at once makes rocprofv3 abort
 # and then hang in its signal handler -- every pass runs under its own timeout)
 for grp in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
-           "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-           "TA_FLAT_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum" \
            "TCC_BUSY_avr TCC_REQ_sum TCC_TAG_STALL_sum" \
