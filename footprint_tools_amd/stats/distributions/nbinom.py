@@ -69,3 +69,9 @@ def fit(data, p=None, r=None):
         warnings.simplefilter("ignore")
         root = scipy.optimize.fsolve(mle, np.array([p, r]), args=(data, sm))
     return (root[0], root[1])
+
+
+def rvs(p, r):
+    """nbinom.pyx:174-189: declared and not implemented in the reference either (null counts are drawn by
+    `dispersion_model.sample`)."""
+    raise NotImplementedError

@@ -917,8 +917,31 @@ def g13():
     save("predict_ties.npz", **out)
 
 
+# ---------------------------------------------------------------- G14: Storey q-values (stats/fdr/__init__.py:39-95)
+def g14():
+    """pi0est and qvalue on p-value sets of several shapes.  (bh_qvalue, :98-131, cannot be run: its
+    sorted(iterable, None, key) is Python 2 -- TypeError under Python 3 -- so no expected values exist for it.)"""
+    rs = np.random.RandomState(140)
+    out = {}
+    sets = [rs.uniform(0, 1, 400) ** 2, rs.uniform(0, 1, 1000), np.concatenate([rs.uniform(0, 1e-3, 50), rs.uniform(0, 1, 450)]),
+            rs.beta(0.5, 2.0, 250), np.round(rs.uniform(0, 1, 300), 2), rs.uniform(0.2, 1, 120)]
+    for k, pv in enumerate(sets):
+        out["p%d" % k] = pv
+        out["pi0_%d" % k] = np.asarray(fdr.pi0est(pv), dtype=np.float64).ravel()
+        out["q%d" % k] = np.asarray(fdr.qvalue(pv.copy()), dtype=np.float64)
+    lamb = np.arange(0.1, 0.9, 0.1)
+    out["lamb"] = lamb
+    out["pi0_lamb"] = np.asarray(fdr.pi0est(sets[0], lamb), dtype=np.float64).ravel()
+    try:
+        fdr.bh_qvalue(np.sort(sets[0]))
+        out["bh_runs"] = np.array(1)
+    except TypeError:
+        out["bh_runs"] = np.array(0)
+    save("qvalues.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13", "14"]
     bm, table = g1() if ("1" in which or "5" in which) else (None, None)
     if "2" in which:
         g2()
@@ -944,3 +967,5 @@ if __name__ == "__main__":
         g12()
     if "13" in which:
         g13()
+    if "14" in which:
+        g14()

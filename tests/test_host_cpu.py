@@ -417,3 +417,24 @@ def test_interval_file_and_duck_type(tmp_path):
         q.write_text(bad)
         with pytest.raises(ValueError):
             read_intervals(str(q))
+
+
+def test_qvalues_golden():
+    """Storey's pi0 and q-values (stats/fdr/__init__.py:39-95) against the reference's on six p-value sets
+    (uniform, enriched near zero, rounded to ties, none below 0.2); bh_qvalue -- whose reference body cannot run
+    under Python 3 (the fixture records that) -- against scipy's Benjamini-Hochberg adjustment."""
+    from scipy.stats import false_discovery_control
+    from footprint_tools_amd.stats import fdr
+    g = golden("qvalues.npz")
+    assert int(g["bh_runs"]) == 0
+    for k in range(6):
+        p = g["p%d" % k]
+        assert np.allclose(np.ravel(fdr.pi0est(p)), g["pi0_%d" % k], rtol=1e-13, atol=0)
+        q = fdr.qvalue(p)
+        assert np.allclose(q, g["q%d" % k], rtol=1e-12, atol=0), k
+        bh = fdr.bh_qvalue(p)
+        assert np.allclose(bh, false_discovery_control(p, method="bh"), rtol=1e-12, atol=0), k
+    assert np.allclose(np.ravel(fdr.pi0est(g["p0"], g["lamb"])), g["pi0_lamb"], rtol=1e-13, atol=0)
+    with pytest.raises(ValueError):
+        fdr.bh_qvalue(np.array([0.1, 1.2]))
+    assert fdr.bh_qvalue(np.zeros(0)).size == 0
