@@ -9,11 +9,15 @@
 // Here a workgroup owns a tile of one interval, a lane one base of it (plus `hw` halo bases either
 // side for the likelihood windows), and loops over the datasets twice:
 //   1. the two priors of its base -- counts over datasets, the Beta posterior mean and variance in
-//      closed form (scipy.stats.beta.stats is a/(a+b) and ab/((a+b)^2 (a+b+1)));
-//   2. per dataset: both NB log-pmfs of the base (dispersion.pyx:170-226 -> nbinom.pyx:82-100:
-//      lgam(k+r) - lgam(k+1) - lgam(r) + r log p + k log1p(-p); lgam(k+1) is shared by the two) into
-//      LDS, one barrier, the 2*hw+1 window sums left to right like windowing.h:11-23 (edges 1.0,
-//      windowing.pyx:51), log-sum-exp like numpy's logaddexp, clamp, store.
+//      closed form (scipy.stats.beta.stats is a/(a+b) and ab/((a+b)^2 (a+b+1))), the latter only for the
+//      datasets that are called at the base, each lane working through its own;
+//   2. per chunk of datasets, the occupied log-pmf (exp x delta) of the bases that have a called dataset, the
+//      (base, dataset) pairs dealt out densely over the lanes; then per dataset: both NB log-pmfs of the base
+//      (dispersion.pyx:170-226 -> nbinom.pyx:82-100: lgam(k+r) - lgam(k+1) - lgam(r) + r log p + k log1p(-p);
+//      the unoccupied one from a table) into LDS, one barrier, the 2*hw+1 window sums left to right like
+//      windowing.h:11-23 (edges 1.0, windowing.pyx:51), log-sum-exp like numpy's logaddexp, clamp, store.
+// The kernel runs by the number of wavefronts a CU holds (long dependent fp64 chains, a barrier per dataset): LDS
+// per one-wavefront workgroup is kept at 5.4 KB for that (the posterior kernel).
 // Tracks are dataset-major (D rows of sum(L) bases: lanes read consecutive doubles); the result
 // is base-major (sum(L) rows of D values), which is what the reference's record holds
 // (`post.T`) and what its writer prints per base.
@@ -159,23 +163,23 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {
     return t == t ? r : t;  // NaN
 }
 
-// datasets whose results are staged in LDS before they are stored (one 64-byte piece of a base's row)
-constexpr int kPostChunk = 8;
-// models and Beta priors are staged in LDS up to this many datasets (26 doubles each); beyond it they
-// are read where they lie (one address per wavefront: L1 / L2 hits) -- any number of datasets runs
-constexpr int kPostLdsModels = 128;
+// datasets whose results are staged in LDS before they are stored (one 32-byte piece of a base's row; eight
+// cost 2 KB more LDS per wavefront and with it 8 % of the rate: three workgroups fewer on a CU)
+constexpr int kPostChunk = 4;
 
 template <int NT>
 __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     extern __shared__ double smem[];
     const int D = a.n_datasets, hw = a.hw;
-    const bool staged = D <= kPostLdsModels;
     double *lp = smem;                              // [2 buffers][on, off][NT]
-    double *stage = lp + 4 * NT;                    // [NT][kPostChunk + 1]: the posteriors of a chunk of datasets
-    double *par_lds = stage + NT * (kPostChunk + 1);// D x 24, D x 2, then D flags (when staged)
-    const double *par = staged ? par_lds : a.models;
-    const double *beta = staged ? par_lds + (size_t)D * 24 : a.betas;
-    int *simple_lds = reinterpret_cast<int *>(par_lds + (size_t)D * 26);  // (only when staged)
+    double *stage = lp + 4 * NT;                    // [NT][kPostChunk + 1]: the occupied log-pmfs, then the posteriors of a chunk of datasets
+    double *dl = stage + NT * (kPostChunk + 1);     // [NT]: delta of every lane's base
+    int *blist = reinterpret_cast<int *>(dl + NT);  // [NT] the lanes whose base has delta != 1, then [NT] their count
+    // (the models and the Beta priors are read where they lie -- one address per wavefront in the passes over the
+    // datasets, L1 hits in the dense ones: staged in LDS they were 1.7 KB of a one-wavefront workgroup's 9, and
+    // this kernel runs by the number of wavefronts a CU holds: DESIGN.md section 4)
+    const double *par = a.models;
+    const double *beta = a.betas;
     const int tid = threadIdx.x;
     const int64_t iv = blockIdx.x;
     int64_t off;
@@ -192,11 +196,12 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     // (gridDim.y comes from the LONGEST interval of the batch: a workgroup beyond this interval's tiles
     // leaves before it stages anything -- the same for all of its lanes, so ahead of the barrier)
     if ((int64_t)blockIdx.y * TL >= L) return;
-    if (staged) {
-        for (int i = tid; i < D * 24; i += NT) par_lds[i] = a.models[i];
-        for (int i = tid; i < D * 2; i += NT) par_lds[(size_t)D * 24 + i] = a.betas[i];
-        for (int i = tid; i < D; i += NT) simple_lds[i] = simple_model(a.models + (size_t)i * 24) ? 1 : 0;
-        __syncthreads();
+    // every dataset's fits by their active segment (piecewise_active), or every dataset's by the sums
+    bool all_simple;
+    {
+        int ok = 1;
+        for (int i = tid; i < D; i += NT) ok &= simple_model(a.models + (size_t)i * 24) ? 1 : 0;
+        all_simple = __syncthreads_and(ok) != 0;
     }
 
     bool zero_div = false;
@@ -209,33 +214,48 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
         double pr = 1.0, delta = 1.0;
         if (valid) {
             double k_called = 0.0, n_cov = 0.0, sw = 0.0, swm = 0.0;
-            for (int d = 0; d < D; ++d) {
-#pragma clang fp contract(off)
-                const int64_t j = (int64_t)d * T + g;
-                const double f = a.fdr[j], ww = a.w[j], o = a.obs[j], e = a.exp[j];
-                if (f <= a.cutoff) k_called += 1.0;
-                n_cov += ww;
-                // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean a / s and variance a b / (s^2 (s + 1)),
-                // s = a + b, by the reference's own operations -- delta = sum(w mu) / sum(w) must come out as the
-                // reference's to the bit: with one dataset called it is exactly that dataset's mean (w mu / w), often
-                // a short fraction, and exp x delta then falls ON a breakpoint of the piecewise dispersion fits,
-                // which jump there (a closed form one division shorter moved delta by an ulp and the posterior by
-                // 1e-2: test_posterior_driver_against_the_reference_driver).  What IS left out: a dataset that is not
-                // called here (fdr above the cutoff: weight 0) adds exactly nothing, so its three divisions and
-                // square root are skipped.  scipy returns NaN outside the domain, and 0 x NaN stays NaN
-                // (posterior.py:72-88)
-                const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
-                double wt = 0.0, wm = 0.0;
-                if (!(al > 0.0 && be > 0.0)) {
-                    wm = NAN;
-                    wt = f > a.cutoff ? 0.0 : NAN;
-                } else if (!(f > a.cutoff)) {
-                    const double s = al + be, mu = al / s, var = al * be / ((s * s) * (s + 1.0));
-                    wt = 1.0 / sqrt(var);
-                    wm = wt * mu;
+            // Beta(k + beta_a, n - k + beta_b) with n = max(exp, obs): mean a / s and variance a b / (s^2 (s + 1)),
+            // s = a + b, by the reference's own operations -- delta = sum(w mu) / sum(w) must come out as the
+            // reference's to the bit: with one dataset called it is exactly that dataset's mean (w mu / w), often
+            // a short fraction, and exp x delta then falls ON a breakpoint of the piecewise dispersion fits,
+            // which jump there (a closed form one division shorter moved delta by an ulp and the posterior by
+            // 1e-2: test_posterior_driver_against_the_reference_driver).  What IS left out: a dataset that is not
+            // called here (fdr above the cutoff: weight 0) adds exactly nothing, so its three divisions and
+            // square root are skipped -- and the called ones are few and scattered (a twentieth of the pairs of a
+            // null-like track, yet in nearly every wavefront for every dataset), so a lane notes ITS called
+            // datasets in a mask and then works through them on its own, in ascending order like the reference's
+            // sum: a wavefront makes as many trips as its busiest lane has called datasets (two or three of eight),
+            // not one per dataset.  scipy returns NaN outside the domain, and 0 x NaN stays NaN (posterior.py:72-88):
+            // a NaN term makes the sums NaN wherever it stands, so those are added at once.
+            for (int d0 = 0; d0 < D; d0 += 64) {
+                unsigned long long called = 0ull;
+                const int dn = D - d0 < 64 ? D - d0 : 64;
+                for (int dd = 0; dd < dn; ++dd) {
+                    const int d = d0 + dd;
+                    const int64_t j = (int64_t)d * T + g;
+                    const double f = a.fdr[j], ww = a.w[j], o = a.obs[j], e = a.exp[j];
+                    if (f <= a.cutoff) k_called += 1.0;
+                    n_cov += ww;
+                    const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
+                    if (!(al > 0.0 && be > 0.0)) {
+                        swm += NAN;
+                        sw += f > a.cutoff ? 0.0 : NAN;
+                    } else if (!(f > a.cutoff)) {
+                        called |= 1ull << dd;
+                    }
                 }
-                swm += wm;
-                sw += wt;
+                while (called) {
+#pragma clang fp contract(off)
+                    const int d = d0 + __ffsll((long long)called) - 1;
+                    called &= called - 1ull;
+                    const int64_t j = (int64_t)d * T + g;
+                    const double o = a.obs[j], e = a.exp[j];
+                    const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
+                    const double s = al + be, mu = al / s, var = al * be / ((s * s) * (s + 1.0));
+                    const double wt = 1.0 / sqrt(var);
+                    swm += wt * mu;
+                    sw += wt;
+                }
             }
             const double unocc = n_cov - k_called + a.pseudocount, occ = k_called + a.pseudocount;
             pr = unocc / (unocc + occ);
@@ -243,38 +263,40 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
             if (delta != delta) delta = 1.0;
             if (a.delta_out && tid >= hw && tid < NT - hw) a.delta_out[g] = delta;
         }
+        // the lanes whose base has a called dataset (delta != 1): the occupied form of every dataset is evaluated
+        // for those alone, DENSELY -- below, a chunk of datasets at a time
+        dl[tid] = delta;
+        if (tid == 0) blist[NT] = 0;
+        __syncthreads();
+        const bool busy = valid && delta != 1.0;
+        if (busy) blist[atomicAdd(&blist[NT], 1)] = tid;
+        __syncthreads();
+        const int n_busy = blist[NT];
         const bool mine = valid && tid >= hw && tid < NT - hw;  // an output base of this tile
         const bool inside = mine && u >= hw && u < L - hw;       // its window fits the interval
         const double log_pr = log(pr), log_1mpr = log(1.0 - pr);
         // ---- 2: per dataset, both log-pmfs -> LDS -> window sums -> posterior
         for (int d = 0; d < D; ++d, ++round) {
-            double *lp_on = lp + (size_t)(round & 1) * 2 * NT, *lp_off = lp_on + NT;
-            double v_on = 0.0, v_off = 0.0;
-            const bool simple_d = staged && simple_lds[d] != 0;  // (the same for every lane)
-            if (valid) {
-                const int64_t j = (int64_t)d * T + g;
-                const double o = a.obs[j], e = a.exp[j];
-                const double *mu9 = par + d * 24, *r15 = mu9 + 9;
-                const int32_t k = fptm::c_int(o);
-                const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
-                                         ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
-                // the unoccupied form from the table where (exp, k) is an integer pair inside it
-                const int ei = (int)e;
-                bool need_off = true;
-                if (a.off_table && e >= 0.0 && e < (double)kTabExp && (double)ei == e && (uint32_t)k < (uint32_t)kTabObs) {
-                    v_off = a.off_table[((size_t)d * kTabExp + ei) * kTabObs + k];
-                    need_off = __double_as_longlong(v_off) == kTabDirectBits;
-                }
-                // delta is exactly 1 wherever no dataset is called at the base (most of a real track): the occupied
-                // form is then the unoccupied one, value for value -- the same expression on the same arguments
-                const bool same = delta == 1.0 && !need_off;
-                if (same) v_on = v_off;
-                FPT_NOUNROLL
-                for (int s = same ? 2 : 0; s < 2; ++s) {  // 0: occupied (exp * delta), 1: unoccupied
-                    if (s == 1 && !need_off) break;
-                    const double x = s == 0 ? e * delta : e;
+            if (d % kPostChunk == 0) {
+                // The occupied form (exp x delta: no table) of this chunk of datasets, for the busy lanes' bases: the
+                // (base, dataset) pairs are dealt out to ALL lanes, a pair each -- a third of the bases of a null-like
+                // track are busy, scattered over every wavefront, and evaluated in place each dataset's pass ran
+                // the fits, the product loop and two logarithms for a third of its lanes.  The values wait in `stage`
+                // at the place the base's posterior of that dataset goes to afterwards (same lane, read before
+                // written).  (A barrier first: the rows of the chunk before are being stored from there.)
+                __syncthreads();
+                const int nd = D - d < kPostChunk ? D - d : kPostChunk;
+                for (int q = tid; q < n_busy * nd; q += NT) {
+                    const int bi = q / nd, dd = q - bi * nd;
+                    const int b = blist[bi], dq = d + dd;
+                    const int64_t j = (int64_t)dq * T + off + (t0 - hw + b);
+                    const double o = a.obs[j], x = a.exp[j] * dl[b];
+                    const double *mu9 = par + dq * 24, *r15 = mu9 + 9;
+                    const int32_t k = fptm::c_int(o);
+                    const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
+                                             ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
                     double r, mu;
-                    if (simple_d && __builtin_amdgcn_ballot_w64(!(fabs(x) < fptm::kInf) && x == x) == 0ull) {
+                    if (all_simple && __builtin_amdgcn_ballot_w64(!(fabs(x) < fptm::kInf) && x == x) == 0ull) {
                         const double vr = piecewise_active<5>(r15, x);  // fit_r / fit_mu (dispersion.pyx:127-163) on it
                         const double ir = 1.0 / vr;
                         r = ir > 0.0 ? ir : 1e-6;
@@ -288,9 +310,47 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                         r = fptm::fit_r(r15, x, &zero_div);
                         mu = fptm::fit_mu(mu9, x);
                     }
-                    const double v = nb_logpmf_any(r, mu, k, lg_k1);
-                    if (s == 0) v_on = v; else v_off = v;
+                    stage[b * (kPostChunk + 1) + dd] = nb_logpmf_any(r, mu, k, lg_k1);
                 }
+                __syncthreads();
+            }
+            double *lp_on = lp + (size_t)(round & 1) * 2 * NT, *lp_off = lp_on + NT;
+            double v_on = 0.0, v_off = 0.0;
+            if (valid) {
+                const int64_t j = (int64_t)d * T + g;
+                const double o = a.obs[j], e = a.exp[j];
+                const int32_t k = fptm::c_int(o);
+                // the unoccupied form from the table where (exp, k) is an integer pair inside it
+                const int ei = (int)e;
+                bool need_off = true;
+                if (a.off_table && e >= 0.0 && e < (double)kTabExp && (double)ei == e && (uint32_t)k < (uint32_t)kTabObs) {
+                    v_off = a.off_table[((size_t)d * kTabExp + ei) * kTabObs + k];
+                    need_off = __double_as_longlong(v_off) == kTabDirectBits;
+                }
+                if (need_off) {  // (rare with the tables: a count or an expectation beyond them, a fit that divided by zero)
+                    const double *mu9 = par + d * 24, *r15 = mu9 + 9;
+                    const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
+                                             ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
+                    double r, mu;
+                    if (all_simple && __builtin_amdgcn_ballot_w64(!(fabs(e) < fptm::kInf) && e == e) == 0ull) {
+                        const double vr = piecewise_active<5>(r15, e);
+                        const double ir = 1.0 / vr;
+                        r = ir > 0.0 ? ir : 1e-6;
+                        if (vr == 0.0) {
+                            zero_div = true;
+                            r = NAN;
+                        }
+                        const double vm = piecewise_active<3>(mu9, e);
+                        mu = vm > 0.0 ? vm : 0.1;
+                    } else {
+                        r = fptm::fit_r(r15, e, &zero_div);
+                        mu = fptm::fit_mu(mu9, e);
+                    }
+                    v_off = nb_logpmf_any(r, mu, k, lg_k1);
+                }
+                // delta is exactly 1 wherever no dataset is called at the base (most of a real track): the occupied
+                // form is then the unoccupied one, value for value -- the same expression on the same arguments
+                v_on = busy ? stage[tid * (kPostChunk + 1) + (d % kPostChunk)] : v_off;
             }
             lp_on[tid] = v_on;
             lp_off[tid] = v_off;
@@ -321,8 +381,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
             // The record is base-major -- (sum(L), D), what the reference's writer prints per base -- so a
             // lane's own store would touch one 64-byte piece per lane and dataset (64 lines per store
             // instruction).  A chunk of kPostChunk datasets is staged instead and stored with the lanes
-            // ALONG the rows: eight lanes write the 64 contiguous bytes of a base, a wavefront eight bases
-            // (a whole contiguous 512 bytes when there are eight datasets).
+            // ALONG the rows: four lanes write 32 contiguous bytes of a base, a wavefront sixteen bases.
             if ((d % kPostChunk) == kPostChunk - 1 || d == D - 1) {
                 __syncthreads();
                 const int d0 = d - (d % kPostChunk), nd = d - d0 + 1;
@@ -332,7 +391,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     if (e < nd)
                         a.post_out[(off + t0 + b) * D + d0 + e] = stage[(hw + b) * (kPostChunk + 1) + e];
                 }
-                // (the next chunk's first write to `stage` comes after the next dataset's barrier)
+                // (the next chunk's first write to `stage` comes after a barrier of its own)
             }
         }
     }
@@ -348,7 +407,8 @@ size_t posterior_table_bytes(int n_datasets) {
 }
 
 size_t posterior_lds_bytes(int n_datasets, int nt) {
-    return (size_t)((n_datasets <= kPostLdsModels ? n_datasets * 27 : 0) + 4 * nt + nt * (kPostChunk + 1)) * sizeof(double);
+    (void)n_datasets;
+    return (size_t)(4 * nt + nt * (kPostChunk + 1) + nt + nt / 2 + 1) * sizeof(double);
 }
 
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
