@@ -1180,6 +1180,10 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
     pl.ll_on_out = d->ll_on_out;
     pl.ll_off_out = d->ll_off_out;
     pl.status_out = d->status_out;
+    // the kernel instance without the reference's sums over the segments where every model allows it (the usual case)
+    pl.all_simple = true;
+    for (int i = 0; i < d->n_datasets && pl.all_simple; ++i)
+        pl.all_simple = fptk::posterior_model_simple(d->models ? d->models + (size_t)i * kModelDoubles : c->h_models[d->dm_id + i]);
     // tables of the unoccupied log-pmf and of lgam(k + 1), rebuilt by every call (slot 13)
     // -- where they pay and fit: 65,536 evaluations and 512 KiB per dataset, so a batch of fewer than 16,384
     // bases (the tables would cost more evaluations than they save), more than 4,096 datasets (2 GiB) or a

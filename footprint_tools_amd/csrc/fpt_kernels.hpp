@@ -133,7 +133,9 @@ struct posterior_launch {
     double *prior_out, *delta_out, *ll_on_out, *ll_off_out;
     int32_t *status_out;
     double *off_table, *lgam_table;     // workspace of posterior_table_bytes(): filled by the launch (or both nullptr)
+    bool all_simple;                    // every dataset's model passes posterior_model_simple() (decided on the host's copy)
 };
+bool posterior_model_simple(const double *par24);  // finite parameters, ascending breakpoints: the fits by their active segment
 size_t posterior_table_bytes(int n_datasets);  // off_table: n_datasets x 256 x 256 doubles, then lgam_table: 4096
 size_t posterior_lds_bytes(int n_datasets, int nt);
 hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl);

@@ -26,6 +26,7 @@
 // work, not HBM traffic (40 bytes per dataset-base): see DESIGN.md for the measured rate.
 #include "fpt_kernels.hpp"
 
+#include <cmath>
 #include <cstdlib>
 
 #include "fpt_device.hpp"
@@ -131,8 +132,8 @@ __global__ void __launch_bounds__(256) k_posterior_tables(const double *__restri
 // the sum IS the active segment's y + k x (the same two roundings): the segment's index is the number of
 // breakpoints x has reached, and its two parameters are read by that index -- 14 instructions where the sum over
 // five segments is ~70.  A NaN x reaches no breakpoint and gives NaN through segment 0, as the sum does.  Whether
-// a dataset's parameters allow this is decided once per workgroup (`simple_model`); an infinite x (whose inactive
-// terms are 0 x inf = NaN in the reference) sends the wavefront through the sum.
+// the datasets' parameters allow this is decided once per launch, on the host (`posterior_model_simple`); an x
+// that is not finite is settled in fit_r_mu.
 template <int NSEG>
 __device__ __forceinline__ double piecewise_active(const double *par, double x) {
 #pragma clang fp contract(off)
@@ -140,13 +141,6 @@ __device__ __forceinline__ double piecewise_active(const double *par, double x) 
 #pragma unroll
     for (int i = 0; i + 1 < NSEG; ++i) s += x >= par[i] ? 1 : 0;
     return par[NSEG + s] + par[2 * NSEG + s] * x;
-}
-__device__ __forceinline__ bool simple_model(const double *par24) {
-    bool ok = true;
-    for (int i = 0; i < 24; ++i) ok = ok && fabs(par24[i]) < fptm::kInf;
-    ok = ok && par24[0] <= par24[1];                                                        // mu: x0 <= x1 (x2 unused)
-    ok = ok && par24[9] <= par24[10] && par24[10] <= par24[11] && par24[11] <= par24[12];   // r: x0 .. x3 (x4 unused)
-    return ok;
 }
 
 // np.max(np.vstack([a, b]), axis=0) of two values: NaN wins (posterior.py:72)
@@ -167,7 +161,32 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {
 // cost 2 KB more LDS per wavefront and with it 8 % of the rate: three workgroups fewer on a CU)
 constexpr int kPostChunk = 4;
 
-template <int NT>
+// fit_r / fit_mu (dispersion.pyx:127-163) on x for one dataset.  SIMPLE: by the active segment; an x that is not
+// finite makes every term of the reference's sums NaN (0 x inf in the segments it is not in), which its clamps
+// turn into r = 1e-6 and mu = 0.1 without a ZeroDivisionError.
+template <bool SIMPLE>
+__device__ __forceinline__ void fit_r_mu(const double *mu9, const double *r15, double x, double *r, double *mu, bool *zero_div) {
+    if (SIMPLE) {
+        const double vr = piecewise_active<5>(r15, x);
+        const double ir = 1.0 / vr;
+        *r = ir > 0.0 ? ir : 1e-6;
+        if (vr == 0.0) {
+            *zero_div = true;
+            *r = NAN;
+        }
+        const double vm = piecewise_active<3>(mu9, x);
+        *mu = vm > 0.0 ? vm : 0.1;
+        if (!(fabs(x) < fptm::kInf)) *r = 1e-6, *mu = 0.1;
+    } else {
+        *r = fptm::fit_r(r15, x, zero_div);
+        *mu = fptm::fit_mu(mu9, x);
+    }
+}
+
+// SIMPLE: every dataset's parameters are finite and its breakpoints ascending (posterior_model_simple, decided by the host
+// for the launch): the fits are their active segment, and the reference's sums over the segments -- 16 more
+// registers, a wavefront per SIMD -- are not part of the kernel.
+template <int NT, bool SIMPLE>
 __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     extern __shared__ double smem[];
     const int D = a.n_datasets, hw = a.hw;
@@ -196,13 +215,6 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     // (gridDim.y comes from the LONGEST interval of the batch: a workgroup beyond this interval's tiles
     // leaves before it stages anything -- the same for all of its lanes, so ahead of the barrier)
     if ((int64_t)blockIdx.y * TL >= L) return;
-    // every dataset's fits by their active segment (piecewise_active), or every dataset's by the sums
-    bool all_simple;
-    {
-        int ok = 1;
-        for (int i = tid; i < D; i += NT) ok &= simple_model(a.models + (size_t)i * 24) ? 1 : 0;
-        all_simple = __syncthreads_and(ok) != 0;
-    }
 
     bool zero_div = false;
     int round = 0;               // parity of the LDS buffer across tiles and datasets
@@ -296,20 +308,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
                                              ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
                     double r, mu;
-                    if (all_simple && __builtin_amdgcn_ballot_w64(!(fabs(x) < fptm::kInf) && x == x) == 0ull) {
-                        const double vr = piecewise_active<5>(r15, x);  // fit_r / fit_mu (dispersion.pyx:127-163) on it
-                        const double ir = 1.0 / vr;
-                        r = ir > 0.0 ? ir : 1e-6;
-                        if (vr == 0.0) {
-                            zero_div = true;
-                            r = NAN;
-                        }
-                        const double vm = piecewise_active<3>(mu9, x);
-                        mu = vm > 0.0 ? vm : 0.1;
-                    } else {
-                        r = fptm::fit_r(r15, x, &zero_div);
-                        mu = fptm::fit_mu(mu9, x);
-                    }
+                    fit_r_mu<SIMPLE>(mu9, r15, x, &r, &mu, &zero_div);
                     stage[b * (kPostChunk + 1) + dd] = nb_logpmf_any(r, mu, k, lg_k1);
                 }
                 __syncthreads();
@@ -332,20 +331,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     const double lg_k1 = (a.lgam_table && (uint32_t)k < (uint32_t)kTabLgam)
                                              ? a.lgam_table[k] : fptm::lgam((double)fptm::wrap_inc(k));
                     double r, mu;
-                    if (all_simple && __builtin_amdgcn_ballot_w64(!(fabs(e) < fptm::kInf) && e == e) == 0ull) {
-                        const double vr = piecewise_active<5>(r15, e);
-                        const double ir = 1.0 / vr;
-                        r = ir > 0.0 ? ir : 1e-6;
-                        if (vr == 0.0) {
-                            zero_div = true;
-                            r = NAN;
-                        }
-                        const double vm = piecewise_active<3>(mu9, e);
-                        mu = vm > 0.0 ? vm : 0.1;
-                    } else {
-                        r = fptm::fit_r(r15, e, &zero_div);
-                        mu = fptm::fit_mu(mu9, e);
-                    }
+                    fit_r_mu<SIMPLE>(mu9, r15, e, &r, &mu, &zero_div);
                     v_off = nb_logpmf_any(r, mu, k, lg_k1);
                 }
                 // delta is exactly 1 wherever no dataset is called at the base (most of a real track): the occupied
@@ -402,6 +388,14 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
 
 namespace fptk {
 
+bool posterior_model_simple(const double *par24) {
+    bool ok = true;
+    for (int i = 0; i < 24; ++i) ok = ok && std::fabs(par24[i]) < HUGE_VAL;
+    ok = ok && par24[0] <= par24[1];                                                        // mu: x0 <= x1 (x2 unused)
+    ok = ok && par24[9] <= par24[10] && par24[10] <= par24[11] && par24[11] <= par24[12];   // r: x0 .. x3 (x4 unused)
+    return ok;
+}
+
 size_t posterior_table_bytes(int n_datasets) {
     return ((size_t)n_datasets * kTabExp * kTabObs + kTabLgam) * sizeof(double);
 }
@@ -455,7 +449,8 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     int gy = tiles <= 8 ? 1 : (int)((tiles + 7) / 8);
     if (gy > 65535) gy = 65535;
     const size_t lds = posterior_lds_bytes(pl.n_datasets, nt);
-    void (*kern)(const post_args) = nt == 64 ? k_posterior<64> : (nt == 128 ? k_posterior<128> : k_posterior<256>);
+    void (*kern)(const post_args) = pl.all_simple ? (nt == 64 ? k_posterior<64, true> : (nt == 128 ? k_posterior<128, true> : k_posterior<256, true>))
+                                                   : (nt == 64 ? k_posterior<64, false> : (nt == 128 ? k_posterior<128, false> : k_posterior<256, false>));
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     for (int64_t done = 0; done < pl.n_intervals; done += 0x7fffff00) {

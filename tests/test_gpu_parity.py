@@ -1098,6 +1098,62 @@ def test_posterior_batch_zero_division(fpt):
         posterior.posterior_batch(obs, exp, fdr, w, betas, [ok, zd])
 
 
+@pytest.mark.parametrize("models_kind", ["simple", "unordered"])
+def test_posterior_batch_unusual_tracks_and_models(fpt, orc, models_kind):
+    """expected counts that are not finite, negative, fractional or huge, counts beyond the product form (48) and
+    beyond the lgam table (4,096) -- through the kernel instance whose fits are the active segment (every model
+    finite with ascending breakpoints: an x that is not finite is settled there as the reference's sums settle
+    it) and through the instance with the reference's sums (one model's breakpoints out of order): the oracle's
+    records either way."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    lat = golden("nb_lattice.npz")
+    rs = np.random.RandomState(505)
+    D, hw = 3, 3
+    lens = np.array([70, 130, 9, 64])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(off[-1])
+    pars = [(np.array(lat["mu_" + k], dtype=np.float64), np.array(lat["r_" + k], dtype=np.float64)) for k in "ABC"]
+    if models_kind == "unordered":
+        mu, r = pars[1]
+        r[[0, 2]] = r[[2, 0]]      # breakpoints out of order: two masks of the reference's sum can be 1 at once
+        mu2, r2 = pars[2]
+        mu2[[0, 1]] = mu2[[1, 0]]
+    dms = []
+    for mu, r in pars:
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = mu, r
+        dms.append(dm)
+    exp = np.round(rs.gamma(2.0, 6.0, (D, total)))
+    obs = np.floor(exp * rs.uniform(0.0, 1.6, (D, total)))
+    fdr = rs.uniform(0, 1, (D, total)) ** 4.0
+    w = np.ones((D, total))
+    for d in range(D):
+        pos = rs.choice(total, 14, replace=False)
+        exp[d, pos[:8]] = [np.inf, -np.inf, np.nan, -3.0, 2.5, 1e15, 300.0, 0.0]
+        obs[d, pos[8:]] = [49.0, 60.0, 500.0, 4096.0, 5000.0, 0.0]
+        fdr[d, pos[::3]] = 0.001   # called there: the occupied form of those bases, exp x delta
+    betas = rs.uniform(0.5, 30.0, (D, 2))
+    stats, pc = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw,
+                                          interval_off=off, pieces=True)
+    models = [(mu, r) for mu, r in pars]
+    for a, b in zip(off[:-1], off[1:]):
+        want, wp = orc.posterior_stats(obs[:, a:b], exp[:, a:b], fdr[:, a:b], w[:, a:b], betas, models, cutoff=0.05, hw=hw)
+        assert rel_err(pc["delta"][a:b], wp["delta"]) < 1e-12, (models_kind, a)
+        assert np.allclose(pc["ll_on"][:, a:b], wp["ll_on"], rtol=P_TOL, atol=1e-9, equal_nan=True), (models_kind, a)
+        assert np.allclose(pc["ll_off"][:, a:b], wp["ll_off"], rtol=P_TOL, atol=1e-9, equal_nan=True), (models_kind, a)
+        assert np.allclose(stats[a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True), (models_kind, a)
+    # without the tables: the same bits
+    os.environ["FPT_POSTERIOR_TABLES"] = "0"
+    try:
+        ctx2 = fpt.Context(0)
+    finally:
+        del os.environ["FPT_POSTERIOR_TABLES"]
+    stats2 = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, half_win_width=hw, interval_off=off, ctx=ctx2)
+    ctx2.close()
+    assert np.array_equal(stats, stats2, equal_nan=True)
+
+
 # ---------------------------------------------------------------- A10: empirical FDR on the device
 def _scan_small(orc, n_iv, L, seed, dm="A", bump=None):
     from footprint_tools_amd.scan import FootprintScanner
