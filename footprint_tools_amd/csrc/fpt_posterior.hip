@@ -161,6 +161,21 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {
 // cost 2 KB more LDS per wavefront and with it 8 % of the rate: three workgroups fewer on a CU)
 constexpr int kPostChunk = 4;
 
+// The workgroup's barrier.  A one-wavefront workgroup needs none: its LDS instructions are carried out in the order
+// they were issued, for all lanes at once -- only the compiler has to keep that order.  (`__syncthreads()` also
+// waits for every global load AND store of the wavefront still in flight, which is what a workgroup-wide release
+// asks for; measured: 2 % of this kernel.)
+template <int NT>
+__device__ __forceinline__ void tile_sync() {
+    if (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // fit_r / fit_mu (dispersion.pyx:127-163) on x for one dataset.  SIMPLE: by the active segment; an x that is not
 // finite makes every term of the reference's sums NaN (0 x inf in the segments it is not in), which its clamps
 // turn into r = 1e-6 and mu = 0.1 without a ZeroDivisionError.
@@ -279,10 +294,10 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
         // for those alone, DENSELY -- below, a chunk of datasets at a time
         dl[tid] = delta;
         if (tid == 0) blist[NT] = 0;
-        __syncthreads();
+        tile_sync<NT>();
         const bool busy = valid && delta != 1.0;
         if (busy) blist[atomicAdd(&blist[NT], 1)] = tid;
-        __syncthreads();
+        tile_sync<NT>();
         const int n_busy = blist[NT];
         const bool mine = valid && tid >= hw && tid < NT - hw;  // an output base of this tile
         const bool inside = mine && u >= hw && u < L - hw;       // its window fits the interval
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                 // the fits, the product loop and two logarithms for a third of its lanes.  The values wait in `stage`
                 // at the place the base's posterior of that dataset goes to afterwards (same lane, read before
                 // written).  (A barrier first: the rows of the chunk before are being stored from there.)
-                __syncthreads();
+                tile_sync<NT>();
                 const int nd = D - d < kPostChunk ? D - d : kPostChunk;
                 for (int q = tid; q < n_busy * nd; q += NT) {
                     const int bi = q / nd, dd = q - bi * nd;
@@ -311,7 +326,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     fit_r_mu<SIMPLE>(mu9, r15, x, &r, &mu, &zero_div);
                     stage[b * (kPostChunk + 1) + dd] = nb_logpmf_any(r, mu, k, lg_k1);
                 }
-                __syncthreads();
+                tile_sync<NT>();
             }
             double *lp_on = lp + (size_t)(round & 1) * 2 * NT, *lp_off = lp_on + NT;
             double v_on = 0.0, v_off = 0.0;
@@ -340,7 +355,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
             }
             lp_on[tid] = v_on;
             lp_off[tid] = v_off;
-            __syncthreads();  // the other buffer is free again once every lane is past the NEXT barrier
+            tile_sync<NT>();  // the other buffer is free again once every lane is past the NEXT barrier
             if (mine) {
                 double ll_on = 1.0, ll_off = 1.0;  // windowing.pyx:51: edges keep the 1.0 of np.ones
                 if (inside) {
@@ -369,7 +384,7 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
             // instruction).  A chunk of kPostChunk datasets is staged instead and stored with the lanes
             // ALONG the rows: four lanes write 32 contiguous bytes of a base, a wavefront sixteen bases.
             if ((d % kPostChunk) == kPostChunk - 1 || d == D - 1) {
-                __syncthreads();
+                tile_sync<NT>();
                 const int d0 = d - (d % kPostChunk), nd = d - d0 + 1;
                 const int n_out = min(TL, L - t0);          // output bases of this tile: lanes hw .. hw + n_out - 1
                 for (int i = tid; i < n_out * kPostChunk; i += NT) {
