@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fused per-nucleotide footprint scan on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
     (the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT: bench.py imports no
-    torch; the collective is RCCL bound by the library itself, footprint_tools_amd/distributed.py)
+    torch; the collective is RCCL bound by the library itself, footprint_tools_amd/distributed.py.
+    With --gpus N > 1 and NO launcher around it, bench.py starts its N ranks itself: launch_ranks)
 
 One step = one pass of the hot path (6-mer lookup -> expected cleavage with trimmed-mean
 smoothing -> NB p-value -> Stouffer windows) over one batch of synthetic intervals that is
@@ -375,6 +376,10 @@ def cpu_baseline(cfg, table, DM, budget_s=12.0):
                       "OpenMP over intervals on %d threads, %.1f s; 1-core figure on %d intervals, %.1f s"
                       % (n, L, len(scales), cores, dt, n1, dt1))
     out["reference_native"] = reference_native(cfg, table, DM, cores)
+    # the same figures as plain scalars of this block (nested dicts do not survive every reader of the line)
+    rn = out["reference_native"]
+    out["reference_native_1core"] = rn["value_1core"] if rn else None
+    out["reference_native_allcores"] = rn["value"] if rn else None
     kc = os.path.join(ROOT, "profiles", "k_cal.json")
     if os.path.exists(kc):
         k = json.load(open(kc))
@@ -387,6 +392,9 @@ def cpu_baseline(cfg, table, DM, budget_s=12.0):
                             note="measured in the build container, not on this box: covers the reference's Python-loop "
                                  "overhead only; its native C is timed on this box in reference_native")
         out["implied_reference_1core"] = out["value_1core"] / k["workers_1"]["k_cal"]
+        out["k_cal_1worker"] = k["workers_1"]["k_cal"]
+        out["k_cal_8workers"] = k["workers_8"]["k_cal"]
+        out["k_cal_cpu"] = k.get("cpu_model")
     return out
 
 
@@ -461,6 +469,86 @@ def reference_native(cfg, table, DM, cores, budget_s=3.0):
                        % (len(items), L, len(scales), dt1, len(work), cores, dtn))
 
 
+def launch_ranks(n, argv, timeout_s=None, program=None):
+    """`python3 bench.py --gpus N` with no launcher around it: this process starts the N ranks itself -- the
+    counterpart of the reference's `batch_iter(num_workers=n)` forking its own workers (cli/detect.py:394).
+    Called before anything here has touched the GPU.  Every rank is a fresh `python bench.py <same argv>` in its
+    own session with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run
+    would set; the externally launched form keeps working); rank 0's stdout -- the one JSON line -- is this
+    process's stdout, the other ranks' stdout is dropped, every rank's stderr is this one's.  If a rank fails,
+    or the job outlives FPT_LAUNCH_TIMEOUT_S (default 1800), every rank's process group is killed and the exit
+    code is non-zero.  Returns the exit code.  (`program`: tests start another script in place of this file.)"""
+    import signal
+    import socket
+    import subprocess
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("FPT_LAUNCH_TIMEOUT_S", "1800"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    # the communicator id travels through a file named after this job alone (distributed._id_path)
+    comm_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fpt_comm_bench_%d_%d.id" % (os.getpid(), port))
+    procs = []
+    devnull = open(os.devnull, "wb")
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)  # (start_new_session: pgid == pid)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def on_signal(signum, _frame):
+        kill_all()
+        os._exit(128 + signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.setdefault("FPT_COMM_FILE", comm_file)
+            procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=None if r == 0 else devnull, start_new_session=True))
+        t_end = time.time() + timeout_s
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                live.discard(r)
+                if c != 0:
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other %d ranks\n" % (r, c, len(live)))
+                    rc = c if 0 < c < 256 else 1
+                    live.clear()
+                    break
+            if live and time.time() > t_end:
+                sys.stderr.write("bench.py: ranks %s still running after %.0f s (FPT_LAUNCH_TIMEOUT_S); stopping the job\n"
+                                 % (sorted(live), timeout_s))
+                rc = 124
+                break
+            if live:
+                time.sleep(0.05)
+    finally:
+        kill_all()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        devnull.close()
+        try:
+            os.unlink(comm_file)
+        except OSError:
+            pass
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,9 +595,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus %d must be launched with one process per GPU, e.g. python -m "
-                 "torch.distributed.run --nproc-per-node %d ... (only RANK / LOCAL_RANK / WORLD_SIZE / "
-                 "MASTER_PORT are read; no torch is imported)" % (args.gpus, args.gpus))
+        # no launcher around this process: be the launcher (this process has made no GPU call yet)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus > 1 and args.gpus != world:
+        sys.exit("bench.py --gpus %d inside a job of WORLD_SIZE=%d: the launcher's --nproc-per-node and --gpus "
+                 "must agree" % (args.gpus, world))
     cfg = CONFIGS[args.config]
     if args.intervals:
         cfg = dict(cfg, n_iv=args.intervals, name=cfg["name"].replace(str(cfg["n_iv"]), str(args.intervals), 1))
@@ -1093,6 +1183,16 @@ def main():
                                                         "the next step's scan, two track buffers in turn" % args.assembly)
                                               if dt_asm else None),
                                bases_per_rank=counts,
+                               # how to read `value` against N x the one-GPU value: the K scans are
+                               # communication-free, the ONE assembly at the end moves this rank's shard to every peer over
+                               # that peer's own xGMI link (~50 GB/s one way assumed for a large transfer), so a perfectly
+                               # scaling job still reads K t_scan / (K t_scan + shard_bytes / link) of linear in `value`;
+                               # `scan_only` is the figure weak-scaling efficiency of the path itself is computed from
+                               expected_value_vs_linear=(
+                                   dt_scan / (dt_scan + max(counts) * 8 / 50e9) if (do_gather and world > 1) else 1.0),
+                               expected_value_vs_linear_assumes=dict(link_GBps_one_way=50.0, shard_bytes=max(counts) * 8,
+                                                                     assemblies_in_timed_region=1 if do_gather else 0),
+                               value_over_scan_only=(dt_scan / dt if dt > 0 else None),
                                # ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator and
                                # the PCI bus id of its device, gathered over the communicator (fpt_comm_info)
                                rccl_ranks=(min(j["rccl_count"] for j in job) if job else None), ranks=job,

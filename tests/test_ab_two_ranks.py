@@ -104,3 +104,24 @@ def test_bench_two_ranks_one_gpu(assembly):
     # the communicator's own account of the job: two ranks, each reporting itself
     assert mg["rccl_ranks"] == 2 and [r_["rccl_user_rank"] for r_ in mg["ranks"]] == [0, 1]
     assert all(r_["pci_bus_id"] for r_ in mg["ranks"])
+
+
+@pytest.mark.gpu
+def test_bench_launches_two_ranks_itself():
+    """`python3 bench.py --gpus 2 ...` as ONE command with no launcher around it (what the driver's scaling run is
+    most likely to issue): the parent starts both ranks before touching the GPU (bench.launch_ranks), relays rank 0's
+    one line and exits 0; the line is a two-rank job by the communicator's own account"""
+    _fake()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "FPT_COMM_FILE")}
+    env.update(FPT_RCCL_LIB=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0", FPT_COMM_TIMEOUT_S="120", FPT_LAUNCH_TIMEOUT_S="600")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--intervals", "20000",
+                          "--steps", "3", "--warmup", "1", "--share-gpu"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity"]["exp_bit_exact"] is True and d["parity"]["p_max_rel_err"] < 1e-6
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == 2 and [r_["rccl_user_rank"] for r_ in mg["ranks"]] == [0, 1]
+    assert 0 < mg["expected_value_vs_linear"] < 1 and 0 < mg["value_over_scan_only"] <= 1

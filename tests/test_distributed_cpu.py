@@ -202,3 +202,93 @@ def test_id_rendezvous_ignores_leftovers(tmp_path):
         assert D._id_path() != a
     finally:
         D._comm_counter[0] -= 1
+
+
+LAUNCHED = r'''
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["FPT_COMM_FILE"]
+open(os.path.join(sys.argv[1], "rank%d" % r), "w").write(" ".join(
+    [str(os.getpid()), os.environ["WORLD_SIZE"], os.environ["MASTER_PORT"], os.environ["FPT_COMM_FILE"]] + sys.argv[2:]))
+mode = sys.argv[2]
+if mode == "fail" and r == 3:
+    time.sleep(0.5)
+    sys.exit(3)
+if mode in ("fail", "hang"):
+    time.sleep(600)
+print('{"rank": %d}' % r)
+'''
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fpt_bench_for_tests", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    try:  # a zombie of another parent counts as gone
+        return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_bench_launches_its_own_ranks(tmp_path, capfd):
+    """`python3 bench.py --gpus 8` with no launcher around it starts the eight ranks itself (bench.launch_ranks;
+    the reference's counterpart is batch_iter(num_workers=n), cli/detect.py:394): every rank gets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT and one rendezvous file name, the arguments arrive unchanged, only rank
+    0's standard output reaches the caller's.  A rank that exits 3 stops the job within seconds with a non-zero code
+    and no process left behind; so does a job that outlives its limit."""
+    import time
+    bench = _load_bench()
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED)
+    d = tmp_path / "ok"
+    d.mkdir()
+    rc = bench.launch_ranks(8, [str(d), "ok", "--gpus", "8", "--steps", "2"], program=str(script))
+    out = capfd.readouterr().out
+    assert rc == 0 and out.strip() == '{"rank": 0}'
+    seen = [open(d / ("rank%d" % r)).read().split() for r in range(8)]
+    assert all(s[1] == "8" and s[5:] == ["--gpus", "8", "--steps", "2"] for s in seen)
+    assert len(set(s[2] for s in seen)) == 1 and len(set(s[3] for s in seen)) == 1
+    assert not os.path.exists(seen[0][3])
+
+    d = tmp_path / "fail"
+    d.mkdir()
+    t0 = time.time()
+    rc = bench.launch_ranks(8, [str(d), "fail"], program=str(script))
+    assert rc == 3 and time.time() - t0 < 20
+    pids = [int(open(d / ("rank%d" % r)).read().split()[0]) for r in range(8)]
+    time.sleep(0.2)
+    assert not [p for p in pids if _alive(p)]
+
+    d = tmp_path / "hang"
+    d.mkdir()
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [str(d), "hang"], program=str(script), timeout_s=2.0)
+    assert rc == 124 and time.time() - t0 < 20
+    pids = [int(open(d / ("rank%d" % r)).read().split()[0]) for r in range(2)]
+    time.sleep(0.2)
+    assert not [p for p in pids if _alive(p)]
+
+
+def test_bench_gpus_flag_reaches_the_launcher(tmp_path):
+    """the command the driver would run: `python3 bench.py --gpus 8 ...` as ONE process.  Here (no GPU) the ranks
+    cannot make a context, so each fails -- what is checked is that the parent launches rather than refuses,
+    reports the failing rank and exits non-zero promptly."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["FPT_LAUNCH_TIMEOUT_S"] = "120"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "4", "--intervals", "1000",
+                          "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the launched ranks run (covered by the -m gpu test)")
+    assert out.returncode != 0 and "must be launched" not in out.stderr
+    assert "exited with code" in out.stderr
