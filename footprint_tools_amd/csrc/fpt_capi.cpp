@@ -1195,6 +1195,12 @@ int fpt_posterior_dev(fpt_ctx *c, const fpt_posterior_desc *d) {
             pl.lgam_table = pl.off_table + (size_t)d->n_datasets * 256 * 256;
         }
     }
+    pl.max_len_unknown = d->interval_off && d->max_interval_len <= 0;
+    if (d->interval_off) {  // the list of the long intervals' further chunks (slot 14, shared with the FDR pass's workspace)
+        void *d_plan;
+        if (int rc = ws_get(c, 14, fptk::posterior_plan_bytes(d->total_bases, d->half_win_width), &d_plan)) return rc;
+        pl.plan_ws = d_plan;
+    }
     HIP_TRY(fptk::launch_posterior(c->stream, pl));
     return launch_ok("k_posterior");
 }

@@ -134,7 +134,10 @@ struct posterior_launch {
     int32_t *status_out;
     double *off_table, *lgam_table;     // workspace of posterior_table_bytes(): filled by the launch (or both nullptr)
     bool all_simple;                    // every dataset's model passes posterior_model_simple() (decided on the host's copy)
+    bool max_len_unknown;               // max_len is a guess: plan for longer intervals anyway
+    void *plan_ws;                      // ragged batches: posterior_plan_bytes() of workspace for the chunk list
 };
+size_t posterior_plan_bytes(int64_t total_bases, int hw);
 bool posterior_model_simple(const double *par24);  // finite parameters, ascending breakpoints: the fits by their active segment
 size_t posterior_table_bytes(int n_datasets);  // off_table: n_datasets x 256 x 256 doubles, then lgam_table: 4096
 size_t posterior_lds_bytes(int n_datasets, int nt);

@@ -52,7 +52,15 @@ struct post_args {
     // integer (exp, k) pair below kTabExp x kTabObs per dataset, and lgam(k + 1) for k < kTabLgam
     const double *off_table;
     const double *lgam_table;
+    // ragged batches: a workgroup takes ONE chunk of kPostChunkTiles tiles of one interval.  Launch A: workgroup b = chunk 0
+    // of interval b (chunk_list null); launch B: the further chunks of the intervals longer than that, listed by
+    // k_posterior_plan -- (interval, chunk) pairs, *chunk_count of them (the launch is sized by a bound: workgroups
+    // beyond the count leave at once).  Uniform batches: blockIdx.y is the chunk.
+    const int2 *chunk_list;
+    const int32_t *chunk_count;
 };
+
+constexpr int kPostChunkTiles = 8;
 
 // The unoccupied likelihood is the NB log-pmf at the expected count itself, an integer (the scan's
 // exp track is a sum of two rounded values), so per dataset it is a function of the integer pair
@@ -76,7 +84,7 @@ __device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, do
 // lane (a wavefront runs the longest).  The factors carry q = mu / (r + mu) with them, so that
 // k log1p(-p) = k log q is part of the same logarithm:
 //     log pmf = log( prod_{j<k} (r + j) q ) - lgam(k + 1) + r log p,     p = r / (r + mu)
-// Every factor lies between q r and min(r, mu) + k (with r and mu in [1e-3, 1e12] and one of them below 1e6 nothing
+// Every factor lies between q r and min(r, mu) + k (with r in [1e-3, 1e7] and mu in [1e-3, 1e12] nothing
 // over- or underflows for k <= kProdMax), the
 // product is good to k ulps, and where gamma.c's two lgam values cancel (r large) this form is the
 // more accurate one.  Against the reference's expression it differs by ~1e-14 absolute per value
@@ -85,11 +93,18 @@ __device__ __forceinline__ double nb_logpmf_terms(double lg_kr, double lg_k1, do
 constexpr int kProdMax = 48;
 __device__ __forceinline__ double nb_logpmf_any(double r, double mu, int32_t k, double lg_k1) {
     const double d = r + mu;
-    if ((uint32_t)k <= (uint32_t)kProdMax && r >= 1e-3 && r <= 1e12 && mu >= 1e-3 && mu <= 1e12 && (r <= 1e6 || mu <= 1e6)) {
+    // (r <= 1e7, round 6: beyond it the reference's own lgam(k + r) - lgam(r) is the difference of two values of 1e9 and
+    // more -- an absolute error of 1e-6 and up that the product form does not have -- and parity means the reference's
+    // value: tests/test_gpu_parity.py::test_posterior_large_r_and_infinite_prior, r = 1e9 .. 1e12)
+    if ((uint32_t)k <= (uint32_t)kProdMax && r >= 1e-3 && r <= 1e7 && mu >= 1e-3 && mu <= 1e12) {
         double inv = __builtin_amdgcn_rcp(d);  // 2^-24, two Newton steps: below an ulp
         inv = fma(fma(-d, inv, 1.0), inv, inv);
         inv = fma(fma(-d, inv, 1.0), inv, inv);
-        const double p = r * inv, q = mu * inv, c = r * q;
+        // p = r / d correctly rounded (one residual step on the refined reciprocal): r log p multiplies p's last
+        // bit by r, and a quotient an ulp off the reference's r / (r + mu) would move the term by 1.1e-16 r
+        double p = r * inv;
+        p = fma(fma(-p, d, r), inv, p);
+        const double q = mu * inv, c = r * q;
         double prod = 1.0, fj = 0.0;
         int j = 0;
         for (; j + 3 < k; j += 4) {  // four factors a trip: (r + j) q = fma(j, q, r q), the next ones that + q each
@@ -215,7 +230,15 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     const double *par = a.models;
     const double *beta = a.betas;
     const int tid = threadIdx.x;
-    const int64_t iv = blockIdx.x;
+    int64_t iv = blockIdx.x;
+    int chunk = blockIdx.y;
+    if (a.chunk_list) {  // launch B of a ragged batch: the listed chunks
+        typedef const __attribute__((address_space(4))) int32_t kint;
+        if ((int)blockIdx.x >= *(kint *)a.chunk_count) return;
+        const int2 e = a.chunk_list[blockIdx.x];
+        iv = e.x;
+        chunk = e.y;
+    }
     int64_t off;
     int L;
     if (a.interval_off) {
@@ -227,13 +250,14 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     }
     const int64_t T = a.total_bases;
     const int TL = NT - 2 * hw;  // output bases per tile
-    // (gridDim.y comes from the LONGEST interval of the batch: a workgroup beyond this interval's tiles
-    // leaves before it stages anything -- the same for all of its lanes, so ahead of the barrier)
-    if ((int64_t)blockIdx.y * TL >= L) return;
+    // this workgroup's chunk of the interval: kPostChunkTiles tiles from t_first on
+    const int64_t t_first64 = (int64_t)chunk * kPostChunkTiles * TL;
+    if (t_first64 >= L) return;  // (uniform batches whose last chunk is empty; the same for all lanes, ahead of any barrier)
+    const int t_first = (int)t_first64, t_end = min(L, t_first + kPostChunkTiles * TL);
 
     bool zero_div = false;
     int round = 0;               // parity of the LDS buffer across tiles and datasets
-    for (int t0 = blockIdx.y * TL; t0 < L; t0 += gridDim.y * TL) {
+    for (int t0 = t_first; t0 < t_end; t0 += TL) {
         const int u = t0 - hw + tid;  // this lane's base (halo lanes included)
         const bool valid = u >= 0 && u < L;
         const int64_t g = off + (valid ? u : 0);
@@ -264,7 +288,9 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
                     if (f <= a.cutoff) k_called += 1.0;
                     n_cov += ww;
                     const double al = o + beta[2 * d], be = (np_max2(e, o) - o) + beta[2 * d + 1];
-                    if (!(al > 0.0 && be > 0.0)) {
+                    // (al = +inf: the reference's mean al / (al + be) is inf / inf, NaN even for a dataset that is
+                    // not called -- 0 x NaN; be = +inf with a finite al gives mean 0 and adds nothing there)
+                    if (!(al > 0.0 && be > 0.0 && al < fptm::kInf)) {
                         swm += NAN;
                         sw += f > a.cutoff ? 0.0 : NAN;
                     } else if (!(f > a.cutoff)) {
@@ -399,9 +425,30 @@ __global__ void __launch_bounds__(NT) k_posterior(const post_args a) {
     if (zero_div && a.status_out) atomicOr(&a.status_out[iv], 1);
 }
 
+// The chunks beyond the first of every interval longer than kPostChunkTiles tiles, as (interval, chunk) pairs in the
+// order the atomics hand out (a chunk's result does not depend on its place).  count must be zero.
+__global__ void __launch_bounds__(256) k_posterior_plan(const int64_t *__restrict__ off, int64_t n_intervals, int tl,
+                                                        int2 *__restrict__ list, int32_t *__restrict__ count, int32_t capacity) {
+    const int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (iv >= n_intervals) return;
+    const int64_t L = off[iv + 1] - off[iv];
+    const int64_t span = (int64_t)kPostChunkTiles * tl;
+    const int extra = L > span ? (int)((L - 1) / span) : 0;
+    if (!extra) return;
+    const int at = atomicAdd(count, extra);
+    for (int c = 0; c < extra && at + c < capacity; ++c) list[at + c] = make_int2((int)iv, c + 1);
+}
+
 }  // namespace
 
 namespace fptk {
+
+// the extra chunks of a ragged batch are at most total_bases / (kPostChunkTiles x the SMALLEST tile any instance
+// uses): every chunk beyond an interval's first has a full chunk of bases before it
+size_t posterior_plan_bytes(int64_t total_bases, int hw) {
+    const int tl = 64 - 2 * hw > 0 ? 64 - 2 * hw : 1;
+    return (size_t)(total_bases / ((int64_t)kPostChunkTiles * tl) + 2) * sizeof(int2) + 16;
+}
 
 bool posterior_model_simple(const double *par24) {
     bool ok = true;
@@ -444,6 +491,8 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     a.status_out = pl.status_out;
     a.off_table = pl.off_table;
     a.lgam_table = pl.lgam_table;
+    a.chunk_list = nullptr;
+    a.chunk_count = nullptr;
     if (pl.off_table && pl.lgam_table)
         for (int d0 = 0; d0 <= pl.n_datasets; d0 += 32768) {
             const int ny = pl.n_datasets + 1 - d0 < 32768 ? pl.n_datasets + 1 - d0 : 32768;
@@ -460,9 +509,28 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
     if (const char *e = getenv("FPT_POSTERIOR_NT")) nt = atoi(e) == 64 ? 64 : (atoi(e) == 128 ? 128 : 256);
     if (nt - 2 * pl.hw < 16) nt = 256;  // (a tile must hold more than its halo)
     const int tl = nt - 2 * pl.hw;
-    int64_t tiles = ((int64_t)pl.max_len + tl - 1) / tl;
-    int gy = tiles <= 8 ? 1 : (int)((tiles + 7) / 8);
-    if (gy > 65535) gy = 65535;
+    const int64_t tiles = ((int64_t)pl.max_len + tl - 1) / tl;
+    // Chunks of kPostChunkTiles tiles.  A uniform batch has the same number in every interval: gridDim.y.  A ragged
+    // one (round 6): ONE workgroup per interval for its first chunk -- nine in ten intervals of the whole-genome
+    // set have no other -- and a second launch over the listed further chunks of the long ones (k_posterior_plan);
+    // rounds 3 - 5 sized gridDim.y by the LONGEST interval of the batch, and four workgroups in five left at once.
+    int64_t gy64 = pl.interval_off ? 1 : (tiles + kPostChunkTiles - 1) / kPostChunkTiles;
+    if (gy64 > 65535) return hipErrorInvalidValue;  // (an interval of > 30 million bases in a uniform batch)
+    const int gy = (int)gy64;
+    int2 *chunk_list = nullptr;
+    int32_t *chunk_count = nullptr;
+    int64_t chunk_cap = 0;
+    if (pl.interval_off && (tiles > kPostChunkTiles || pl.max_len_unknown)) {
+        if (!pl.plan_ws) return hipErrorInvalidValue;
+        chunk_count = (int32_t *)pl.plan_ws;
+        chunk_list = (int2 *)((char *)pl.plan_ws + 16);
+        chunk_cap = pl.total_bases / ((int64_t)kPostChunkTiles * tl) + 1;
+        if (chunk_cap > 0x7fffff00) return hipErrorInvalidValue;
+        hipError_t e0 = hipMemsetAsync(chunk_count, 0, 16, st);
+        if (e0 != hipSuccess) return e0;
+        hipLaunchKernelGGL(k_posterior_plan, dim3((unsigned)((pl.n_intervals + 255) / 256)), dim3(256), 0, st, pl.interval_off,
+                           pl.n_intervals, tl, chunk_list, chunk_count, (int32_t)chunk_cap);
+    }
     const size_t lds = posterior_lds_bytes(pl.n_datasets, nt);
     void (*kern)(const post_args) = pl.all_simple ? (nt == 64 ? k_posterior<64, true> : (nt == 128 ? k_posterior<128, true> : k_posterior<256, true>))
                                                    : (nt == 64 ? k_posterior<64, false> : (nt == 128 ? k_posterior<128, false> : k_posterior<256, false>));
@@ -485,6 +553,12 @@ hipError_t launch_posterior(hipStream_t st, const posterior_launch &pl) {
             if (b.status_out) b.status_out += done;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)n, gy), dim3(nt), lds, st, b);
+    }
+    if (chunk_list) {  // launch B: sized by the bound, the count decides
+        post_args b = a;
+        b.chunk_list = chunk_list;
+        b.chunk_count = chunk_count;
+        hipLaunchKernelGGL(kern, dim3((unsigned)chunk_cap, 1), dim3(nt), lds, st, b);
     }
     return hipSuccess;
 }

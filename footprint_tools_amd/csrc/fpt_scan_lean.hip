@@ -233,7 +233,8 @@ struct lean_mem {
 // ---- B: 6-mer index and propensities, 2*hw window sums, per-tile scans of the window sums.
 // Returns true where an aligned row of 16 equal non-zero window sums shows up (see the header).
 template <int NT, int NP, int NI>
-__device__ __forceinline__ bool lean_phase_b(const lean_mem<NP> &m, const double2 *table2, int ncs, int nt, int tid) {
+__device__ __forceinline__ bool lean_phase_b(const lean_mem<NP> &m, const double2 *table2, int ncs, int nt, int tid,
+                                             bool = false) {
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     bool bad = false;
     // the table gathers of both of a lane's positions go out first: one trip to L2 instead of two
@@ -455,6 +456,14 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
     // (An XCD-contiguous order of the tiles -- workgroup b takes slot (b mod 8) n/8 + b/8, so that intervals that
     // are neighbours in memory meet in one L2 -- was measured on the ragged shape: +1-2 %, dropped.)
     const int64_t tile = a.tile_first + blockIdx.x;
+    // Wave priority (round 6): the SIMD's arbiter issues from its OLDEST wavefront first, and the oldest are deep in
+    // the arithmetic of phases B - E -- a workgroup that has just arrived waits behind them for the few instructions
+    // that send its loads off, and the 2.6 us of their latency start late.  Raised until the inputs are staged
+    // (s_setprio 3 here, 0 before the first barrier), the loads of a new tile go out at once: config 3 23.5 -> 21.3 ms,
+    // config 2 0.85 -> 0.78, config 4 1.63 -> 1.52, bit-identical (profiles/r06_lean_prio.txt: the level -- 1, 2, 3 --
+    // does not matter, raising it in any later phase too gives part of it back).  FPT_LEAN_PRIO=0 switches it off.
+    const bool prio = a.prio != 0;
+    if (prio) __builtin_amdgcn_s_setprio(3);
     LEAN_TRACE(1);
     const lean_tile g = lean_geometry(a, tile);
     const double2 *memo = a.memo + (size_t)g.dm * a.memo_exp * a.memo_obs;
@@ -465,6 +474,7 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
     if (lean_lds<NP>::kTab && a.n_scales > 1)  // (read four barriers from here)
         for (int i = tid; i < 4 * FPT_NDTR_GTAB_N; i += NT) m.gt[i] = g_lean_gtab[i] * kc->inv_g0;
     bool bad = lean_stage<NT, NI>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
+    if (prio) __builtin_amdgcn_s_setprio(0);
     LEAN_TRACE(2);
     __syncthreads();
     LEAN_TRACE(3);

@@ -1076,6 +1076,99 @@ def test_posterior_batch_fuzz(fpt, orc, seed):
                                                     interval_off=off), stats, equal_nan=True)
 
 
+def test_posterior_large_r_and_infinite_prior(fpt, orc):
+    """Two corners of the posterior kernel (advisor, round 5).  (1) A dispersion fit whose 1/r is just above zero --
+    r from 1e9 to 1e12: the fast log-pmf's term r log p multiplies the last bit of p = r / (r + mu) by r, so p must be
+    the reference's correctly rounded quotient (the contract on the likelihoods is 1e-6 relative).  (2) A Beta prior
+    with an infinite first parameter: the reference's mean is inf / inf = NaN, and 0 x NaN stays NaN for a dataset that
+    is not called -- delta is then 1 at every base, as in the checker."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    lat = golden("nb_lattice.npz")
+    rs = np.random.RandomState(99)
+    D, total = 4, 600
+    dms, models = [], []
+    for inv_r in (1e-9, 1e-10, 1e-11, 1e-12):
+        r = np.array(lat["r_A"], dtype=np.float64)
+        r[5:10], r[10:] = inv_r, 0.0          # 1/r = inv_r on every segment
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_A"], r
+        dms.append(dm)
+        models.append((lat["mu_A"], r))
+    exp = np.round(rs.gamma(2.0, 8.0, (D, total)))
+    obs = np.floor(exp * rs.uniform(0.0, 1.6, (D, total)))
+    fdr = rs.uniform(0, 1, (D, total)) ** 4
+    w = np.ones((D, total))
+    betas = rs.uniform(0.5, 30.0, (D, 2))
+    off = np.array([0, 250, 600], dtype=np.int64)
+    stats, pc = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, interval_off=off, pieces=True)
+    for a, b in zip(off[:-1], off[1:]):
+        want, wp = orc.posterior_stats(obs[:, a:b], exp[:, a:b], fdr[:, a:b], w[:, a:b], betas, models, cutoff=0.05, hw=3)
+        assert rel_err(pc["ll_on"][:, a:b], wp["ll_on"]) < P_TOL and rel_err(pc["ll_off"][:, a:b], wp["ll_off"]) < P_TOL
+        assert np.allclose(stats[a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True)
+    # (2): dataset 0's prior has alpha = +inf; it is called nowhere (fdr = 1)
+    dms2 = []
+    for key in "ABCA":
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + key], lat["r_" + key]
+        dms2.append(dm)
+    betas2 = betas.copy()
+    betas2[0, 0] = np.inf
+    fdr2 = fdr.copy()
+    fdr2[0] = 1.0
+    stats2, pc2 = posterior.posterior_batch(obs, exp, fdr2, w, betas2, dms2, fdr_cutoff=0.05, interval_off=off, pieces=True)
+    m2 = [(lat["mu_" + k], lat["r_" + k]) for k in "ABCA"]
+    for a, b in zip(off[:-1], off[1:]):
+        want, wp = orc.posterior_stats(obs[:, a:b], exp[:, a:b], fdr2[:, a:b], w[:, a:b], betas2, m2, cutoff=0.05, hw=3)
+        assert np.all(wp["delta"] == 1.0) and np.array_equal(pc2["delta"][a:b], wp["delta"])
+        assert np.allclose(stats2[a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True)
+
+
+def test_posterior_long_intervals_take_listed_chunks(fpt, orc):
+    """A ragged batch gives every interval ONE workgroup for its first eight tiles and lists the further chunks of the
+    long ones on the device (k_posterior_plan; round 6): intervals of exactly 8 tiles, 8 tiles + 1 base, 17 tiles and
+    many chunks, with and without the caller knowing the longest -- the records of every base against the checker."""
+    from footprint_tools_amd.modeling import dispersion
+    from footprint_tools_amd.stats import posterior
+    lat = golden("nb_lattice.npz")
+    rs = np.random.RandomState(5)
+    D = 3
+    tl = 64 - 6
+    lens = np.array([8 * tl, 8 * tl + 1, 30, 17 * tl, 1, 40 * tl + 7, 8 * tl - 1, 100], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(off[-1])
+    dms, models = [], []
+    for key in "ABC":
+        dm = dispersion.dispersion_model()
+        dm.mu_params, dm.r_params = lat["mu_" + key], lat["r_" + key]
+        dms.append(dm)
+        models.append((lat["mu_" + key], lat["r_" + key]))
+    exp = np.round(rs.gamma(2.0, 6.0, (D, total)))
+    obs = np.floor(exp * rs.uniform(0.0, 1.6, (D, total)))
+    fdr = rs.uniform(0, 1, (D, total)) ** 4
+    w = (rs.uniform(0, 1, (D, total)) < 0.9).astype(float)
+    betas = rs.uniform(0.5, 30.0, (D, 2))
+    got = {}
+    for nt in ("64", "256"):
+        os.environ["FPT_POSTERIOR_NT"] = nt
+        try:
+            got[nt] = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, interval_off=off)
+        finally:
+            del os.environ["FPT_POSTERIOR_NT"]
+    assert np.array_equal(got["64"], got["256"], equal_nan=True)
+    # a caller that does not say how long the longest interval is (max_interval_len = 0): planned for anyway
+    real = posterior.posterior_dev
+    posterior.posterior_dev = lambda *a_, **k_: real(*a_, **dict(k_, max_interval_len=0))
+    try:
+        blind = posterior.posterior_batch(obs, exp, fdr, w, betas, dms, fdr_cutoff=0.05, interval_off=off)
+    finally:
+        posterior.posterior_dev = real
+    assert np.array_equal(blind, got["64"], equal_nan=True)
+    for a, b in zip(off[:-1], off[1:]):
+        want = orc.posterior_stats(obs[:, a:b], exp[:, a:b], fdr[:, a:b], w[:, a:b], betas, models, cutoff=0.05, hw=3)[0]
+        assert np.allclose(got["64"][a:b], want, rtol=1e-6, atol=1e-9, equal_nan=True), (a, b)
+
+
 def test_posterior_batch_zero_division(fpt):
     """dm.log_pmf_values raises ZeroDivisionError where the 1/r fit is exactly 0 (dispersion.pyx:160-161);
     so does the batched call, whichever dataset and likelihood hits it."""
