@@ -134,7 +134,7 @@ def traffic_probe(argv_cfg, timeout_s=100):
                    os.path.abspath(__file__)] + argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                                                             "--no-other-mode", "--no-heavy", "--no-posterior",
                                                             "--no-traffic-probe", "--no-box-stream", "--no-config-legs",
-                                                            "--no-issue-probe"]
+                                                            "--no-issue-probe", "--no-host-arrays"]
             child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
                                      start_new_session=True)
             try:
@@ -217,7 +217,7 @@ def issue_probe(argv_cfg, timeout_s=150):
     def counter_run(ctrs, where, limit):
         cmd = [prof, "--pmc"] + ctrs + ["--output-format", "csv", "-d", where, "--", sys.executable, os.path.abspath(__file__)] + \
             argv_cfg + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-mode", "--no-heavy", "--no-posterior",
-                        "--no-traffic-probe", "--no-box-stream", "--no-config-legs", "--no-issue-probe"]
+                        "--no-traffic-probe", "--no-box-stream", "--no-config-legs", "--no-issue-probe", "--no-host-arrays"]
         child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=env["TMPDIR"], env=env,
                                  start_new_session=True)
         try:
@@ -469,6 +469,74 @@ def reference_native(cfg, table, DM, cores, budget_s=3.0):
                        % (len(items), L, len(scales), dt1, len(work), cores, dtn))
 
 
+def host_arrays_leg(ctx, table, DM):
+    """The rate a drop-in Python caller sees: numpy arrays in, numpy arrays out through FootprintScanner.scan
+    (fpt_scan_host: chunks through a copy-in / scan / copy-out pipeline), BASELINE config 2's size, PCIe included --
+    with pageable arrays (np.empty: staged through pinned buffers by host threads) and with page-locked ones
+    (ctx.pinned_empty: the copy engines read and write them directly).  Reference counterpart: the per-call API
+    modeling/predict.pyx:116-163 + dispersion.pyx:291-316 + windowing.pyx:114-130 (arrays in, arrays out).
+    Never `value`: the headline has its inputs resident in HBM."""
+    from oracle import oracle  # inputs (the synthetic generator) and the spot check only
+    from footprint_tools_amd.scan import FootprintScanner
+    cfg = CONFIGS["2"]
+    n_iv, L, scales = cfg["n_iv"], cfg["L"], cfg["scales"]
+    sc = FootprintScanner(table, DM, HW, SHW, CLIP, scales, ctx=ctx, nb_mode="memo")
+    l = sc.padded_len(L)
+    cp, cm = oracle.synth_counts(1, 0, n_iv * l, 0), oracle.synth_counts(1, 0, n_iv * l, 1)
+    sq = oracle.synth_bases(1, 0, n_iv * (l + 6))
+    out = {}
+    res = {}
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            t0 = time.perf_counter()
+            a_in = [ctx.pinned_empty(a.shape, a.dtype) for a in (cp, cm, sq)]
+            for dst, src in zip(a_in, (cp, cm, sq)):
+                dst[...] = src
+            alloc_s = time.perf_counter() - t0
+        else:
+            a_in, alloc_s = (cp, cm, sq), 0.0
+        chunk = int(os.environ.get("FPT_BENCH_HOST_CHUNK", "0"))
+        # the first call makes the output arrays (and brings the pipeline's buffers up); the timed calls write
+        # them again (out=): what a caller that loops over batches does
+        t0 = time.perf_counter()
+        r = sc.scan(a_in[0], a_in[1], a_in[2], interval_len=L, pinned_out=kind == "pinned", chunk_bases=chunk)
+        first_s = time.perf_counter() - t0
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = sc.scan(a_in[0], a_in[1], a_in[2], interval_len=L, chunk_bases=chunk, out=r)
+            dt = time.perf_counter() - t0
+            st = ctx.scan_host_last()
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        res[kind] = r
+        dt, st = best
+        out[kind] = dict(value=n_iv * L / dt, unit="bases/s", ms_per_call=dt * 1e3, pipeline_ms=st["seconds"] * 1e3,
+                         first_call_ms=first_s * 1e3, chunks=st["chunks"],
+                         link_GBps_h2d=st["bytes_h2d"] / st["seconds"] / 1e9,
+                         link_GBps_d2h=st["bytes_d2h"] / st["seconds"] / 1e9,
+                         link_GBps_both=(st["bytes_h2d"] + st["bytes_d2h"]) / st["seconds"] / 1e9,
+                         arrays_used_directly=bool(st["inputs_pinned"] and st["outputs_pinned"]),
+                         calling_thread_ms=dict(waiting=st["wait_seconds"] * 1e3, staging_copies=st["stage_seconds"] * 1e3,
+                                                issuing=st["issue_seconds"] * 1e3))
+        if kind == "pinned":
+            out[kind]["input_alloc_and_fill_s"] = alloc_s
+    iv = n_iv - 1
+    e, o, p, wp = oracle.detect_batch(cp[iv * l:(iv + 1) * l], cm[iv * l:(iv + 1) * l], sq[iv * (l + 6):(iv + 1) * (l + 6)], 1, L,
+                                      HW, SHW, CLIP, table, DM.mu_params, DM.r_params, scales)
+    r = res["pageable"]
+    sl = slice(iv * L, (iv + 1) * L)
+    same = all(np.array_equal(res["pageable"][k], res["pinned"][k], equal_nan=True) for k in ("exp", "obs", "pval", "winp"))
+    out["parity"] = dict(exp_bit_exact=bool(np.array_equal(r["exp"][sl], e) and np.array_equal(r["obs"][sl], o)),
+                         p_max_rel_err=float(np.nanmax(np.abs(r["pval"][sl] - p) / np.maximum(np.abs(p), 1e-300))),
+                         winp_max_rel_err=float(np.nanmax(np.abs(r["winp"][:, sl] - wp) / np.maximum(np.abs(wp), 1e-300))),
+                         pinned_equals_pageable_bitwise=bool(same))
+    out["workload"] = (cfg["name"] + ", numpy arrays in and out of FootprintScanner.scan (PCIe-inclusive; best of 3 calls "
+                       "that write the output arrays of a first call again: first_call_ms is the one that made them)")
+    out["bytes_per_base_over_the_link"] = dict(h2d=(l / L) * 17.0, d2h=8.0 * (3 + len(scales)))
+    return out
+
+
 def launch_ranks(n, argv, timeout_s=None, program=None):
     """`python3 bench.py --gpus N` with no launcher around it: this process starts the N ranks itself -- the
     counterpart of the reference's `batch_iter(num_workers=n)` forking its own workers (cli/detect.py:394).
@@ -580,6 +648,9 @@ def main():
                     help="tests: run the configuration legs on this many intervals each (and allow them beside --intervals)")
     ap.add_argument("--no-issue-probe", action="store_true",
                     help="config 5: do not read the SQ counters of the FDR kernels in a child run under rocprofv3")
+    ap.add_argument("--no-host-arrays", action="store_true",
+                    help="N=1, default config: skip the host-arrays leg (numpy in / numpy out through FootprintScanner.scan, "
+                         "config 2's size, PCIe included)")
     ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the assembly of the p-value track (same as --assembly none)")
     ap.add_argument("--assembly", default="allgather", choices=["allgather", "gather", "none"],
                     help="N>1: how the per-base track is re-assembled -- every rank gets it (one RCCL all-gather: BASELINE.json's "
@@ -1036,6 +1107,18 @@ def main():
                                                 p_out, total, 5, ctypes.byref(ms)))
         box = float(ms.value)
 
+    # ---- the per-call API a drop-in caller uses: host arrays in and out, PCIe included (never `value`)
+    host_leg = None
+    if (world == 1 and args.config == "3" and not args.no_host_arrays and not args.hotspots and args.nb_mode == "memo"
+            and args.scales is None):
+        for buf in (d_cp, d_cm, d_sq, d_out):  # the resident batch is done with
+            buf.free()
+        ctx.trim_pool()
+        try:
+            host_leg = host_arrays_leg(ctx, table, DM)
+        except Exception as ex:  # (a leg beside the headline: its failure is reported, not fatal)
+            host_leg = dict(error="%s: %s" % (type(ex).__name__, ex))
+
     if rank == 0:
         rd, wr = algorithmic_bytes_per_base(L if not ragged else total / n_iv, S)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None
@@ -1206,6 +1289,7 @@ def main():
             "posterior": post,
             "fdr": fdr_block,
             "parity": parity,
+            "host_arrays": host_leg,
         }
         if legs is not None:
             # every BASELINE configuration that fits one GPU, from THIS invocation: the headline (this process) and

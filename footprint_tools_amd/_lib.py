@@ -27,6 +27,7 @@ EXPORTS = [
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
     "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize", "fpt_comm_info",
+    "fpt_scan_host", "fpt_scan_host_last", "fpt_host_alloc", "fpt_host_free",
     "fpt_stream_pattern_dev", "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
@@ -63,6 +64,13 @@ class ScanDesc(C.Structure):
         ("winp_out", C.c_void_p),
         ("status_out", C.c_void_p),
     ]
+
+
+class ScanHostStats(C.Structure):
+    """struct fpt_scan_host_stats of include/fpt.h"""
+    _fields_ = [("seconds", C.c_double), ("bases", C.c_int64), ("chunks", C.c_int64), ("bytes_h2d", C.c_int64),
+                ("bytes_d2h", C.c_int64), ("inputs_pinned", C.c_int32), ("outputs_pinned", C.c_int32),
+                ("wait_seconds", C.c_double), ("stage_seconds", C.c_double), ("issue_seconds", C.c_double)]
 
 
 class FdrDesc(C.Structure):
@@ -200,6 +208,10 @@ def load():
         L.fpt_set_memo_dims.argtypes = [vp, i32, i32]
         L.fpt_drop_kept_tables.argtypes = [vp]
         L.fpt_timing_enable.argtypes = [vp, i32]
+        L.fpt_scan_host.argtypes = [vp, vp, i64]
+        L.fpt_scan_host_last.argtypes = [vp, vp]
+        L.fpt_host_alloc.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
+        L.fpt_host_free.argtypes = [vp, vp]
         if hasattr(L, "fpt_stream_pattern_dev"):  # (absent from older builds loaded through FPT_LIB_PATH for A/B runs)
             L.fpt_stream_pattern_dev.argtypes = [vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, C.POINTER(C.c_float)]
         L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]
@@ -367,6 +379,25 @@ class Context(object):
 
     def synchronize(self):
         check(self.L.fpt_ctx_synchronize(self.h))
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """An uninitialised numpy array in page-locked host memory (fpt_host_alloc): arrays of this kind are read
+        and written by the copy engines directly when handed to FootprintScanner.scan.  Freed with the array."""
+        import weakref
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        p = C.c_void_p()
+        check(self.L.fpt_host_alloc(self.h, max(n, 16), C.byref(p)))
+        buf = (C.c_char * max(n, 16)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        L, h, addr = self.L, self.h, p.value
+        weakref.finalize(buf, lambda: L.fpt_host_free(h, C.c_void_p(addr)) if h else None)
+        return arr
+
+    def scan_host_last(self):
+        st = ScanHostStats()
+        check(self.L.fpt_scan_host_last(self.h, C.byref(st)))
+        return dict((k, getattr(st, k)) for k, _ in ScanHostStats._fields_)
 
     def set_stream(self, hip_stream):
         """Run on a caller-owned hipStream_t (integer handle).  0 is the device's default (null)

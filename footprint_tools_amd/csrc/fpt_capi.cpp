@@ -9,9 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "fpt_host_threads.hpp"
 #include "fpt_kernels.hpp"
 
 namespace {
@@ -41,8 +46,12 @@ constexpr int kModelDoubles = 24;
 
 }  // namespace
 
+struct fpt_host_pipe;                       // fpt_scan_host's streams, device buffers and pinned staging (end of this file)
+static void host_pipe_free(fpt_host_pipe *);
+
 struct fpt_ctx {
     int device = 0;
+    fpt_host_pipe *pipe = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     double *d_table = nullptr;   // 4097 doubles (slot 4096 = default)
@@ -251,6 +260,7 @@ int fpt_ctx_destroy(fpt_ctx *c) {
     if (!c) return FPT_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
+    host_pipe_free(c->pipe);
     for (int i = 0; i < kSlots; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->d_table) (void)hipFree(c->d_table);
@@ -1368,6 +1378,338 @@ int fpt_memcpy_d2h(fpt_ctx *c, void *host, const void *dev, int64_t bytes) {
     if (bytes == 0) return FPT_OK;
     HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return FPT_OK;
+}
+
+
+/* ---- host arrays in, host arrays out: the per-call form a drop-in caller uses (modeling/predict.pyx:116-163 hands
+ *      numpy arrays over and gets numpy arrays back), as a three-stage pipeline over chunks of intervals */
+#pragma GCC visibility pop
+}  // extern "C"
+
+// A small team for host-to-host copies (pageable user arrays <-> pinned staging): one core moves ~10 GB/s, the
+// link wants 50 in each direction.
+namespace {
+class copy_team {
+public:
+    explicit copy_team(int n) : n_(std::max(1, n)) {
+        for (int i = 1; i < n_; ++i) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~copy_team() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void copy(void *dst, const void *src, size_t bytes) {
+        if (bytes < ((size_t)1 << 20) || n_ == 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = (char *)dst, src_ = (const char *)src, bytes_ = bytes;
+            left_ = n_ - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        part(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+    }
+
+private:
+    void part(int i) {
+        const size_t per = ((bytes_ / n_) + 4095) & ~(size_t)4095;
+        const size_t a = std::min(bytes_, per * i), b = i == n_ - 1 ? bytes_ : std::min(bytes_, per * (i + 1));
+        if (b > a) memcpy(dst_ + a, src_ + a, b - a);
+    }
+    void loop(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+            }
+            part(i);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --left_;
+            }
+            done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0;
+    int left_ = 0;
+};
+
+bool is_pinned(const void *p) {  // memory the runtime can DMA from / to directly (hipHostMalloc, hipHostRegister)
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+constexpr int kPipeSlots = 3;
+struct fpt_host_pipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    struct slot_t {
+        char *d_in = nullptr, *d_out = nullptr, *p_in = nullptr, *p_out = nullptr;
+        size_t d_in_bytes = 0, d_out_bytes = 0, p_in_bytes = 0, p_out_bytes = 0;
+        hipEvent_t ev_in = nullptr, ev_scan = nullptr, ev_out = nullptr;
+        bool busy = false;
+        // what the chunk in flight still owes the caller once ev_out has passed
+        int64_t base0 = 0, bases = 0, iv0 = 0, n_iv = 0;
+    } slot[kPipeSlots];
+    copy_team *team = nullptr;
+    fpt_scan_host_stats last = {};
+};
+
+static void host_pipe_free(fpt_host_pipe *p) {
+    if (!p) return;
+    for (auto &s : p->slot) {
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.p_in) (void)hipHostFree(s.p_in);
+        if (s.p_out) (void)hipHostFree(s.p_out);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_scan) (void)hipEventDestroy(s.ev_scan);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    }
+    if (p->s_in) (void)hipStreamDestroy(p->s_in);
+    if (p->s_out) (void)hipStreamDestroy(p->s_out);
+    delete p->team;
+    delete p;
+}
+
+namespace {
+int pipe_grow(char **buf, size_t *have, size_t want, bool pinned) {
+    if (*have >= want) return FPT_OK;
+    if (*buf) {
+        if (pinned) (void)hipHostFree(*buf);
+        else (void)hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
+    }
+    want += want / 8;
+    hipError_t e = pinned ? hipHostMalloc((void **)buf, want, hipHostMallocDefault) : hipMalloc((void **)buf, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FPT_ERR_NOMEM, "%s allocation of %zu bytes failed", pinned ? "pinned host" : "device", want);
+    }
+    *have = want;
+    return FPT_OK;
+}
+inline size_t up16(size_t n) { return (n + 15) & ~(size_t)15; }
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int fpt_host_alloc(fpt_ctx *c, int64_t bytes, void **host_out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!host_out || bytes < 0) return fail(FPT_ERR_INVALID, "bad arguments");
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes > 0 ? (size_t)bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FPT_ERR_NOMEM, "pinned host allocation of %lld bytes failed", (long long)bytes);
+    }
+    *host_out = p;
+    return FPT_OK;
+}
+
+int fpt_host_free(fpt_ctx *c, void *host) {
+    if (int rc = check_ctx(c)) return rc;
+    if (host) HIP_TRY(hipHostFree(host));
+    return FPT_OK;
+}
+
+int fpt_scan_host_last(fpt_ctx *c, fpt_scan_host_stats *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!out) return fail(FPT_ERR_INVALID, "null output");
+    if (!c->pipe) return fail(FPT_ERR_INVALID, "fpt_scan_host has not run on this context");
+    *out = c->pipe->last;
+    return FPT_OK;
+}
+
+int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
+    if (d->n_intervals < 0) return fail(FPT_ERR_INVALID, "negative interval count");
+    if (d->n_scales < 0 || d->n_scales > FPT_MAX_SCALES) return fail(FPT_ERR_INVALID, "bad n_scales");
+    if (d->half_win_width < 0 || d->smoothing_half_win_width < 0) return fail(FPT_ERR_INVALID, "negative window width");
+    if (!d->counts_plus || !d->counts_minus || !d->seq) return fail(FPT_ERR_INVALID, "null input");
+    const int64_t n = d->n_intervals;
+    if (n == 0) return FPT_OK;
+    const int64_t *off = d->interval_off ? d->interval_off : d->interval_off_host;  // HOST offsets, either field
+    const bool ragged = off != nullptr;
+    if (!ragged && d->interval_len <= 0) return fail(FPT_ERR_INVALID, "interval_len must be positive");
+    if (ragged)
+        for (int64_t i = 0; i < n; ++i)
+            if (off[i + 1] < off[i]) return fail(FPT_ERR_INVALID, "bad interval offsets");
+    const int pad = d->half_win_width + d->smoothing_half_win_width, S = d->n_scales;
+    const int64_t L = d->interval_len;
+    auto base_at = [&](int64_t i) { return ragged ? off[i] - off[0] : i * L; };
+    const int64_t total = base_at(n);
+    if (chunk_bases <= 0) chunk_bases = (int64_t)1 << 21;
+
+    if (!c->pipe) {
+        c->pipe = new fpt_host_pipe();
+        fpt_host_pipe *np_ = c->pipe;
+        HIP_TRY(hipStreamCreateWithFlags(&np_->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&np_->s_out, hipStreamNonBlocking));
+        for (auto &s : np_->slot) {
+            HIP_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+        }
+        np_->team = new copy_team(std::min(fpt_host_cpus(), 12));
+    }
+    fpt_host_pipe *P = c->pipe;
+    // which of the caller's arrays the link can reach directly
+    const bool in_pinned = is_pinned(d->counts_plus) && is_pinned(d->counts_minus) && is_pinned(d->seq);
+    double *outs[3 + FPT_MAX_SCALES];
+    outs[0] = d->exp_out, outs[1] = d->obs_out, outs[2] = d->pval_out;
+    for (int s = 0; s < S; ++s) outs[3 + s] = d->winp_out ? d->winp_out + (size_t)s * total : nullptr;
+    bool out_pinned = true, any_out = false;
+    for (int k = 0; k < 3 + S; ++k)
+        if (outs[k]) any_out = true, out_pinned = out_pinned && is_pinned(outs[k]);
+    if (d->status_out) out_pinned = out_pinned && is_pinned(d->status_out);
+    (void)any_out;
+
+    fpt_scan_host_stats st = {};
+    st.inputs_pinned = in_pinned, st.outputs_pinned = out_pinned;
+    const auto t_start = std::chrono::steady_clock::now();
+
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
+    auto finish = [&](fpt_host_pipe::slot_t &sl) -> int {  // the chunk's results are on the host: hand them over
+        if (!sl.busy) return FPT_OK;
+        const auto tw = tick();
+        HIP_TRY(hipEventSynchronize(sl.ev_out));
+        st.wait_seconds += since(tw);
+        const auto ts = tick();
+        if (!out_pinned) {
+            const size_t tb = (size_t)sl.bases * 8;
+            for (int k = 0; k < 3 + S; ++k)
+                if (outs[k]) P->team->copy(outs[k] + sl.base0, sl.p_out + (size_t)k * tb, tb);
+            if (d->status_out) memcpy(d->status_out + sl.iv0, sl.p_out + (size_t)(3 + S) * tb, (size_t)sl.n_iv * 4);
+        }
+        st.stage_seconds += since(ts);
+        sl.busy = false;
+        return FPT_OK;
+    };
+
+    int64_t i0 = 0;
+    for (int64_t k = 0; i0 < n; ++k) {
+        // the chunk: intervals [i0, i1) holding about chunk_bases output bases (at least one interval)
+        int64_t i1;
+        if (!ragged) {
+            i1 = std::min(n, i0 + std::max<int64_t>(1, chunk_bases / L));
+        } else {
+            const int64_t want = base_at(i0) + chunk_bases;
+            i1 = std::upper_bound(off + i0 + 1, off + n + 1, want + off[0]) - off - 1;
+            i1 = std::min(n, std::max(i1, i0 + 1));
+        }
+        const int64_t ni = i1 - i0, b0 = base_at(i0), cb = base_at(i1) - b0;
+        const int64_t c0 = b0 + i0 * (2 * pad + 1), nc = cb + ni * (2 * pad + 1);   // counts: first element, elements
+        const int64_t q0 = b0 + i0 * (2 * pad + 7), nq = cb + ni * (2 * pad + 7);   // sequence bytes
+        fpt_host_pipe::slot_t &sl = P->slot[k % kPipeSlots];
+        if (int rc = finish(sl)) return rc;
+        // layout of the chunk's input block: counts+, counts-, sequence, rebased offsets, model ids
+        const size_t o_cm = (size_t)nc * 8, o_sq = 2 * o_cm, o_off = o_sq + up16((size_t)nq),
+                     o_dm = o_off + up16(ragged ? (size_t)(ni + 1) * 8 : 0), in_bytes = o_dm + up16(d->dm_ids ? (size_t)ni * 4 : 0);
+        const size_t tb = (size_t)cb * 8, out_bytes = (size_t)(3 + S) * tb + up16((size_t)ni * 4);
+        if (int rc = pipe_grow(&sl.d_in, &sl.d_in_bytes, in_bytes, false)) return rc;
+        if (int rc = pipe_grow(&sl.d_out, &sl.d_out_bytes, out_bytes, false)) return rc;
+        if (int rc = pipe_grow(&sl.p_in, &sl.p_in_bytes, in_pinned ? in_bytes - o_off + 16 : in_bytes, true)) return rc;
+        if (!out_pinned)
+            if (int rc = pipe_grow(&sl.p_out, &sl.p_out_bytes, out_bytes, true)) return rc;
+        // (the slot's previous chunk has been handed over: its device and staging buffers are free)
+        const auto ti = tick();
+        double staged_here = 0.0;
+        char *small = in_pinned ? sl.p_in : sl.p_in + o_off;   // rebased offsets + model ids always go through staging
+        if (ragged) {
+            int64_t *ro = (int64_t *)small;
+            for (int64_t i = 0; i <= ni; ++i) ro[i] = off[i0 + i] - off[i0];
+        }
+        if (d->dm_ids) memcpy(small + (o_dm - o_off), d->dm_ids + i0, (size_t)ni * 4);
+        if (in_pinned) {
+            HIP_TRY(hipMemcpyAsync(sl.d_in, d->counts_plus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
+            HIP_TRY(hipMemcpyAsync(sl.d_in + o_cm, d->counts_minus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
+            HIP_TRY(hipMemcpyAsync(sl.d_in + o_sq, d->seq + q0, (size_t)nq, hipMemcpyHostToDevice, P->s_in));
+            if (in_bytes > o_off)
+                HIP_TRY(hipMemcpyAsync(sl.d_in + o_off, small, in_bytes - o_off, hipMemcpyHostToDevice, P->s_in));
+        } else {
+            const auto ts = tick();
+            P->team->copy(sl.p_in, d->counts_plus + c0, o_cm);
+            P->team->copy(sl.p_in + o_cm, d->counts_minus + c0, o_cm);
+            P->team->copy(sl.p_in + o_sq, d->seq + q0, (size_t)nq);
+            staged_here = since(ts);
+            st.stage_seconds += staged_here;
+            HIP_TRY(hipMemcpyAsync(sl.d_in, sl.p_in, in_bytes, hipMemcpyHostToDevice, P->s_in));
+        }
+        HIP_TRY(hipEventRecord(sl.ev_in, P->s_in));
+        HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_in, 0));
+        fpt_scan_desc cd = *d;
+        cd.n_intervals = ni;
+        cd.interval_off = ragged ? (const int64_t *)(sl.d_in + o_off) : nullptr;
+        cd.interval_off_host = ragged ? (const int64_t *)small : nullptr;
+        cd.counts_plus = (const double *)sl.d_in;
+        cd.counts_minus = (const double *)(sl.d_in + o_cm);
+        cd.seq = (const uint8_t *)(sl.d_in + o_sq);
+        cd.dm_ids = d->dm_ids ? (const int32_t *)(sl.d_in + o_dm) : nullptr;
+        double *dout = (double *)sl.d_out;
+        cd.exp_out = dout, cd.obs_out = dout + cb, cd.pval_out = dout + 2 * cb;
+        cd.winp_out = S ? dout + 3 * cb : nullptr;
+        cd.status_out = (int32_t *)(sl.d_out + (size_t)(3 + S) * tb);
+        HIP_TRY(hipMemsetAsync(cd.status_out, 0, (size_t)ni * 4, c->stream));
+        if (int rc = fpt_scan_dev(c, &cd)) return rc;
+        HIP_TRY(hipEventRecord(sl.ev_scan, c->stream));
+        HIP_TRY(hipStreamWaitEvent(P->s_out, sl.ev_scan, 0));
+        if (out_pinned) {
+            for (int t = 0; t < 3 + S; ++t)
+                if (outs[t]) HIP_TRY(hipMemcpyAsync(outs[t] + b0, sl.d_out + (size_t)t * tb, tb, hipMemcpyDeviceToHost, P->s_out));
+            if (d->status_out)
+                HIP_TRY(hipMemcpyAsync(d->status_out + i0, cd.status_out, (size_t)ni * 4, hipMemcpyDeviceToHost, P->s_out));
+        } else {
+            HIP_TRY(hipMemcpyAsync(sl.p_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, P->s_out));
+        }
+        HIP_TRY(hipEventRecord(sl.ev_out, P->s_out));
+        sl.busy = true;
+        sl.base0 = b0, sl.bases = cb, sl.iv0 = i0, sl.n_iv = ni;
+        st.issue_seconds += since(ti) - staged_here;
+        st.chunks += 1;
+        st.bytes_h2d += (int64_t)in_bytes;
+        st.bytes_d2h += (int64_t)out_bytes;
+        i0 = i1;
+    }
+    // (in the order the chunks were issued: the slot after the last one used holds the oldest)
+    for (int j = 0; j < kPipeSlots; ++j)
+        if (int rc = finish(P->slot[(st.chunks + j) % kPipeSlots])) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    st.bases = total;
+    P->last = st;
     return FPT_OK;
 }
 

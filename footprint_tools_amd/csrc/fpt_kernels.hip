@@ -793,6 +793,9 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
     const int64_t sbase = out_off + iv * (int64_t)(2 * pad + 7) + ta;
 
     // ---- A: stage table, model, counts and sequence codes
+    // (raised wave priority until the inputs are staged, as in k_scan_lean: a new tile's loads go out ahead of the
+    // arithmetic of the older wavefronts of the SIMD)
+    __builtin_amdgcn_s_setprio(3);
     if (!TBLG)
         for (int i = tid; i <= kTable; i += NT) smem[i] = a.table[i];
     // dispersion model of this interval (dm_ids: one slot index per interval, else slot 0 of
@@ -839,6 +842,7 @@ __device__ __forceinline__ void scan_tile(Args &a, const int64_t tile) {
         }
         for (int v = tid + kStage * NT; v < nc + 6; v += NT) sq[v] = (uint8_t)base_code(a.seq[sbase + v]);
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (ABL(32)) return;
 

@@ -185,9 +185,32 @@ class FootprintScanner(object):
         return ms.value
 
     # ---- numpy level ---------------------------------------------------------------------
-    def scan(self, counts_plus, counts_minus, seq, interval_len=None, interval_off=None, dm_ids=None):
-        """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status).
-        dm_ids: optional per-interval index into the scanner's list of dispersion models."""
+    def _desc(self, n_intervals):
+        """a scan descriptor with this scanner's geometry, model slots and scales"""
+        d = _lib.ScanDesc()
+        d.n_intervals = int(n_intervals)
+        d.half_win_width, d.smoothing_half_win_width = self.hw, self.shw
+        d.smoothing_clip = self.clip
+        d.n_scales = len(self.scales)
+        for i, s in enumerate(self.scales):
+            d.scales[i] = s
+        d.dm_id = self._model_slot()
+        d.n_dm = len(self.models)
+        d.nb_mode = self.nb_mode
+        return d
+
+    def scan(self, counts_plus, counts_minus, seq, interval_len=None, interval_off=None, dm_ids=None, pinned_out=False,
+             chunk_bases=0, out=None):
+        """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status): the per-call form a drop-in
+        caller uses (the reference's prediction.compute / dm.p_values / windowing.stouffers_z take and return numpy
+        arrays).  One fpt_scan_host call: the batch travels in chunks through a three-stage pipeline (host-to-device
+        copy, scan, device-to-host copy), the two directions of the link and the kernel overlapping.  Arrays made
+        by `ctx.pinned_empty` (inputs; outputs with pinned_out=True) are used by the copy engines directly, other
+        arrays go through pinned staging buffers the context keeps.
+        dm_ids: optional per-interval index into the scanner's list of dispersion models.
+        out: the dict an earlier call of the same shape returned -- its arrays are written again instead of new ones
+        being made (a fresh numpy array costs a page fault per 4 KiB when first written, a fresh page-locked one
+        ~170 ms per GiB to allocate: a caller that loops over batches reuses them)."""
         ctx = self.ctx
         cp, cm = _lib.f64(counts_plus).ravel(), _lib.f64(counts_minus).ravel()
         if isinstance(seq, str):
@@ -196,7 +219,7 @@ class FootprintScanner(object):
               else np.ascontiguousarray(seq, dtype=np.uint8).ravel())
         if interval_off is not None:
             off = np.ascontiguousarray(interval_off, dtype=np.int64)
-            n_iv, total = off.size - 1, int(off[-1])
+            n_iv, total = off.size - 1, int(off[-1] - off[0])
         else:
             lp = self.padded_len(interval_len)
             if cp.size % lp:
@@ -209,38 +232,38 @@ class FootprintScanner(object):
             raise ValueError("input sizes do not match the batch layout (counts %d/%d, seq %d/%d)"
                              % (cp.size, n_c, sq.size, n_s))
         S = len(self.scales)
-        bufs = []
-        try:
-            d_cp = DeviceArray(ctx, max(cp.nbytes, 16)).upload(cp); bufs.append(d_cp)
-            d_cm = DeviceArray(ctx, max(cm.nbytes, 16)).upload(cm); bufs.append(d_cm)
-            d_sq = DeviceArray(ctx, max(sq.nbytes, 16)).upload(sq); bufs.append(d_sq)
-            d_out = DeviceArray(ctx, max((3 + S) * total * 8, 16)); bufs.append(d_out)
-            d_st = DeviceArray(ctx, max(n_iv * 4, 16)).upload(np.zeros(max(n_iv, 1), np.int32)); bufs.append(d_st)
-            d_off = None
-            if off is not None:
-                d_off = DeviceArray(ctx, off.nbytes).upload(off); bufs.append(d_off)
-            d_dm = None
-            if dm_ids is not None:
-                ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
-                if ids.size != n_iv or ids.min() < 0 or ids.max() >= len(self.models):
-                    raise ValueError("dm_ids needs one valid model index per interval")
-                d_dm = DeviceArray(ctx, max(ids.nbytes, 16)).upload(ids); bufs.append(d_dm)
-            t8 = total * 8
-            self.scan_dev(n_iv, d_cp.ptr, d_cm.ptr, d_sq.ptr, exp_out=d_out.ptr, obs_out=d_out.ptr + t8,
-                          pval_out=d_out.ptr + 2 * t8, winp_out=(d_out.ptr + 3 * t8) if S else None,
-                          interval_len=interval_len, interval_off_dev=d_off.ptr if d_off else None,
-                          interval_off_host=off, status_out=d_st.ptr, dm_ids_dev=d_dm.ptr if d_dm else None)
-            ctx.synchronize()
-            flat = d_out.download(np.float64, (3 + S) * total)
-            status = d_st.download(np.int32, n_iv)
-        finally:
-            for b in bufs:
-                b.free()
+        ids = None
+        if dm_ids is not None:
+            ids = np.ascontiguousarray(dm_ids, dtype=np.int32)
+            if ids.size != n_iv or (n_iv and (ids.min() < 0 or ids.max() >= len(self.models))):
+                raise ValueError("dm_ids needs one valid model index per interval")
+        empty = ctx.pinned_empty if pinned_out else (lambda shape, dtype=np.float64: np.empty(shape, dtype=dtype))
+        if out is not None:
+            flat, status = out.get("_flat"), out.get("status")
+            if flat is None or status is None or flat.size != (3 + S) * total or status.size != n_iv:
+                raise ValueError("`out` is not the result of a scan of this shape")
+        else:
+            flat = empty((3 + S) * total)
+            status = empty(max(n_iv, 1), np.int32)[:n_iv]
+        status[:] = 0
+        if n_iv and total:
+            ctx.set_bias_table(self.table, self.dflt)
+            d = self._desc(n_iv)
+            d.interval_len = int(interval_len or 0)
+            d.interval_off = _lib.ptr(off)
+            d.interval_off_host = _lib.ptr(off)
+            d.dm_ids = _lib.ptr(ids)
+            d.counts_plus, d.counts_minus, d.seq = cp.ctypes.data, cm.ctypes.data, sq.ctypes.data
+            d.exp_out, d.obs_out = flat.ctypes.data, flat.ctypes.data + total * 8
+            d.pval_out = flat.ctypes.data + 2 * total * 8
+            d.winp_out = flat.ctypes.data + 3 * total * 8 if S else None
+            d.status_out = status.ctypes.data
+            _lib.check(ctx.L.fpt_scan_host(ctx.h, C.byref(d), int(chunk_bases)))
         pval = flat[2 * total:3 * total]
         if self.nb_mode == _lib.NB_NONE:  # counts only: no p-values were computed
             pval = np.full(total, np.nan)
         return dict(exp=flat[:total], obs=flat[total:2 * total], pval=pval,
-                    winp=flat[3 * total:].reshape(S, total), status=status)
+                    winp=flat[3 * total:].reshape(S, total), status=status, _flat=flat)
 
     # ---- empirical FDR (cli/detect.py:132-135) ------------------------------------------
     def fdr_dev(self, n_intervals, exp, winp, efdr_out, times=100, seed=0, half_win_width=3,

@@ -209,6 +209,36 @@ int fpt_drop_kept_tables(fpt_ctx *ctx);
 /* Enqueue the fused scan on the context's stream (no synchronisation). */
 int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
 
+/* The same scan on HOST arrays: what the reference's per-call API is (`prediction.compute` /
+ * `dm.p_values` / `windowing.stouffers_z` take numpy arrays and return numpy arrays:
+ * modeling/predict.pyx:116-163, modeling/dispersion.pyx:291-316, stats/windowing.pyx:114-130).  EVERY
+ * pointer of `desc` is a host pointer here (interval_off or interval_off_host: the host offsets of a ragged
+ * batch, either field; status_out optional).  The batch is cut into chunks of about `chunk_bases` output bases
+ * (0: 2^21) that travel through a three-stage pipeline -- host-to-device copy, fpt_scan_dev, device-to-host copy,
+ * each on its own stream, three chunks in flight -- so that the two directions of the PCIe link and the kernel
+ * overlap.  Arrays from fpt_host_alloc (or registered with hipHostRegister) are read and written by the copy
+ * engines directly; any other (pageable) array goes through pinned staging buffers the context keeps, moved by
+ * a small team of host threads.  Returns when every output is in place.  Results are those of fpt_scan_dev on
+ * the whole batch, bit for bit (intervals are independent). */
+int fpt_scan_host(fpt_ctx *ctx, const fpt_scan_desc *desc, int64_t chunk_bases);
+
+/* what the last fpt_scan_host of the context did */
+typedef struct fpt_scan_host_stats {
+    double seconds;           /* wall time of the call */
+    int64_t bases;            /* output bases */
+    int64_t chunks;
+    int64_t bytes_h2d, bytes_d2h;
+    int32_t inputs_pinned, outputs_pinned; /* 1: the caller's arrays were used by the copy engines directly */
+    /* where the calling thread spent the call: waiting for a chunk's results, moving bytes between the caller's
+     * pageable arrays and the staging buffers, and issuing copies and launches */
+    double wait_seconds, stage_seconds, issue_seconds;
+} fpt_scan_host_stats;
+int fpt_scan_host_last(fpt_ctx *ctx, fpt_scan_host_stats *out);
+
+/* page-locked host memory for the arrays of fpt_scan_host (hipHostMalloc / hipHostFree) */
+int fpt_host_alloc(fpt_ctx *ctx, int64_t bytes, void **host_out);
+int fpt_host_free(fpt_ctx *ctx, void *host);
+
 /* ---- empirical FDR of the window p-values (cli/detect.py:132-135 for many intervals)
  *
  * Reference, per interval: `_, pvals_null = dm.sample(exp, times)` draws `times` NB counts per

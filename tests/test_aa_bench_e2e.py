@@ -71,3 +71,11 @@ def test_bench_default_line_carries_every_configuration():
     # (with --leg-intervals the counters are not collected: the fractions are None there, the keys are in the line)
     assert "ta_busy" in c5["roofline"] and "lds_busy" in c5["roofline"]
     assert d["configs"]["4"]["workload"].startswith("20000xragged")
+    # the host-arrays leg (numpy in / numpy out through FootprintScanner.scan, config 2's size, PCIe included)
+    h = d["host_arrays"]
+    assert "error" not in h, h
+    assert h["parity"]["exp_bit_exact"] is True and h["parity"]["p_max_rel_err"] < 1e-6 and h["parity"]["pinned_equals_pageable_bitwise"] is True
+    assert h["pinned"]["arrays_used_directly"] is True and h["pageable"]["arrays_used_directly"] is False
+    assert h["pinned"]["value"] > 1e8 and h["pageable"]["value"] > 1e8
+    # the CPU baseline's figures as plain scalars are absent here (--no-cpu-baseline); the multi-GPU block is None at N = 1
+    assert d["multi_gpu"] is None

@@ -371,6 +371,72 @@ def test_fused_scan_vs_oracle(fpt, orc, L, hw, shw, clip, scales, dm, nb_mode):
         assert rel_err(out["winp"], wp) < P_TOL
 
 
+@pytest.mark.parametrize("shape", ["uniform", "ragged"])
+def test_scan_host_pipeline_equals_one_call(fpt, orc, shape):
+    """FootprintScanner.scan (host arrays in and out: fpt_scan_host) cuts a batch into chunks that travel through a
+    three-stage pipeline.  Whatever the chunk size -- one interval per chunk, more chunks than pipeline slots, one
+    chunk for everything -- and whether the caller's arrays are page-locked (used by the copy engines directly)
+    or pageable (staged), the tracks are those of ONE fpt_scan_dev over the whole batch, bit for bit; and they
+    match the oracle."""
+    from footprint_tools_amd.scan import DeviceArray, FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    ctx = fpt.get_ctx()
+    models = [_DM(lat["mu_A"], lat["r_A"]), _DM(lat["mu_B"], lat["r_B"])]
+    scales = (3, 10)
+    sc = FootprintScanner(table, models, 5, 50, 0.01, scales, nb_mode="memo")
+    rs = np.random.RandomState(11)
+    n_iv = 37
+    if shape == "uniform":
+        L, off = 300, None
+        lens = np.full(n_iv, 300)
+    else:
+        L = None
+        lens = rs.choice([1, 7, 50, 162, 163, 400, 1100, 2300], n_iv)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(lens.sum())
+    n_c, n_s = sc.input_sizes(n_iv, total)
+    cp, cm, sq = orc.synth_counts(9, 0, n_c, 0), orc.synth_counts(9, 0, n_c, 1), orc.synth_bases(9, 0, n_s)
+    ids = rs.randint(0, 2, n_iv).astype(np.int32)
+    # the reference: one device call over the whole batch
+    bufs = [DeviceArray(ctx, a.nbytes).upload(a) for a in (cp, cm, sq, ids)]
+    d_off = DeviceArray(ctx, off.nbytes).upload(off) if off is not None else None
+    d_out = DeviceArray(ctx, (3 + len(scales)) * total * 8)
+    t8 = total * 8
+    sc.scan_dev(n_iv, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, exp_out=d_out.ptr, obs_out=d_out.ptr + t8,
+                pval_out=d_out.ptr + 2 * t8, winp_out=d_out.ptr + 3 * t8, interval_len=L,
+                interval_off_dev=d_off.ptr if d_off else None, interval_off_host=off, dm_ids_dev=bufs[3].ptr)
+    ctx.synchronize()
+    want = d_out.download(np.float64, (3 + len(scales)) * total)
+    for b in bufs + [d_out] + ([d_off] if d_off else []):
+        b.free()
+    pin = [ctx.pinned_empty(a.shape, a.dtype) for a in (cp, cm, sq)]
+    for dst, src in zip(pin, (cp, cm, sq)):
+        dst[...] = src
+    for chunk in (1, 1500, 0):
+        for pinned in (False, True):
+            a_in = pin if pinned else (cp, cm, sq)
+            out = sc.scan(a_in[0], a_in[1], a_in[2], interval_len=L, interval_off=off, dm_ids=ids, pinned_out=pinned,
+                          chunk_bases=chunk)
+            st = ctx.scan_host_last()
+            assert st["bases"] == total and st["inputs_pinned"] == int(pinned) and st["outputs_pinned"] == int(pinned)
+            assert st["chunks"] == (n_iv if chunk == 1 else st["chunks"]) and (chunk != 0 or st["chunks"] == 1)
+            got = np.concatenate([out["exp"], out["obs"], out["pval"], out["winp"].ravel()])
+            assert np.array_equal(got, want, equal_nan=True), (shape, chunk, pinned)
+            assert not out["status"].any()
+    # ... and the oracle, interval by interval
+    o_off = np.concatenate([[0], np.cumsum(lens)])
+    for i in (0, 5, n_iv - 1):
+        Li = int(lens[i])
+        c0, s0 = int(o_off[i]) + i * 111, int(o_off[i]) + i * 117
+        m = models[ids[i]]
+        e, o, p, wp = orc.detect_batch(cp[c0:c0 + Li + 111], cm[c0:c0 + Li + 111], sq[s0:s0 + Li + 117], 1, Li, 5, 50, 0.01,
+                                       table, m.mu_params, m.r_params, np.array(scales, np.int32))
+        sl = slice(int(o_off[i]), int(o_off[i + 1]))
+        assert np.array_equal(out["exp"][sl], e) and np.array_equal(out["obs"][sl], o)
+        assert rel_err(out["pval"][sl], p) < P_TOL and rel_err(out["winp"][:, sl], wp) < P_TOL
+
+
 @pytest.mark.parametrize("kind", ["float", "huge", "mixed"])
 def test_fused_scan_non_integer_counts(fpt, orc, kind):
     """the smoothing scans run on int32 when a tile's window sums are small integers and on
@@ -987,7 +1053,7 @@ def test_sparse_counts_stay_in_the_first_pass(fpt, orc):
     sq = orc.synth_bases(3, 0, n_iv * (l + 6))
     for lam in (0.02, 0.1):
         cp, cm = rs.poisson(lam, n_iv * l).astype(np.float64), rs.poisson(lam, n_iv * l).astype(np.float64)
-        out = sc.scan(cp, cm, sq, interval_len=L)
+        out = sc.scan(cp, cm, sq, interval_len=L, chunk_bases=1 << 40)  # (one chunk: scan_stats speaks of the last launch)
         tiles, redone, _ = sc.ctx.scan_stats()
         if _lean_on():
             assert tiles == n_iv and redone < 0.03 * tiles, (lam, tiles, redone)
