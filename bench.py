@@ -1195,14 +1195,31 @@ def main():
             # (three units near their limits at once, none alone: the vector pipes, LDS, and the texture addresser that
             # the sampler's two table gathers per draw go through -- `frac` stays the vector pipes' as the review of
             # round 4 defined it, the other two ride beside it)
+            # A work-based fraction (round 6; rounds 4 - 5 printed VALUBusy here, which any kernel that burns vector
+            # instructions scores high on): draws per second over the rate at which the vector pipes could issue a
+            # FLOOR of instructions per draw -- Philox4x32-10 15 (sixty per block of four words), the alias draw 4 (slot,
+            # address, compare, select), the 7-term window sum and its negation 7, the guide slice 3 (fused multiply-add,
+            # clamp, convert), one threshold probe 2, the histogram add 1: 32 per draw and lane, against the 86 the
+            # kernel issues (`valu_instructions_per_draw`).  The gathers and LDS accesses of the same floor (2 and ~6 per
+            # draw) fit beside them; VALUBusy stays in the block as `valu_busy`.
+            floor_instr = 32.0
+            floor_draws_per_s = peak * 1e9 * 64.0 / floor_instr
+            draws_rate = (total * fdr_times / (draws_ms * 1e-3)) if draws_ms else None
             roof = dict(bound="valu+lds issue",
                         also_near_its_limit="the texture addresser (the sampler's two table gathers per draw): ta_busy",
                         kernel="the null draws of fpt_fdr_dev: k_fdr_null<NT,false,3,true,3> (one workgroup per interval of up to "
                                "256 bases) + k_fdr_slice<192> (slices of longer intervals); set-up k_fdr_null<...,1> before them",
-                        achieved=(draws["valu_instructions_per_call"] / (draws_ms * 1e-3) / 1e9 if draws and draws_ms else None),
-                        peak=peak, unit="G wave64 VALU instructions/s",
-                        # = rocprofv3's VALUBusy of the draw kernels: SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles)
-                        frac=(draws["valu_busy"] if draws else None), traffic=None,
+                        achieved=(draws_rate / 1e9 if draws_rate else None),
+                        peak=floor_draws_per_s / 1e9, unit="G null draws/s",
+                        frac=(draws_rate / floor_draws_per_s if draws_rate else None), traffic=None,
+                        frac_is="draws/s of the draw kernels over the vector-issue rate of a 32-instruction draw (Philox 15, alias "
+                                "draw 4, window 7, guide slice 3, one probe 2, histogram 1) at 1,024 SIMDs x clock / 4",
+                        floor_valu_instructions_per_draw=floor_instr,
+                        valu_G_instructions_per_s=(draws["valu_instructions_per_call"] / (draws_ms * 1e-3) / 1e9
+                                                   if draws and draws_ms else None),
+                        valu_peak_G_instructions_per_s=peak,
+                        # rocprofv3's VALUBusy of the draw kernels: SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles)
+                        valu_busy=(draws["valu_busy"] if draws else None),
                         lds_busy=(draws["lds_busy"] if draws else None),
                         ta_busy=(draws.get("ta_busy") if draws else None),
                         ta_busy_cycles_per_gather_instruction=(draws.get("ta_busy_cycles_per_vmem_read_instruction") if draws else None),

@@ -5,7 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-template <int BYTES, int SPREAD>  // SPREAD: 0 = random over the table, 1 = random inside one 128-byte line per 16 lanes, 2 = coalesced
+// ACTIVE: lanes (of 64, a different random subset at every instruction) that take part in the gather
+template <int BYTES, int SPREAD, int ACTIVE = 64>  // SPREAD: 0 = random over the table, 1 = random inside one 128-byte line per 16 lanes, 2 = coalesced
 __global__ void __launch_bounds__(256) k(int iters, const char *tab, uint32_t mask, uint32_t *out) {
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
     uint32_t acc = 0;
@@ -17,6 +18,7 @@ __global__ void __launch_bounds__(256) k(int iters, const char *tab, uint32_t ma
             if (SPREAD == 1) idx = ((threadIdx.x >> 4) * 977u + (i * 8 + j) * 131u) * (128 / BYTES) + (idx & (128 / BYTES - 1));
             if (SPREAD == 2) idx = threadIdx.x + (i * 8 + j) * 64;
             const uint32_t off = (idx * BYTES) & mask & ~(uint32_t)(BYTES - 1);
+            if (ACTIVE < 64 && ((x >> 3) & 63u) >= (uint32_t)ACTIVE) continue;
             if (BYTES == 4) { acc += *reinterpret_cast<const uint32_t *>(tab + off); asm volatile("" ::: "memory"); }
             if (BYTES == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(tab + off); acc += v.x ^ v.y; asm volatile("" ::: "memory"); }
             if (BYTES == 16) { const uint4 v = *reinterpret_cast<const uint4 *>(tab + off); acc += v.x ^ v.y ^ v.z ^ v.w; asm volatile("" ::: "memory"); }
@@ -24,14 +26,14 @@ __global__ void __launch_bounds__(256) k(int iters, const char *tab, uint32_t ma
     }
     if (acc == 0x12345u) out[0] = acc;
 }
-template <int BYTES, int SPREAD> void run(const char *name, const char *tab, uint32_t table_bytes, uint32_t *out, int n_cu, double ghz) {
+template <int BYTES, int SPREAD, int ACTIVE = 64> void run(const char *name, const char *tab, uint32_t table_bytes, uint32_t *out, int n_cu, double ghz) {
     printf("%-58s", name);
     for (int w : {2, 8}) {
         const int iters = 500;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL((k<BYTES, SPREAD>), dim3(n_cu * w), dim3(256), 0, 0, 10, tab, table_bytes - 1, out);
+        hipLaunchKernelGGL((k<BYTES, SPREAD, ACTIVE>), dim3(n_cu * w), dim3(256), 0, 0, 10, tab, table_bytes - 1, out);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<BYTES, SPREAD>), dim3(n_cu * w), dim3(256), 0, 0, iters, tab, table_bytes - 1, out);
+        hipLaunchKernelGGL((k<BYTES, SPREAD, ACTIVE>), dim3(n_cu * w), dim3(256), 0, 0, iters, tab, table_bytes - 1, out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double cyc = ms * 1e-3 * ghz * 1e9;
@@ -48,6 +50,11 @@ int main() {
     run<4, 0>("4 B, random over 16 KB", tab, 1 << 14, out, n_cu, ghz);
     run<8, 0>("8 B, random over 16 KB", tab, 1 << 14, out, n_cu, ghz);
     run<16, 0>("16 B, random over 16 KB", tab, 1 << 14, out, n_cu, ghz);
+    run<8, 0, 48>("8 B, random over 16 KB, 48 of 64 lanes", tab, 1 << 14, out, n_cu, ghz);
+    run<8, 0, 32>("8 B, random over 16 KB, 32 of 64 lanes", tab, 1 << 14, out, n_cu, ghz);
+    run<8, 0, 16>("8 B, random over 16 KB, 16 of 64 lanes", tab, 1 << 14, out, n_cu, ghz);
+    run<8, 0, 8>("8 B, random over 16 KB, 8 of 64 lanes", tab, 1 << 14, out, n_cu, ghz);
+    run<16, 0, 32>("16 B, random over 16 KB, 32 of 64 lanes", tab, 1 << 14, out, n_cu, ghz);
     run<4, 0>("4 B, random over 256 KB (L2)", tab, 1 << 18, out, n_cu, ghz);
     run<8, 0>("8 B, random over 256 KB (L2)", tab, 1 << 18, out, n_cu, ghz);
     run<16, 0>("16 B, random over 256 KB (L2)", tab, 1 << 18, out, n_cu, ghz);
