@@ -390,10 +390,10 @@ int fpt_bam_read(fpt_bam *b, int64_t max_reads, int32_t *ref_id, int32_t *ref_st
     return FPT_OK;
 }
 
-// The records themselves (SAM/BAM specification 4.2: every record behind its 4-byte block_size), for what needs
-// more of an alignment than its coordinates -- the allelically resolved counts (cutcounts.py:315-488) read a
-// read's name, mate flags, template length, bases, base qualities and its NM / XM tag.  Same walk, same region
-// rule and the same checks as fpt_bam_read; a record is handed over whole or not at all.
+// The records themselves (SAM/BAM specification 4.2: every record behind its 4-byte block_size), for a caller that
+// needs more of an alignment than its coordinates (name, mate flags, template length, bases, qualities, tags).  Same
+// walk, same region rule and the same checks as fpt_bam_read; a record is handed over whole or not at all.  When
+// the FIRST record does not fit `cap` the call fails with *n_out = 0 and *bytes_out = the bytes that record needs.
 int fpt_bam_read_raw(fpt_bam *b, int64_t max_reads, uint8_t *buf, int64_t cap, int64_t *n_out, int64_t *bytes_out) {
     if (!b || !n_out || !bytes_out || max_reads < 0 || cap < 0 || (cap > 0 && !buf))
         return fpt_internal_fail(FPT_ERR_INVALID, "bad arguments");
@@ -417,7 +417,11 @@ int fpt_bam_read_raw(fpt_bam *b, int64_t max_reads, uint8_t *buf, int64_t cap, i
             break;
         }
         if (used + 4 + (int64_t)block > cap) {  // no room: the record stays for the next call
-            if (n == 0) return fpt_internal_fail(FPT_ERR_INVALID, "buffer of %lld bytes cannot hold a record of %d", (long long)cap, block);
+            if (n == 0) {  // nothing read; *bytes_out says how large a buffer this record needs
+                *n_out = 0;
+                *bytes_out = 4 + (int64_t)block;
+                return fpt_internal_fail(FPT_ERR_INVALID, "buffer of %lld bytes cannot hold a record of %d", (long long)cap, block);
+            }
             break;
         }
         std::memcpy(buf + used, rec, 4 + (size_t)block);

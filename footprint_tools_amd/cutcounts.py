@@ -13,12 +13,6 @@ a read counts if it is not QC-fail (remove_qcfail) / duplicate (remove_dups), ha
 and -- when paired -- is a proper pair and neither secondary nor supplementary; forward reads cut
 at reference_start + offset[0] on '+', reverse reads at reference_end + offset[1] on '-'.
 
-`bamfile.lookup_allelic(chrom, start, end, pos, ref, alt, flip=False)` (cutcounts.py:315-488) resolves the counts
-of a window by the allele its read pairs carry at a variant: host code like the reference's -- it walks a few
-hundred reads per variant -- over the records the library's reader hands out whole (`fpt_bam_read_raw`), with the
-reference's rules for a usable base call (quality >= 20, more than 3 bases from the read's 5' end, at most one
-mismatch for the reference allele and two for the alternate by the XM / NM tag) and for a pair (both mates agree).
-
 Differences, on purpose: the file is read once by the library's own BGZF/BAM reader (htslib /
 pysam are not available here; no .bai, no CRAM; blocks inflated on a team of threads), all
 alignments are kept ON THE DEVICE (13 bytes per alignment; the host keeps one start key per 256
@@ -40,109 +34,6 @@ import numpy as np
 
 from . import _lib
 from .scan import DeviceArray
-
-
-class ReadError(Exception):
-    ERROR_ALIGNMENT = (0, "Read alignment problematic (QC fail, duplicate, or MAPQ < 1)")
-    ERROR_5PROXIMITY = (1, "Variant too close to 5' end of tag")
-    ERROR_BASEQ = (2, "Base quality < 20")
-    ERROR_GENOTYPE = (3, "Base does not match reference or expected alternate allele")
-    ERROR_MISMATCH = (4, "Read contains too many mismatches")
-
-    def __init__(self, e):
-        self.value = e[0]
-        self.message = e[1]
-
-
-class GenotypeError(Exception):
-    pass
-
-
-class ReadFormatError(Exception):
-    pass
-
-
-_SEQ_CODES = "=ACMGRSVTWYHKDBN"
-
-
-class aligned_read(object):
-    """One alignment record (SAM/BAM specification 4.2) with the members of pysam.AlignedSegment that
-    cutcounts.py:119-248, 315-385 read: flags, reference_start / reference_end, mapping_quality, query_name,
-    query_sequence, query_qualities, template_length, reference_id, has_tag / get_tag for integer tags."""
-
-    __slots__ = ("reference_id", "reference_start", "reference_end", "mapping_quality", "flag", "query_name",
-                 "next_reference_id", "next_reference_start", "template_length", "query_sequence", "query_qualities",
-                 "_tags", "reference_name")
-
-    def __init__(self, rec, ref_names=None):
-        import struct
-        (rid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, nrid, npos, tlen) = struct.unpack_from("<iiBBHHHiiii", rec, 0)
-        self.reference_id, self.reference_start, self.mapping_quality, self.flag = rid, pos, mapq, flag
-        self.next_reference_id, self.next_reference_start, self.template_length = nrid, npos, tlen
-        at = 32
-        self.query_name = bytes(rec[at:at + max(l_name - 1, 0)]).decode("ascii", "replace")
-        at += l_name
-        span = 0
-        for k in range(n_cig):
-            v = struct.unpack_from("<I", rec, at + 4 * k)[0]
-            if (v & 0xf) in (0, 2, 3, 7, 8):  # M D N = X consume the reference
-                span += v >> 4
-        self.reference_end = pos + span if span > 0 else None  # (pysam: None without such an operation)
-        at += 4 * n_cig
-        packed = rec[at:at + (l_seq + 1) // 2]
-        seq = []
-        for b in packed:
-            seq.append(_SEQ_CODES[b >> 4])
-            seq.append(_SEQ_CODES[b & 0xf])
-        self.query_sequence = "".join(seq[:l_seq]) if l_seq else None
-        at += (l_seq + 1) // 2
-        q = rec[at:at + l_seq]
-        self.query_qualities = None if (l_seq == 0 or (len(q) and q[0] == 0xff)) else list(q)
-        at += l_seq
-        self._tags = {}
-        n = len(rec)
-        sizes = {"c": ("<b", 1), "C": ("<B", 1), "s": ("<h", 2), "S": ("<H", 2), "i": ("<i", 4), "I": ("<I", 4), "f": ("<f", 4), "A": (None, 1)}
-        while at + 3 <= n:  # the optional fields: tag (2), type (1), value
-            tag, ty = bytes(rec[at:at + 2]).decode("ascii", "replace"), chr(rec[at + 2])
-            at += 3
-            if ty in sizes:
-                fmt, w = sizes[ty]
-                if at + w > n:
-                    break
-                self._tags[tag] = chr(rec[at]) if fmt is None else struct.unpack_from(fmt, rec, at)[0]
-                at += w
-            elif ty in "ZH":
-                end = at
-                while end < n and rec[end] != 0:
-                    end += 1
-                self._tags[tag] = bytes(rec[at:end]).decode("ascii", "replace")
-                at = end + 1
-            elif ty == "B":
-                if at + 5 > n:
-                    break
-                sub, cnt = chr(rec[at]), struct.unpack_from("<i", rec, at + 1)[0]
-                at += 5 + cnt * sizes.get(sub, (None, 1))[1]
-            else:
-                break
-        self.reference_name = ref_names[rid] if (ref_names is not None and 0 <= rid < len(ref_names)) else None
-
-    # the flag bits pysam names (SAM specification 1.4)
-    is_paired = property(lambda self: bool(self.flag & 0x1))
-    is_proper_pair = property(lambda self: bool(self.flag & 0x2))
-    is_unmapped = property(lambda self: bool(self.flag & 0x4))
-    is_reverse = property(lambda self: bool(self.flag & 0x10))
-    is_read1 = property(lambda self: bool(self.flag & 0x40))
-    is_read2 = property(lambda self: bool(self.flag & 0x80))
-    is_secondary = property(lambda self: bool(self.flag & 0x100))
-    is_qcfail = property(lambda self: bool(self.flag & 0x200))
-    is_duplicate = property(lambda self: bool(self.flag & 0x400))
-    is_supplementary = property(lambda self: bool(self.flag & 0x800))
-
-    def has_tag(self, tag):
-        return tag in self._tags
-
-    def get_tag(self, tag, with_value_type=False):
-        return self._tags[tag]
 
 
 class CutCountDesc(C.Structure):
@@ -167,7 +58,6 @@ def _bind(L):
     L.fpt_bam_read.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.fpt_bam_has_index.argtypes = [vp, C.POINTER(i32)]
     L.fpt_bam_seek_region.argtypes = [vp, i32, i64, i64]
-    L.fpt_bam_read_raw.argtypes = [vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fpt_cut_counts_dev.argtypes = [vp, C.POINTER(CutCountDesc)]
     return L
 
@@ -395,178 +285,9 @@ class bamfile(object):
         cm.free()
         return {"+": plus, "-": minus, "fragments": []}
 
-    # ---- the allelically resolved counts (cutcounts.py:119-248, 315-488): host code, like the reference's
-    def fetch(self, chrom, start, end):
-        """the alignments that overlap [start, end) of `chrom`, in file order, as `aligned_read`s -- what
-        `samfile.fetch(chrom, start, end)` yields (cutcounts.py:191).  Through the BAI index when there is one,
-        else in one pass over the file."""
-        import struct
-        L = _bind(_lib.load())
-        rid = self._ref_index.get(chrom, -1)
-        if rid < 0:
-            return
-        names = [n for n, _ in self.references]
-        h = C.c_void_p()
-        _lib.check(L.fpt_bam_open(str(self.filepath).encode(), C.byref(h)))
-        try:
-            indexed = C.c_int32(0)
-            _lib.check(L.fpt_bam_has_index(h, C.byref(indexed)))
-            if indexed.value:
-                _lib.check(L.fpt_bam_seek_region(h, rid, max(int(start), 0), int(end)))
-            cap = 1 << 20
-            buf = (C.c_uint8 * cap)()
-            n, used = C.c_int64(), C.c_int64()
-            while True:
-                _lib.check(L.fpt_bam_read_raw(h, 4096, buf, cap, C.byref(n), C.byref(used)))
-                if n.value == 0:
-                    break
-                raw = C.string_at(buf, used.value)
-                at = 0
-                for _ in range(n.value):
-                    block = struct.unpack_from("<i", raw, at)[0]
-                    read = aligned_read(raw[at + 4:at + 4 + block], names)
-                    at += 4 + block
-                    if read.reference_id != rid or read.is_unmapped:
-                        continue
-                    if read.reference_start >= end:
-                        if indexed.value:
-                            return
-                        continue
-                    r_end = read.reference_end if read.reference_end is not None else read.reference_start + 1
-                    if r_end > start:
-                        yield read
-        finally:
-            L.fpt_bam_close(h)
-
-    def validate_read(self, read):
-        """cutcounts.py:119-145"""
-        if self.remove_qcfail and read.is_qcfail:
-            raise ReadError(ReadError.ERROR_ALIGNMENT)
-        if self.remove_dups and read.is_duplicate:
-            raise ReadError(ReadError.ERROR_ALIGNMENT)
-        if read.mapping_quality < self.min_qual:
-            raise ReadError(ReadError.ERROR_ALIGNMENT)
-        return read
-
-    def read_pair_generator(self, chrom, start, end):
-        """(read1, read2) of every usable pair with an alignment in [start - 10, end + 10) -- either may be
-        None: single-end data, or a mate outside the window (cutcounts.py:170-229)"""
-        waiting = {}
-        for read in self.fetch(chrom, max(start - 10, 0), end + 10):
-            try:
-                self.validate_read(read)
-            except ReadError:
-                continue
-            if not read.is_paired:
-                yield read, None
-                continue
-            if not read.is_proper_pair or read.is_secondary or read.is_supplementary:
-                continue
-            name = read.query_name
-            if name not in waiting:
-                waiting[name] = [read, None] if read.is_read1 else [None, read]
-            else:
-                first, second = waiting.pop(name)
-                yield (read, second) if read.is_read1 else (first, read)
-        for first, second in waiting.values():  # pairs whose mate lies outside the window
-            yield first, second
-
-    def _add_read(self, read, fw, rev):
-        """cutcounts.py:231-248"""
-        if read.is_reverse:
-            a = int(read.reference_end) + self.offset[1]
-            rev[a] = rev.get(a, 0.0) + 1.0
-        else:
-            a = int(read.reference_start) + self.offset[0]
-            fw[a] = fw.get(a, 0.0) + 1.0
-
-    def _get_fragment(self, read):
-        """the fragment of a mapped read, from the 5' ends of the pair (cutcounts.py:250-272)"""
-        from .intervals import genomic_interval
-        tlen = read.template_length
-        if read.is_reverse:
-            end = int(read.reference_end) + self.offset[1]
-            start = end + tlen
-        else:
-            start = int(read.reference_start) + self.offset[0]
-            end = start + tlen
-        return genomic_interval(read.reference_name, start, end)
-
-    def _validate_genotype(self, read, pos, ref, alt):
-        """the allele a read carries at `pos` (0-based): `ref`, `alt`, or None where the read does not cover
-        the position; ReadError for a base call that cannot be used (cutcounts.py:315-385)"""
-        if not read:
-            return None
-        try:
-            offset = pos - read.reference_start
-            if offset < 0:
-                raise IndexError
-            base_call = read.query_sequence[offset]
-            qual = read.query_qualities[offset]
-            if qual < 20:
-                raise ReadError(ReadError.ERROR_BASEQ)
-            offset_5p = read.reference_end - 1 - pos if read.is_reverse else pos - read.reference_start
-            if offset_5p <= 3:
-                raise ReadError(ReadError.ERROR_5PROXIMITY)
-            if read.has_tag("XM"):
-                tag = "XM"
-            elif read.has_tag("NM"):
-                tag = "NM"
-            else:
-                raise ReadFormatError("No mismatch tag in read! (must contain XM or NM tag)")
-            mm = int(read.get_tag(tag, with_value_type=False))
-            if base_call == ref:
-                if mm > 1:
-                    raise ReadError(ReadError.ERROR_MISMATCH)
-                return ref
-            if base_call == alt:
-                if mm > 2:
-                    raise ReadError(ReadError.ERROR_MISMATCH)
-                return alt
-            raise ReadError(ReadError.ERROR_GENOTYPE)
-        except IndexError:  # the variant lies outside the read
-            return None
-
-    def lookup_allelic(self, chrom, start, end, pos, ref, alt, flip=False):
-        """Counts of [start, end) resolved by the allele the read pairs carry at the variant `pos` (0-based):
-        {ref: {...}, alt: {...}, 'other': {...}}, each {'+': array, '-': array, 'fragments': [...]} -- 'other'
-        holds the pairs that do not cover the variant; a pair with an unusable base call or discordant mates is
-        left out (cutcounts.py:387-488)."""
-        import logging
-        counts = {k: ({}, {}, []) for k in ("ref", "alt", "non")}
-        for read1, read2 in self.read_pair_generator(chrom, max(start - 10, 0), end + 10):
-            try:
-                g1 = self._validate_genotype(read1, pos, ref, alt)
-                g2 = self._validate_genotype(read2, pos, ref, alt)
-                if (not g1) and (not g2):
-                    fw, rev, reads = counts["non"]
-                elif (g1 and g2) and g1 != g2:
-                    raise ReadError(ReadError.ERROR_GENOTYPE)
-                elif g1 == ref or g2 == ref:
-                    fw, rev, reads = counts["ref"]
-                elif g1 == alt or g2 == alt:
-                    fw, rev, reads = counts["alt"]
-                else:
-                    raise ReadError(ReadError.ERROR_GENOTYPE)
-                if read1:
-                    self._add_read(read1, fw, rev)
-                if read2:
-                    self._add_read(read2, fw, rev)
-                reads.append(self._get_fragment(read1 if read1 else read2))
-            except ReadError as e:
-                logging.debug(e)
-                continue
-
-        def arrays(fw, rev, reads):
-            f = np.array([fw.get(i, 0.0) for i in range(start, end)])
-            r = np.array([rev.get(i, 0.0) for i in range(start, end)])
-            return {"+": r[::-1] if flip else f, "-": f[::-1] if flip else r, "fragments": reads}
-
-        return {ref: arrays(*counts["ref"]), alt: arrays(*counts["alt"]), "other": arrays(*counts["non"])}
-
     def __getitem__(self, x):
-        """intervals only: the reference's dispatch hands a `pysam.VariantRecord` to `lookup_allelic` as ONE
-        argument (cutcounts.py:513-515), which raises TypeError there -- call `lookup_allelic` directly"""
+        """intervals only (the allelically resolved counts of cutcounts.py:315-488 are outside this path: SURVEY.md
+        section 8 f-3 names cutcounts.py:231-313 and :119-145)"""
         if not hasattr(x, "chrom") or not hasattr(x, "start") or not hasattr(x, "end"):
             raise TypeError("Query type not supported: %s" % type(x))
         return self.lookup(x)

@@ -32,7 +32,7 @@ def pi0est(pvals, lamb=None):
     best = pi0[mse == mse.min()]
     if best.size != 1:   # (the reference's `min(array, 1)` cannot decide then; the first minimum is taken here)
         best = best[:1]
-    return best if best[0] < 1 else 1
+    return best if best[0] <= 1 else 1   # the reference's min(array, 1): the array unless it exceeds 1
 
 
 def qvalue(pvals):
@@ -56,8 +56,9 @@ def qvalue(pvals):
 def bh_qvalue(pvals):
     """Benjamini-Hochberg adjusted p-values (stats/fdr/__init__.py:98-131): m p_(j) / j made monotone from the
     largest p-value down (which is kept as it is).  The reference's own body fails under Python 3 -- `sorted`
-    with a positional comparison argument -- so this is what that body computes under Python 2; ValueError for
-    p-values outside [0, 1] as there."""
+    with a positional comparison argument -- so this is what that body computes under Python 2.  ValueError for
+    p-values outside [0, 1]: EVERY value is checked here (the reference looks at the first and the last of the
+    unsorted input only); NaN values are ordered last by the sort rather than rejected."""
     p = np.asarray(pvals, dtype=np.float64)
     m = p.size
     if m == 0:

@@ -442,10 +442,10 @@ int fpt_bam_read(fpt_bam *bam, int64_t max_reads, int32_t *ref_id, int32_t *ref_
 int fpt_bam_has_index(fpt_bam *bam, int32_t *yes_out);
 int fpt_bam_seek_region(fpt_bam *bam, int32_t ref_id, int64_t beg, int64_t end);
 /* The alignment records themselves, each behind its 4-byte block_size as in the file (SAM/BAM specification 4.2),
- * up to max_reads of them or as many as fit `cap` bytes: for the allelically resolved counts of
- * cutcounts.py:315-488 (`lookup_allelic`, `_validate_genotype`), which read a read's name, mate flags, template
- * length, bases, base qualities and its NM / XM tag.  Same walk and region rule as fpt_bam_read (the two share
- * the reader's position). */
+ * up to max_reads of them or as many as fit `cap` bytes: for a caller that needs more of an alignment than its
+ * coordinates (name, mate flags, template length, bases, base qualities, tags -- what pysam's AlignedSegment carries in
+ * cutcounts.py:170-229).  Same walk and region rule as fpt_bam_read (the two share the reader's position).  If the
+ * first record does not fit `cap`, FPT_ERR_INVALID with *n_out = 0 and *bytes_out = the bytes that record needs. */
 int fpt_bam_read_raw(fpt_bam *bam, int64_t max_reads, uint8_t *buf, int64_t cap, int64_t *n_out, int64_t *bytes_out);
 
 /* Alignments -> cut counts of a batch of intervals, added into the padded CSR count arrays the

@@ -789,6 +789,7 @@ def test_full_size_config4_config5_properties(fpt, orc):
 
         run(0, n_iv, d_out.ptr, t8, 0)
         sums = [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(n_tr)]
+        allowance_used = {}
         # (1) sampled intervals against the oracle
         rs = np.random.RandomState(9)
         picks = {0, n_iv - 1, int(np.argmin(lens)), int(np.argmax(lens))}
@@ -807,10 +808,21 @@ def test_full_size_config4_config5_properties(fpt, orc):
             assert np.array_equal(d_out.download(np.float64, Li, t8 + o0 * 8), o), (cfg, iv)
             assert rel_err(d_out.download(np.float64, Li, 2 * t8 + o0 * 8), p) < P_TOL, (cfg, iv)
             assert rel_err(d_out.download(np.float64, Li, 3 * t8 + o0 * 8), wp[0]) < P_TOL, (cfg, iv)
-            if cfg == "5" and Li <= 600:  # (the oracle draws L x 100 values per interval on one core)
+            if cfg == "5":
+                # every sampled interval, the sliced ones (more than 256 bases: 257, 512, 513, 1,024, the longest of
+                # 2,000) included: the oracle's restatement of the sampler takes 0.07 s for 2,000 bases x 100 draws
                 want = orc.fdr_null(m.mu_params, m.r_params, e, wp[0], 3, times, seed=1, base0=o0)
                 got = d_out.download(np.float64, Li, 4 * t8 + o0 * 8)
-                assert np.max(np.abs(got - want)) <= 2.5 / (Li * times), (cfg, iv, float(np.max(np.abs(got - want))))
+                used = float(np.max(np.abs(got - want))) * Li * times   # in null windows counted differently
+                allowance_used[iv] = (Li, used)
+                assert used <= 2.5, (cfg, iv, Li, used)
+        if cfg == "5":
+            # the allowance of 2.5 counts in L x times (ties between a null window and an observed one that the device's and
+            # the oracle's normal cdf round apart) as MEASURED: printed, and at least one sliced interval is among the samples
+            assert any(Li > 600 for Li, _ in allowance_used.values()) and any(Li >= 1024 for Li, _ in allowance_used.values())
+            worst = max(u for _, u in allowance_used.values())
+            print("config 5 efdr vs the oracle's sampler: %d intervals (lengths %s), largest difference %.3g counts in L x times "
+                  "(allowed 2.5)" % (len(allowance_used), sorted(Li for Li, _ in allowance_used.values()), worst))
         # (2) idempotence
         run(0, n_iv, d_out.ptr, t8, 0)
         assert [sc.checksum_dev(d_out.ptr + k * t8, total) for k in range(n_tr)] == sums, cfg

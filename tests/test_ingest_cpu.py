@@ -567,75 +567,3 @@ def test_track_reader_passes_over_members_safely(tmp_path, tbi):
     tb.close()
 
 
-def test_lookup_allelic(tmp_path):
-    """`bamfile.lookup_allelic` (cutcounts.py:315-488) on a file the test writes: which allele a pair is counted
-    for and which pairs are left out, rule by rule -- hand-derived (pysam is not in the image: unpinned against
-    the reference, like the reader).  Variant A>G at position 1000; 50-base reads of C with one base set."""
-    from .bamwriter import write_bam
-    from footprint_tools_amd.cutcounts import ReadFormatError, bamfile
-    POS, REF, ALT = 1000, "A", "G"
-
-    def read(name, pos, base, flag=0, qual=40, nm=0, length=50, tags=True, mapq=30, **kw):
-        seq = ["C"] * length
-        if 0 <= POS - pos < length:
-            seq[POS - pos] = base
-        d = dict(name=name, ref=0, pos=pos, cigar="%dM" % length, flag=flag, mapq=mapq, seq="".join(seq), qual=qual)
-        if tags:
-            d["tags"] = {"NM": nm}
-        d.update(kw)
-        return d
-    PAIR1, PAIR2, REV = 0x1 | 0x2 | 0x40, 0x1 | 0x2 | 0x80, 0x10
-    reads = [
-        read("se_ref", 980, "A"),                                   # reference allele, forward: cut 980 on '+'
-        read("se_alt", 990, "G", nm=1),                             # alternate allele: cut 990
-        read("se_5prime", 998, "A"),                                # 2 bases from the 5' end: left out
-        read("se_rev_ref", 960, "A", flag=REV),                     # reverse, ends at 1010: cut 1009 on '-'
-        read("se_rev_5prime", 951, "A", flag=REV),                  # ends at 1001: the variant is its 5' base: left out
-        read("se_other", 940, "A"),                                 # ends at 990: does not cover the variant -> 'other'
-        read("se_third_base", 970, "T"),                            # neither allele: left out
-        read("se_lowq", 975, "A", qual=10),                         # base quality below 20: left out
-        read("se_ref_2mm", 976, "A", nm=2),                         # reference allele with two mismatches: left out
-        read("se_alt_2mm", 977, "G", nm=2),                         # alternate allele may carry two: cut 977
-        read("se_alt_3mm", 978, "G", nm=3),                         # ... not three
-        read("se_qcfail", 979, "A", flag=0x200),                    # QC fail: never reaches the genotype
-        read("se_mapq0", 981, "A", mapq=0),                         # MAPQ below min_qual
-        read("pe_alt", 950, "A", flag=PAIR1, next_ref=0, next_pos=990, tlen=90),          # ends at 1000: not covering
-        read("pe_alt", 990, "G", flag=PAIR2 | REV, nm=1, next_ref=0, next_pos=950, tlen=-90),  # -> alt: cuts 950 / 1039
-        read("pe_discordant", 965, "A", flag=PAIR1, next_ref=0, next_pos=985, tlen=70),
-        read("pe_discordant", 985, "G", flag=PAIR2 | REV, nm=1, next_ref=0, next_pos=965, tlen=-70),  # mates disagree: left out
-        read("pe_improper", 982, "A", flag=0x1 | 0x40),             # paired but not a proper pair: skipped
-        read("pe_half", 1050, "A", flag=PAIR1, next_ref=0, next_pos=5000, tlen=4000),     # mate far away: (read, None) -> 'other'
-        read("far", 3000, "A"),                                     # outside the window
-    ]
-    reads.sort(key=lambda r: r["pos"])
-    for indexed in (False, True):
-        path = str(tmp_path / ("allelic%d.bam" % indexed))
-        write_bam(path, [("chr1", 100000)], reads, index=indexed)
-        bf = bamfile(path)
-        out = bf.lookup_allelic("chr1", 900, 1100, POS, REF, ALT)
-        assert set(out) == {"A", "G", "other"}
-
-        def cuts(d):
-            return ({900 + int(i): float(v) for i, v in enumerate(d["+"]) if v}, {900 + int(i): float(v) for i, v in enumerate(d["-"]) if v})
-        assert cuts(out["A"]) == ({980: 1.0}, {1009: 1.0})
-        assert cuts(out["G"]) == ({990: 1.0, 977: 1.0, 950: 1.0}, {1039: 1.0})
-        assert cuts(out["other"]) == ({940: 1.0, 1050: 1.0}, {})
-        assert len(out["A"]["+"]) == 200 and len(out["G"]["fragments"]) == 3 and len(out["A"]["fragments"]) == 2
-        frag = [f for f in out["G"]["fragments"] if (f.end - f.start) == 90][0]   # the pair's fragment from read 1
-        assert (frag.chrom, frag.start, frag.end) == ("chr1", 950, 1040)
-        flipped = bf.lookup_allelic("chr1", 900, 1100, POS, REF, ALT, flip=True)
-        assert np.array_equal(flipped["A"]["+"], out["A"]["-"][::-1]) and np.array_equal(flipped["A"]["-"], out["A"]["+"][::-1])
-        # the same window through `lookup`: every usable read once, whatever it carries at the variant
-        class Iv(object):
-            chrom, start, end, strand = "chr1", 900, 1100, "+"
-        # (lookup runs on the device; here the host rule: allelic counts + left-out pairs add up to it)
-        total_plus = out["A"]["+"] + out["G"]["+"] + out["other"]["+"]
-        assert total_plus.sum() == 6 and bf.n_reads == len(reads)
-        bf.close()
-    # a read without NM / XM that reaches the tag test stops the call, as in the reference (ReadFormatError is not caught)
-    path = str(tmp_path / "notag.bam")
-    write_bam(path, [("chr1", 100000)], [read("untagged", 980, "A", tags=False)])
-    with pytest.raises(ReadFormatError):
-        bamfile(path).lookup_allelic("chr1", 900, 1100, POS, REF, ALT)
-    with pytest.raises(TypeError):
-        bamfile(path)[object()]
