@@ -54,6 +54,7 @@ struct lean_args {
     const int32_t *memo2_have;
     const int32_t *dm_ids;
     int32_t stop;  // timing-only diagnostics, honoured only in -DFPT_ABLATE builds (FPT_ABLATE env)
+    int32_t tab;   // phase E's g from the LDS table (FPT_LEAN_TAB=0, read once: from the Horner chain -- A/B runs)
     int32_t prio;  // raised wave priority until a tile's inputs are staged (FPT_LEAN_PRIO=0, read once, switches it off: A/B runs)
     int64_t *trace;  // -DFPT_ABLATE builds: per-workgroup timestamps (FPT_LEAN_TRACE)
     lean_coef c;
@@ -279,6 +280,10 @@ __device__ __forceinline__ bool lean_window_narrow(const Args &a, kcoef *kc, con
     return inside && !(arg > -kc->limit);
 }
 
+inline int lean_tab() {
+    static const int v = getenv("FPT_LEAN_TAB") ? atoi(getenv("FPT_LEAN_TAB")) : 1;
+    return v;
+}
 inline int lean_prio() {
     static const int v = getenv("FPT_LEAN_PRIO") ? atoi(getenv("FPT_LEAN_PRIO")) : 1;
     return v;
@@ -321,6 +326,7 @@ inline void fill_lean_args(const fptk::scan_launch &sl, lean_args &a) {
     a.dm_ids = sl.dm_ids;
     a.stop = sl.ablate;
     a.prio = lean_prio();
+    a.tab = lean_tab();
     a.trace = nullptr;
     const double g[FPT_NDTR_G_N + 1] = {FPT_NDTR_G_LIST}, e[FPT_NDTR_E_N + 1] = {FPT_NDTR_E_LIST};
     for (int i = 0; i <= FPT_NDTR_G_N; ++i) a.c.g[i] = g[i] / g[0];

@@ -64,15 +64,16 @@ struct lean_lds {
     static constexpr int oPP = 0;                  // P+[v]
     static constexpr int oPM = oPP + NPP;          // P-[v-1]
     static constexpr int oRT = oPM + NPP;          // row totals (NROW), then row carries (NROW + 4)
-    // The table form of the normal cdf's g (fptm::ndtr_fast_tab: 256 cubics staged in 8 KB of LDS, two
-    // 16-byte reads and 9 instructions in place of the 15 fp64 ones of the Horner chain) is built and
-    // OFF: config 3 23.7 / 23.7 / 24.6 ms with it against 23.6 / 23.7 without (same box, same lease) --
-    // thirty fp64 instructions fewer per base changed nothing, like ninety scalar ones in phase B: at
-    // 1 kb per tile the kernel is not waiting for instruction issue at the margin
-    static constexpr bool kTab = false;
+    // The table form of the normal cdf's g (fptm::ndtr_fast_tab: 128 cubics, 4 KB; two 16-byte LDS reads and 9
+    // instructions in place of the 15 fp64 ones of the Horner chain -- and an fp64 instruction takes two issue slots
+    // on gfx950).  Round 5 kept the table in 8 KB of its own (256 cubics), a third of the residency: no gain then.
+    // Round 6: the table lives in the scan arrays, which nobody reads after phase D (behind the z prefix sums: oGT
+    // below) -- no LDS of its own -- and with the wave priority of phase A the kernel runs at 0.89 of vector issue,
+    // where an instruction saved is time saved.
+    static constexpr bool kTab = true;
     static constexpr int oTB = oRT + 2 * NROW + 4;
-    static constexpr int nDoubles = oTB + (kTab ? 4 * FPT_NDTR_GTAB_N : 0);
-    static_assert((oTB % 2) == 0, "the table is read 16 bytes at a time");
+    static constexpr int nDoubles = oTB;
+    static_assert((oTB % 2) == 0, "the 32-bit words start on a 16-byte boundary");
     // 32-bit words, after the doubles
     static constexpr int oB0 = 0;                  // sequence bit planes
     static constexpr int oB1 = oB0 + NCR / 32 + 4;
@@ -89,6 +90,10 @@ struct lean_lds {
     // nobody reads after phase D: 6 * NCR words >= 2 * (NT + 48)
     static constexpr int oZB = oSP;                // in words; 8-byte aligned: see the static_assert
     static_assert((oSP % 2) == 0 && 6 * NCR >= 2 * (NT + 48), "z prefix must fit the scan arrays, aligned");
+    // ... and behind them the table of g (phase E, several scales): 4 doubles per interval, read 16 bytes at a time
+    static constexpr int oGT = (oZB + 2 * (NT + 48) + 3) & ~3;
+    static_assert(oGT + 8 * FPT_NDTR_GTAB_N <= oEG, "the table of g must fit the scan arrays behind the z prefix");
+    static constexpr int kGtPerLane = (4 * FPT_NDTR_GTAB_N + NT - 1) / NT;   // table doubles a lane carries to phase E
     static constexpr size_t bytes = (size_t)nDoubles * 8 + (size_t)nWords * 4;
 };
 
@@ -220,9 +225,10 @@ struct lean_mem {
     u32 *bits0, *bits1, *pk, *psP, *psM, *xP, *xPs, *xM, *xMs, *edge;
     __device__ __forceinline__ explicit lean_mem(double *smem) {
         typedef lean_lds<NT> LY;
-        PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW, gt = smem + LY::oTB;
+        PP = smem + LY::oPP, PM = smem + LY::oPM, rowtot = smem + LY::oRT, C = rowtot + LY::NROW;
         u32 *words = reinterpret_cast<u32 *>(smem + LY::nDoubles);
         Z = reinterpret_cast<double *>(words + LY::oZB);
+        gt = reinterpret_cast<double *>(words + LY::oGT);
         bits0 = words + LY::oB0, bits1 = words + LY::oB1, pk = words + LY::oPK;
         psP = words + LY::oSP, psM = words + LY::oSM;
         xP = words + LY::oXP, xPs = words + LY::oXPs, xM = words + LY::oXM, xMs = words + LY::oXMs;
@@ -471,8 +477,17 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
     // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
     lean_inputs<NI> in;
     lean_load<NT, NI>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
-    if (lean_lds<NP>::kTab && a.n_scales > 1)  // (read four barriers from here)
-        for (int i = tid; i < 4 * FPT_NDTR_GTAB_N; i += NT) m.gt[i] = g_lean_gtab[i] * kc->inv_g0;
+    // the table of g for phase E's several scales: loaded behind the inputs, carried in registers (the kernel uses
+    // 36 of the 80 its residency allows) until the scan arrays it will live in are free
+    constexpr int KG = lean_lds<NP>::kGtPerLane;
+    const bool use_tab = lean_lds<NP>::kTab && a.tab != 0;  // (FPT_LEAN_TAB=0: the Horner chain, for A/B runs)
+    const bool wide = use_tab && a.n_scales > 0 && !(a.n_scales == 1 && a.max_scale <= 8);
+    double gtr[KG];
+#pragma unroll
+    for (int i = 0; i < KG; ++i) {
+        gtr[i] = 0.0;
+        if (wide && i * NT + tid < 4 * FPT_NDTR_GTAB_N) gtr[i] = g_lean_gtab[i * NT + tid];
+    }
     bool bad = lean_stage<NT, NI>(in, g.ncs, tid, m.pk, m.bits0, m.bits1);  // outside the case this kernel handles?
     if (prio) __builtin_amdgcn_s_setprio(0);
     LEAN_TRACE(2);
@@ -516,6 +531,11 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
         for (int b = 0; b < BPL; ++b) zr[b] = lean_z_rows<NP>(z[b], b * NT + tid, m.rowtot);
         __syncthreads();
         lean_z_carries<NP>(tid, m.rowtot, m.C);
+        if (use_tab) {  // every lane is through phase C: the scan arrays are free
+#pragma unroll
+            for (int i = 0; i < KG; ++i)
+                if (i * NT + tid < 4 * FPT_NDTR_GTAB_N) m.gt[i * NT + tid] = gtr[i] * kc->inv_g0;
+        }
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < BPL; ++b) lean_z_finish<NP>(zr[b], b * NT + tid, m.C, m.Z);  // two barriers behind phase C: the scan arrays are free
@@ -524,9 +544,13 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
             m.Z[kEdge] = -1e4;
         }
         __syncthreads();
+        if (use_tab) {
 #pragma unroll
-        for (int b = 0; b < BPL; ++b)
-            bad |= lean_windows<NP, lean_args, lean_lds<NP>::kTab>(a, kc, o[b], b * NT + tid, m.Z, m.gt);
+            for (int b = 0; b < BPL; ++b) bad |= lean_windows<NP, lean_args, true>(a, kc, o[b], b * NT + tid, m.Z, m.gt);
+        } else {
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) bad |= lean_windows<NP, lean_args, false>(a, kc, o[b], b * NT + tid, m.Z, m.gt);
+        }
     }
     if (bad) a.redo[tile] = 1;
     LEAN_TRACE(6);

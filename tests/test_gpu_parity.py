@@ -93,12 +93,12 @@ def test_ndtr_window_device(fpt, ctx, orc):
     err = rel_err(got, want)
     print("ndtr_window max rel err %.2e" % err)
     assert err < 2e-11
-    # the table form of the same formula (g from 256 cubics in 1/(t + 5) instead of a degree-14 polynomial:
-    # what the wide-window phase of the large workgroups evaluates, from LDS): fit 1.2e-11
-    assert rel_err(special(fpt, ctx, "ndtr_window_tab", w["ndtr_a"]), w["ndtr_val"]) < 5e-11
+    # the table form of the same formula (g from 128 cubics in 1/(t + 5) instead of a degree-14 polynomial:
+    # what the several-scales phase of the first-pass kernel evaluates, from LDS): fit 1.9e-10, contract 1e-6
+    assert rel_err(special(fpt, ctx, "ndtr_window_tab", w["ndtr_a"]), w["ndtr_val"]) < 5e-10
     err_t = rel_err(special(fpt, ctx, "ndtr_window_tab", a), want)
     print("ndtr_window_tab max rel err %.2e" % err_t)
-    assert err_t < 5e-11
+    assert err_t < 5e-10
 
 
 # ---------------------------------------------------------------- A1: 6-mer lookup, bit-exact
@@ -621,10 +621,10 @@ def test_memo_equals_direct_bitwise(fpt, orc):
         outs.append(sc.scan(cp, cm, orc.synth_bases(1, 0, n_iv * (l + 6)), interval_len=L))
     for key in ("exp", "obs", "pval"):
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
-    # window p-values: the lean first pass evaluates the normal cdf with its polynomial in monic
-    # form (coefficients in scalar registers), the general kernel with plain Horner: same
-    # approximation, roundings differ
-    assert rel_err(outs[0]["winp"], outs[1]["winp"]) < 1e-12
+    # window p-values: the lean first pass evaluates the normal cdf's g from its table of 128 cubics (1.9e-10 of
+    # the exact value), the general kernel from the degree-14 polynomial (4.5e-12): two approximations of one
+    # function, both far inside the contract of 1e-6
+    assert rel_err(outs[0]["winp"], outs[1]["winp"]) < 5e-10
 
 
 # ---------------------------------------------------------------- size-independent properties at bench scale

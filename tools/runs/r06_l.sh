@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06_l; mkdir -p $O
+F="--no-cpu-baseline --no-traffic-probe --no-other-mode --no-heavy --no-config-legs --no-issue-probe --no-box-stream --no-posterior --no-host-arrays"
+for rep in 1 2 3; do
+for p in 0 1; do
+  FPT_LEAN_TAB=$p python3 bench.py --config 3 --steps 20 --warmup 5 $F 2>/dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tab=$p cfg=3 ms=%.4f kernel_ms=%.4f parity=%s'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['parity']))" >> $O/tab.log
+  FPT_LEAN_TAB=$p python3 bench.py --config 1 --steps 50 --warmup 50 $F 2>/dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tab=$p cfg=1 ms=%.4f kernel_ms=%.4f parity=%s'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['parity']))" >> $O/tab.log
+done
+done
+cat $O/tab.log
+python3 -m pytest tests -m gpu -x -q 2>&1 | tail -8
