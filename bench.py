@@ -712,6 +712,17 @@ def main():
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
 
     ctx = _lib.Context(0 if args.share_gpu else local_rank)
+    # ---- the per-call API a drop-in caller uses: host arrays in and out, PCIe included (never `value`).  Run FIRST,
+    #      before the resident batch's ~100 GB are allocated: the same leg behind them (allocated and freed again) moves
+    #      8.2e8 bases/s where it moves 1.4e9 in a fresh process -- the pipeline's device buffers then come out of
+    #      fragmented memory (gpurun_out/r06_n)
+    host_leg = None
+    if (world == 1 and args.config == "3" and not args.no_host_arrays and not args.hotspots and args.nb_mode == "memo"
+            and args.scales is None):
+        try:
+            host_leg = host_arrays_leg(ctx, table, DM)
+        except Exception as ex:  # (a leg beside the headline: its failure is reported, not fatal)
+            host_leg = dict(error="%s: %s" % (type(ex).__name__, ex))
     models = DM
     if n_models > 1:  # per-interval dispersion models: DM-SYNTH-A and variants with scaled 1/r
         lat = np.load(os.path.join(ROOT, "tests", "golden", "nb_lattice.npz"))
@@ -1106,18 +1117,6 @@ def main():
                                                 int(lens.max()) if ragged else L, HW + SHW, 3 + S, p_cp, p_cm, p_sq,
                                                 p_out, total, 5, ctypes.byref(ms)))
         box = float(ms.value)
-
-    # ---- the per-call API a drop-in caller uses: host arrays in and out, PCIe included (never `value`)
-    host_leg = None
-    if (world == 1 and args.config == "3" and not args.no_host_arrays and not args.hotspots and args.nb_mode == "memo"
-            and args.scales is None):
-        for buf in (d_cp, d_cm, d_sq, d_out):  # the resident batch is done with
-            buf.free()
-        ctx.trim_pool()
-        try:
-            host_leg = host_arrays_leg(ctx, table, DM)
-        except Exception as ex:  # (a leg beside the headline: its failure is reported, not fatal)
-            host_leg = dict(error="%s: %s" % (type(ex).__name__, ex))
 
     if rank == 0:
         rd, wr = algorithmic_bytes_per_base(L if not ragged else total / n_iv, S)

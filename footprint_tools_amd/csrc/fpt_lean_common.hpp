@@ -267,15 +267,16 @@ __device__ __forceinline__ bool lean_windows(const Args &a, kcoef *kc, const lea
     return low;
 }
 // one narrow scale (the reference's only one is 3): Z holds the raw z, summed left to right
-template <int NT, typename Args>
-__device__ __forceinline__ bool lean_window_narrow(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z) {
+template <int NT, typename Args, bool TAB = false>
+__device__ __forceinline__ bool lean_window_narrow(const Args &a, kcoef *kc, const lean_owner &o, int tid, const double *Z,
+                                                   const double *gt = nullptr) {
     const int hs = a.scales[0];
     const bool inside = o.mine && o.t >= hs && o.t < o.L - hs;
     double sv = 0.0;
     if (inside)
         for (int j = 16 + tid - hs; j <= 16 + tid + hs; ++j) sv += Z[j];
     const double arg = inside ? -(sv * a.scale_rsqrt[0]) : 1e3;  // edges are 1.0 (windowing.pyx:51)
-    const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s(arg, kc);
+    const double pw = LEAN_STOP(4) ? arg : ndtr_fast_s<TAB>(arg, kc, gt);
     if (o.mine) store_at(a.winp_out + o.out_off, (u32)o.t * 8u, pw);
     return inside && !(arg > -kc->limit);
 }

@@ -477,10 +477,12 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
     // ---- A: counts -> packed 16-bit integers, sequence -> two bit planes
     lean_inputs<NI> in;
     lean_load<NT, NI>(g, tid, in, LEAN_STOP(5) || LEAN_STOP(6));
-    // the table of g for phase E's several scales: loaded behind the inputs, carried in registers (the kernel uses
-    // 36 of the 80 its residency allows) until the scan arrays it will live in are free
+    // the table of g for phase E: loaded behind the inputs, carried in registers (the kernel uses 36 of the 80 its
+    // residency allows) until the scan arrays it will live in are free
     constexpr int KG = lean_lds<NP>::kGtPerLane;
     const bool use_tab = lean_lds<NP>::kTab && a.tab != 0;  // (FPT_LEAN_TAB=0: the Horner chain, for A/B runs)
+    // (several scales only: with ONE narrow scale the table's staging -- 512 doubles per tile -- costs more than nine
+    // fp64 instructions per base save: config 2 0.74 -> 0.76 ms, config 4 1.45 -> 1.55, profiles/r06_lean_table.txt)
     const bool wide = use_tab && a.n_scales > 0 && !(a.n_scales == 1 && a.max_scale <= 8);
     double gtr[KG];
 #pragma unroll
