@@ -147,8 +147,10 @@ __device__ __forceinline__ double ndtr_fast_s(double a, kcoef *c, const double *
         const double kf = fma(r, FPT_NDTR_GTAB_SCALE, -(FPT_NDTR_GTAB_XLO * FPT_NDTR_GTAB_SCALE));
         const int k = min(max((int)kf, 0), FPT_NDTR_GTAB_N - 1);
         const double w = __builtin_amdgcn_fract(kf);
-        const double2 c32 = *reinterpret_cast<const double2 *>(gt + 4 * k);
-        const double2 c10 = *reinterpret_cast<const double2 *>(gt + 4 * k + 2);
+        // (two arrays of 16-byte halves, not one of 32-byte entries: slots k and k' then share LDS banks when
+        // k = k' mod 8 instead of mod 4 -- a wavefront's lanes read a dozen different slots)
+        const double2 c32 = *reinterpret_cast<const double2 *>(gt + 2 * k);
+        const double2 c10 = *reinterpret_cast<const double2 *>(gt + 2 * FPT_NDTR_GTAB_N + 2 * k);
         g = fma(fma(fma(c32.x, w, c32.y), w, c10.x), w, c10.y);
     } else {
         g = horner_g_s(add_vs(r, c->neg_r0), c->g);  // g / its leading coefficient

@@ -535,8 +535,11 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
         lean_z_carries<NP>(tid, m.rowtot, m.C);
         if (use_tab) {  // every lane is through phase C: the scan arrays are free
 #pragma unroll
-            for (int i = 0; i < KG; ++i)
-                if (i * NT + tid < 4 * FPT_NDTR_GTAB_N) m.gt[i * NT + tid] = gtr[i] * kc->inv_g0;
+            for (int i = 0; i < KG; ++i) {
+                const int e = i * NT + tid;  // (c3, c2, c1, c0) of slot e / 4: the halves go to two arrays (lean_windows)
+                if (e < 4 * FPT_NDTR_GTAB_N)
+                    m.gt[((e & 2) ? 2 * FPT_NDTR_GTAB_N : 0) + 2 * (e >> 2) + (e & 1)] = gtr[i] * kc->inv_g0;
+            }
         }
         __syncthreads();
 #pragma unroll
