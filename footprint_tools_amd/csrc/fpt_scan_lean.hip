@@ -272,9 +272,12 @@ __device__ __forceinline__ bool lean_phase_b(const lean_mem<NP> &m, const double
         for (int j = 1; j < 2 * kHW; ++j) W += pw[j];
         const int vr = v + (kWave - 1) - 2 * lane;  // the tile mirrored: suffix scans are prefix scans of it
         const u32 Wr = (u32)__builtin_amdgcn_ds_bpermute((kWave - 1 - lane) << 2, (int)W);  // W of the mirrored lane
-        const u32 wp = W & 0xffffu, wm = W >> 16, rp = Wr & 0xffffu, rm = Wr >> 16;
+        const u32 wp = W & 0xffffu, wm = W >> 16;
         m.psP[v] = (u32)wave_scan_i32((int)wp);
         m.psM[v] = (u32)wave_scan_i32((int)wm);
+        // (both strands' extrema as packed 16-bit pairs -- a DPP move and v_pk_max_u16 per step for two scans, a byte
+        // permutation per array afterwards -- was built and measured: +1 % on configs 2, 3 and 4, profiles/r06_lean_table.txt)
+        const u32 rp = Wr & 0xffffu, rm = Wr >> 16;
         m.xP[v] = wave_scan_umax(0xffffu - wp) | (wave_scan_umax(wp) << 16);
         m.xM[v] = wave_scan_umax(0xffffu - wm) | (wave_scan_umax(wm) << 16);
         m.xPs[vr] = wave_scan_umax(0xffffu - rp) | (wave_scan_umax(rp) << 16);
