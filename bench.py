@@ -334,6 +334,8 @@ def leg_summary(d, wall_s=None):
         out["posterior"] = d["posterior"]
     if d.get("fdr"):
         out["fdr"] = d["fdr"]
+    if d.get("degraded"):
+        out["degraded"] = d["degraded"]
     if wall_s is not None:
         out["leg_wall_s"] = wall_s
     return out
@@ -707,6 +709,16 @@ def main():
         if args.leg_intervals:  # (tests: small legs, no counter passes)
             extra = ["--intervals", str(args.leg_intervals), "--no-traffic-probe", "--no-issue-probe"]
         legs = run_config_legs([("2", 100), ("4", 100), ("5", 6)], extra_args=extra)
+
+    # a child run that failed (rocprofv3 missing, a timeout) leaves its block without counters: say so in the line
+    degraded = []
+    if world == 1 and not args.no_traffic_probe and not args.hotspots and live_traffic is None:
+        degraded.append("traffic_probe: no HBM counters from this invocation (roofline.traffic from profiles/traffic.json, or null)")
+    if world == 1 and fdr_times and not args.no_issue_probe and not args.intervals and issue is None:
+        degraded.append("issue_probe: no SQ / TA counters of the FDR kernels from this invocation")
+    for cid, leg in (legs or {}).items():
+        if leg is None or "error" in leg:
+            degraded.append("config %s leg: %s" % (cid, (leg or {}).get("error", "no result")))
 
     from footprint_tools_amd import _lib
     from footprint_tools_amd.scan import DeviceArray, FootprintScanner, shard_intervals
@@ -1306,6 +1318,7 @@ def main():
             "fdr": fdr_block,
             "parity": parity,
             "host_arrays": host_leg,
+            "degraded": degraded + (["host_arrays leg: " + host_leg["error"]] if host_leg and "error" in host_leg else []),
         }
         if legs is not None:
             # every BASELINE configuration that fits one GPU, from THIS invocation: the headline (this process) and

@@ -79,3 +79,5 @@ def test_bench_default_line_carries_every_configuration():
     assert h["pinned"]["value"] > 1e8 and h["pageable"]["value"] > 1e8
     # the CPU baseline's figures as plain scalars are absent here (--no-cpu-baseline); the multi-GPU block is None at N = 1
     assert d["multi_gpu"] is None
+    # no child run of this invocation failed silently
+    assert d["degraded"] == [] and not any("degraded" in leg for leg in d["configs"].values())
