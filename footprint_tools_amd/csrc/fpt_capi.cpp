@@ -1583,6 +1583,11 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
         np_->team = new copy_team(std::min(fpt_host_cpus(), 12));
     }
     fpt_host_pipe *P = c->pipe;
+    for (auto &sl : P->slot)  // a call that failed half way left chunks in flight: let them land, owe nothing for them
+        if (sl.busy) {
+            (void)hipEventSynchronize(sl.ev_out);
+            sl.busy = false;
+        }
     // which of the caller's arrays the link can reach directly
     const bool in_pinned = is_pinned(d->counts_plus) && is_pinned(d->counts_minus) && is_pinned(d->seq);
     double *outs[3 + FPT_MAX_SCALES];
