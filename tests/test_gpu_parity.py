@@ -793,7 +793,7 @@ def test_full_size_config4_config5_properties(fpt, orc):
         # (1) sampled intervals against the oracle
         rs = np.random.RandomState(9)
         picks = {0, n_iv - 1, int(np.argmin(lens)), int(np.argmax(lens))}
-        for target in (128, 129, 192, 193, 256, 257, 512, 513, 1024):  # an interval at / just past a class limit
+        for target in (64, 65, 128, 129, 192, 193, 256, 257, 320, 321, 384, 385, 512, 513, 768, 769, 1024):  # an interval at / just past a class limit
             hit = np.where(lens == target)[0]
             if hit.size:
                 picks.add(int(hit[0]))
