@@ -1325,6 +1325,38 @@ def main():
             # configs 2, 4, 5 as child runs (config 4 / 5: one GPU's share, 437,500 ragged intervals)
             me = leg_summary(out)
             out["configs"] = {"2": legs.get("2"), "3": me, "4": legs.get("4"), "5": legs.get("5")}
+        # the figures of every block once more, compact and LAST in the line: a reader that keeps only the tail of a
+        # long line still sees every configuration, the host-arrays leg and the CPU figures
+        def brief(leg):
+            if not leg or "error" in leg:
+                return leg
+            r_ = leg.get("roofline") or {}
+            b = dict(ms_per_step=round(leg["ms_per_step"], 4), value=float("%.4g" % leg["value"]),
+                     frac=(round(r_["frac"], 4) if r_.get("frac") is not None else None), bound=r_.get("bound"),
+                     kernel_ms=(round(r_["kernel_ms"], 4) if r_.get("kernel_ms") else None),
+                     valu_busy=(round(r_["valu_busy"], 3) if r_.get("valu_busy") else None),
+                     exp_bit_exact=(leg.get("parity") or {}).get("exp_bit_exact"),
+                     p_max_rel_err=(leg.get("parity") or {}).get("p_max_rel_err"),
+                     winp_max_rel_err=(leg.get("parity") or {}).get("winp_max_rel_err"))
+            if (leg.get("parity") or {}).get("efdr_max_abs_err") is not None:
+                b["efdr_max_abs_err"] = leg["parity"]["efdr_max_abs_err"]
+            if leg.get("posterior"):
+                b["posterior_dataset_bases_per_s"] = float("%.4g" % leg["posterior"]["dataset_bases_per_s"])
+                b["posterior_parity_ok"] = leg["posterior"].get("parity_ok")
+            return b
+        summ = dict(configs=({k: brief(v) for k, v in out["configs"].items()} if "configs" in out else {args.config: brief(out)}))
+        if host_leg and "error" not in host_leg:
+            summ["host_arrays_bases_per_s"] = dict(pageable=float("%.4g" % host_leg["pageable"]["value"]),
+                                                   pinned=float("%.4g" % host_leg["pinned"]["value"]),
+                                                   parity_ok=bool(host_leg["parity"]["exp_bit_exact"]
+                                                                  and host_leg["parity"]["p_max_rel_err"] < 1e-6
+                                                                  and host_leg["parity"]["pinned_equals_pageable_bitwise"]))
+        if base:
+            summ["cpu_bases_per_s"] = dict(port_allcores=float("%.4g" % base["value"]), port_1core=float("%.4g" % base["value_1core"]),
+                                           reference_native_allcores=base.get("reference_native_allcores"),
+                                           reference_native_1core=base.get("reference_native_1core"), cores=base["cores"])
+        summ["degraded"] = len(out["degraded"])
+        out["summary"] = summ
         if args.share_gpu and world > 1:  # a smoke test of the launcher path, not a measurement
             out["invalid"] = ("--share-gpu: %d ranks on ONE GPU (%s): not a scaling measurement" % (
                 world, "collectives through the test suite's librccl stand-in" if comm is not None else

@@ -79,5 +79,10 @@ def test_bench_default_line_carries_every_configuration():
     assert h["pinned"]["value"] > 1e8 and h["pageable"]["value"] > 1e8
     # the CPU baseline's figures as plain scalars are absent here (--no-cpu-baseline); the multi-GPU block is None at N = 1
     assert d["multi_gpu"] is None
+    # the compact summary that closes the line repeats every configuration's figures
+    sm = d["summary"]
+    assert list(d)[-1] == "summary" and set(sm["configs"]) == {"2", "3", "4", "5"} and sm["degraded"] == 0
+    assert all(c["exp_bit_exact"] is True and c["ms_per_step"] > 0 for c in sm["configs"].values())
+    assert sm["host_arrays_bases_per_s"]["parity_ok"] is True
     # no child run of this invocation failed silently
     assert d["degraded"] == [] and not any("degraded" in leg for leg in d["configs"].values())
