@@ -1404,14 +1404,29 @@ public:
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
+    struct seg {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
     void copy(void *dst, const void *src, size_t bytes) {
-        if (bytes < ((size_t)1 << 20) || n_ == 1) {
-            memcpy(dst, src, bytes);
+        const seg one = {dst, src, bytes};
+        copy_many(&one, 1);
+    }
+    // several copies as ONE job of the team (a chunk's three input arrays, its 3 + S output tracks): the byte range
+    // of all of them together is cut into one share per thread -- one wake-up of the team per chunk and direction
+    // instead of one per array (a wake-up is tens of microseconds, a chunk a millisecond)
+    void copy_many(const seg *segs, int n_segs) {
+        size_t total = 0;
+        for (int i = 0; i < n_segs; ++i) total += segs[i].bytes;
+        if (total < ((size_t)1 << 20) || n_ == 1) {
+            for (int i = 0; i < n_segs; ++i)
+                if (segs[i].bytes) memcpy(segs[i].dst, segs[i].src, segs[i].bytes);
             return;
         }
         {
             std::lock_guard<std::mutex> g(m_);
-            dst_ = (char *)dst, src_ = (const char *)src, bytes_ = bytes;
+            segs_ = segs, n_segs_ = n_segs, bytes_ = total;
             left_ = n_ - 1;
             ++gen_;
         }
@@ -1422,10 +1437,20 @@ public:
     }
 
 private:
-    void part(int i) {
+    void part(int i) {  // bytes [a, b) of the segments laid end to end
         const size_t per = ((bytes_ / n_) + 4095) & ~(size_t)4095;
-        const size_t a = std::min(bytes_, per * i), b = i == n_ - 1 ? bytes_ : std::min(bytes_, per * (i + 1));
-        if (b > a) memcpy(dst_ + a, src_ + a, b - a);
+        size_t a = std::min(bytes_, per * i);
+        const size_t b = i == n_ - 1 ? bytes_ : std::min(bytes_, per * (i + 1));
+        size_t at = 0;
+        for (int k = 0; k < n_segs_ && a < b; ++k) {
+            const size_t end = at + segs_[k].bytes;
+            if (a < end) {
+                const size_t lo = a - at, hi = std::min(b, end) - at;
+                memcpy((char *)segs_[k].dst + lo, (const char *)segs_[k].src + lo, hi - lo);
+                a = at + hi;
+            }
+            at = end;
+        }
     }
     void loop(int i) {
         uint64_t seen = 0;
@@ -1450,8 +1475,8 @@ private:
     std::condition_variable cv_, done_;
     uint64_t gen_ = 0;
     bool quit_ = false;
-    char *dst_ = nullptr;
-    const char *src_ = nullptr;
+    const seg *segs_ = nullptr;
+    int n_segs_ = 0;
     size_t bytes_ = 0;
     int left_ = 0;
 };
@@ -1615,8 +1640,11 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
         const auto ts = tick();
         if (!out_pinned) {
             const size_t tb = (size_t)sl.bases * 8;
+            copy_team::seg segs[3 + FPT_MAX_SCALES];
+            int ns = 0;
             for (int k = 0; k < 3 + S; ++k)
-                if (outs[k]) P->team->copy(outs[k] + sl.base0, sl.p_out + (size_t)k * tb, tb);
+                if (outs[k]) segs[ns++] = {outs[k] + sl.base0, sl.p_out + (size_t)k * tb, tb};
+            P->team->copy_many(segs, ns);
             if (d->status_out) memcpy(d->status_out + sl.iv0, sl.p_out + (size_t)(3 + S) * tb, (size_t)sl.n_iv * 4);
         }
         st.stage_seconds += since(ts);
@@ -1666,9 +1694,10 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
                 HIP_TRY(hipMemcpyAsync(sl.d_in + o_off, small, in_bytes - o_off, hipMemcpyHostToDevice, P->s_in));
         } else {
             const auto ts = tick();
-            P->team->copy(sl.p_in, d->counts_plus + c0, o_cm);
-            P->team->copy(sl.p_in + o_cm, d->counts_minus + c0, o_cm);
-            P->team->copy(sl.p_in + o_sq, d->seq + q0, (size_t)nq);
+            const copy_team::seg segs[3] = {{sl.p_in, d->counts_plus + c0, o_cm},
+                                            {sl.p_in + o_cm, d->counts_minus + c0, o_cm},
+                                            {sl.p_in + o_sq, d->seq + q0, (size_t)nq}};
+            P->team->copy_many(segs, 3);
             staged_here = since(ts);
             st.stage_seconds += staged_here;
             HIP_TRY(hipMemcpyAsync(sl.d_in, sl.p_in, in_bytes, hipMemcpyHostToDevice, P->s_in));
