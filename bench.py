@@ -474,8 +474,8 @@ def reference_native(cfg, table, DM, cores, budget_s=3.0):
 def host_arrays_leg(ctx, table, DM):
     """The rate a drop-in Python caller sees: numpy arrays in, numpy arrays out through FootprintScanner.scan
     (fpt_scan_host: chunks through a copy-in / scan / copy-out pipeline), BASELINE config 2's size, PCIe included --
-    with pageable arrays (np.empty: staged through pinned buffers by host threads) and with page-locked ones
-    (ctx.pinned_empty: the copy engines read and write them directly).  Reference counterpart: the per-call API
+    with pageable arrays (np.empty: pinned by the runtime on the way, every copy blocking the thread that issued it --
+    hence the call's two threads) and with page-locked ones (ctx.pinned_empty).  Reference counterpart: the per-call API
     modeling/predict.pyx:116-163 + dispersion.pyx:291-316 + windowing.pyx:114-130 (arrays in, arrays out).
     Never `value`: the headline has its inputs resident in HBM."""
     from oracle import oracle  # inputs (the synthetic generator) and the spot check only
@@ -518,9 +518,8 @@ def host_arrays_leg(ctx, table, DM):
                          link_GBps_h2d=st["bytes_h2d"] / st["seconds"] / 1e9,
                          link_GBps_d2h=st["bytes_d2h"] / st["seconds"] / 1e9,
                          link_GBps_both=(st["bytes_h2d"] + st["bytes_d2h"]) / st["seconds"] / 1e9,
-                         arrays_used_directly=bool(st["inputs_pinned"] and st["outputs_pinned"]),
-                         calling_thread_ms=dict(waiting=st["wait_seconds"] * 1e3, staging_copies=st["stage_seconds"] * 1e3,
-                                                issuing=st["issue_seconds"] * 1e3))
+                         arrays_page_locked=bool(st["inputs_pinned"] and st["outputs_pinned"]),
+                         calling_thread_ms=dict(waiting=st["wait_seconds"] * 1e3, issuing=st["issue_seconds"] * 1e3))
         if kind == "pinned":
             out[kind]["input_alloc_and_fill_s"] = alloc_s
     iv = n_iv - 1

@@ -1387,101 +1387,8 @@ int fpt_memcpy_d2h(fpt_ctx *c, void *host, const void *dev, int64_t bytes) {
 #pragma GCC visibility pop
 }  // extern "C"
 
-// A small team for host-to-host copies (pageable user arrays <-> pinned staging): one core moves ~10 GB/s, the
-// link wants 50 in each direction.
 namespace {
-class copy_team {
-public:
-    explicit copy_team(int n) : n_(std::max(1, n)) {
-        for (int i = 1; i < n_; ++i) workers_.emplace_back([this, i] { loop(i); });
-    }
-    ~copy_team() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            quit_ = true;
-            ++gen_;
-        }
-        cv_.notify_all();
-        for (auto &t : workers_) t.join();
-    }
-    struct seg {
-        void *dst;
-        const void *src;
-        size_t bytes;
-    };
-    void copy(void *dst, const void *src, size_t bytes) {
-        const seg one = {dst, src, bytes};
-        copy_many(&one, 1);
-    }
-    // several copies as ONE job of the team (a chunk's three input arrays, its 3 + S output tracks): the byte range
-    // of all of them together is cut into one share per thread -- one wake-up of the team per chunk and direction
-    // instead of one per array (a wake-up is tens of microseconds, a chunk a millisecond)
-    void copy_many(const seg *segs, int n_segs) {
-        size_t total = 0;
-        for (int i = 0; i < n_segs; ++i) total += segs[i].bytes;
-        if (total < ((size_t)1 << 20) || n_ == 1) {
-            for (int i = 0; i < n_segs; ++i)
-                if (segs[i].bytes) memcpy(segs[i].dst, segs[i].src, segs[i].bytes);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> g(m_);
-            segs_ = segs, n_segs_ = n_segs, bytes_ = total;
-            left_ = n_ - 1;
-            ++gen_;
-        }
-        cv_.notify_all();
-        part(0);
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return left_ == 0; });
-    }
-
-private:
-    void part(int i) {  // bytes [a, b) of the segments laid end to end
-        const size_t per = ((bytes_ / n_) + 4095) & ~(size_t)4095;
-        size_t a = std::min(bytes_, per * i);
-        const size_t b = i == n_ - 1 ? bytes_ : std::min(bytes_, per * (i + 1));
-        size_t at = 0;
-        for (int k = 0; k < n_segs_ && a < b; ++k) {
-            const size_t end = at + segs_[k].bytes;
-            if (a < end) {
-                const size_t lo = a - at, hi = std::min(b, end) - at;
-                memcpy((char *)segs_[k].dst + lo, (const char *)segs_[k].src + lo, hi - lo);
-                a = at + hi;
-            }
-            at = end;
-        }
-    }
-    void loop(int i) {
-        uint64_t seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (quit_) return;
-            }
-            part(i);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                --left_;
-            }
-            done_.notify_one();
-        }
-    }
-    int n_;
-    std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    uint64_t gen_ = 0;
-    bool quit_ = false;
-    const seg *segs_ = nullptr;
-    int n_segs_ = 0;
-    size_t bytes_ = 0;
-    int left_ = 0;
-};
-
-bool is_pinned(const void *p) {  // memory the runtime can DMA from / to directly (hipHostMalloc, hipHostRegister)
+bool is_pinned(const void *p) {  // memory the copy engines reach without the runtime's help (hipHostMalloc, hipHostRegister)
     if (!p) return false;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -1496,14 +1403,11 @@ constexpr int kPipeSlots = 3;
 struct fpt_host_pipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
     struct slot_t {
-        char *d_in = nullptr, *d_out = nullptr, *p_in = nullptr, *p_out = nullptr;
-        size_t d_in_bytes = 0, d_out_bytes = 0, p_in_bytes = 0, p_out_bytes = 0;
-        hipEvent_t ev_in = nullptr, ev_scan = nullptr, ev_out = nullptr;
-        bool busy = false;
-        // what the chunk in flight still owes the caller once ev_out has passed
-        int64_t base0 = 0, bases = 0, iv0 = 0, n_iv = 0;
+        char *d_in = nullptr, *d_out = nullptr, *p_small = nullptr;   // device buffers; pinned staging of the offsets / model ids
+        size_t d_in_bytes = 0, d_out_bytes = 0, p_small_bytes = 0;
+        hipEvent_t ev_in = nullptr, ev_scan = nullptr;
+        int64_t base0 = 0, bases = 0, iv0 = 0, n_iv = 0;             // the chunk the slot holds
     } slot[kPipeSlots];
-    copy_team *team = nullptr;
     fpt_scan_host_stats last = {};
 };
 
@@ -1512,15 +1416,12 @@ static void host_pipe_free(fpt_host_pipe *p) {
     for (auto &s : p->slot) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
-        if (s.p_in) (void)hipHostFree(s.p_in);
-        if (s.p_out) (void)hipHostFree(s.p_out);
+        if (s.p_small) (void)hipHostFree(s.p_small);
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
         if (s.ev_scan) (void)hipEventDestroy(s.ev_scan);
-        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     }
     if (p->s_in) (void)hipStreamDestroy(p->s_in);
     if (p->s_out) (void)hipStreamDestroy(p->s_out);
-    delete p->team;
     delete p;
 }
 
@@ -1574,6 +1475,15 @@ int fpt_scan_host_last(fpt_ctx *c, fpt_scan_host_stats *out) {
     return FPT_OK;
 }
 
+// Three stages, three chunks in flight: the calling thread copies a chunk's inputs to the device (stream s_in) and
+// launches its scan (the context's stream, behind an event); a second thread, started per call, copies every chunk's
+// results back in order (stream s_out, behind the scan's event) and frees its slot.  The caller's arrays are handed to
+// hipMemcpyAsync as they are: page-locked ones are read and written by the copy engines while the call returns at once;
+// pageable ones are pinned by the runtime on the way and the call BLOCKS its thread until the copy is done -- at the
+// link's rate all the same (56 GB/s one way, profiles/r06_pcie_micro.txt).  Two threads therefore keep both directions of
+// the link busy whatever the arrays are; one thread with pageable arrays moved 9.6e8 bases/s on config 2's shape, staging
+// through pinned buffers of the library's own by a team of host threads (the first form of this call) 1.15-1.45e9 by
+// what else the host's memory system was doing, this form 1.49e9 with no host copy at all (gpurun_out/r06 host-array runs).
 int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
     if (int rc = check_ctx(c)) return rc;
     if (!d) return fail(FPT_ERR_INVALID, "null descriptor");
@@ -1603,54 +1513,71 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
         for (auto &s : np_->slot) {
             HIP_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
         }
-        np_->team = new copy_team(std::min(fpt_host_cpus(), 12));
     }
     fpt_host_pipe *P = c->pipe;
-    for (auto &sl : P->slot)  // a call that failed half way left chunks in flight: let them land, owe nothing for them
-        if (sl.busy) {
-            (void)hipEventSynchronize(sl.ev_out);
-            sl.busy = false;
-        }
-    // which of the caller's arrays the link can reach directly
-    const bool in_pinned = is_pinned(d->counts_plus) && is_pinned(d->counts_minus) && is_pinned(d->seq);
     double *outs[3 + FPT_MAX_SCALES];
     outs[0] = d->exp_out, outs[1] = d->obs_out, outs[2] = d->pval_out;
     for (int s = 0; s < S; ++s) outs[3 + s] = d->winp_out ? d->winp_out + (size_t)s * total : nullptr;
-    bool out_pinned = true, any_out = false;
-    for (int k = 0; k < 3 + S; ++k)
-        if (outs[k]) any_out = true, out_pinned = out_pinned && is_pinned(outs[k]);
-    if (d->status_out) out_pinned = out_pinned && is_pinned(d->status_out);
-    (void)any_out;
 
     fpt_scan_host_stats st = {};
-    st.inputs_pinned = in_pinned, st.outputs_pinned = out_pinned;
+    st.inputs_pinned = is_pinned(d->counts_plus) && is_pinned(d->counts_minus) && is_pinned(d->seq);
+    st.outputs_pinned = 1;
+    for (int k = 0; k < 3 + S; ++k)
+        if (outs[k] && !is_pinned(outs[k])) st.outputs_pinned = 0;
+    if (d->status_out && !is_pinned(d->status_out)) st.outputs_pinned = 0;
     const auto t_start = std::chrono::steady_clock::now();
-
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
     };
-    auto finish = [&](fpt_host_pipe::slot_t &sl) -> int {  // the chunk's results are on the host: hand them over
-        if (!sl.busy) return FPT_OK;
-        const auto tw = tick();
-        HIP_TRY(hipEventSynchronize(sl.ev_out));
-        st.wait_seconds += since(tw);
-        const auto ts = tick();
-        if (!out_pinned) {
+
+    // the second thread: every chunk's results to the caller's arrays, in the order the chunks were issued
+    struct drain_t {
+        std::mutex m;
+        std::condition_variable cv;
+        int64_t issued = 0, drained = 0;
+        bool stop = false;
+        hipError_t err = hipSuccess;
+    } dr;
+    std::thread drain([&] {
+        (void)hipSetDevice(c->device);
+        for (int64_t j = 0;; ++j) {
+            {
+                std::unique_lock<std::mutex> g(dr.m);
+                dr.cv.wait(g, [&] { return dr.issued > j || dr.stop; });
+                if (dr.issued <= j) return;
+            }
+            fpt_host_pipe::slot_t &sl = P->slot[j % kPipeSlots];
             const size_t tb = (size_t)sl.bases * 8;
-            copy_team::seg segs[3 + FPT_MAX_SCALES];
-            int ns = 0;
-            for (int k = 0; k < 3 + S; ++k)
-                if (outs[k]) segs[ns++] = {outs[k] + sl.base0, sl.p_out + (size_t)k * tb, tb};
-            P->team->copy_many(segs, ns);
-            if (d->status_out) memcpy(d->status_out + sl.iv0, sl.p_out + (size_t)(3 + S) * tb, (size_t)sl.n_iv * 4);
+            hipError_t e = hipStreamWaitEvent(P->s_out, sl.ev_scan, 0);
+            for (int t = 0; t < 3 + S && e == hipSuccess; ++t)
+                if (outs[t]) e = hipMemcpyAsync(outs[t] + sl.base0, sl.d_out + (size_t)t * tb, tb, hipMemcpyDeviceToHost, P->s_out);
+            if (e == hipSuccess && d->status_out)
+                e = hipMemcpyAsync(d->status_out + sl.iv0, sl.d_out + (size_t)(3 + S) * tb, (size_t)sl.n_iv * 4,
+                                   hipMemcpyDeviceToHost, P->s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(P->s_out);
+            {
+                std::lock_guard<std::mutex> g(dr.m);
+                if (e != hipSuccess && dr.err == hipSuccess) dr.err = e;
+                dr.drained = j + 1;
+            }
+            dr.cv.notify_all();
         }
-        st.stage_seconds += since(ts);
-        sl.busy = false;
-        return FPT_OK;
-    };
+    });
+    struct drain_guard {  // every way out of this function stops and joins the thread
+        drain_t &dr;
+        std::thread &th;
+        ~drain_guard() {
+            if (!th.joinable()) return;
+            {
+                std::lock_guard<std::mutex> g(dr.m);
+                dr.stop = true;
+            }
+            dr.cv.notify_all();
+            th.join();
+        }
+    } guard{dr, drain};
 
     int64_t i0 = 0;
     for (int64_t k = 0; i0 < n; ++k) {
@@ -1667,41 +1594,31 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
         const int64_t c0 = b0 + i0 * (2 * pad + 1), nc = cb + ni * (2 * pad + 1);   // counts: first element, elements
         const int64_t q0 = b0 + i0 * (2 * pad + 7), nq = cb + ni * (2 * pad + 7);   // sequence bytes
         fpt_host_pipe::slot_t &sl = P->slot[k % kPipeSlots];
-        if (int rc = finish(sl)) return rc;
-        // layout of the chunk's input block: counts+, counts-, sequence, rebased offsets, model ids
+        {  // the slot's previous chunk (k - kPipeSlots) must have been handed over
+            const auto tw = tick();
+            std::unique_lock<std::mutex> g(dr.m);
+            dr.cv.wait(g, [&] { return dr.drained > k - kPipeSlots; });
+            st.wait_seconds += since(tw);
+            if (dr.err != hipSuccess) return fail(FPT_ERR_HIP, "device-to-host copy failed: %s", hipGetErrorString(dr.err));
+        }
+        // layout of the chunk's input block on the device: counts+, counts-, sequence, rebased offsets, model ids
         const size_t o_cm = (size_t)nc * 8, o_sq = 2 * o_cm, o_off = o_sq + up16((size_t)nq),
                      o_dm = o_off + up16(ragged ? (size_t)(ni + 1) * 8 : 0), in_bytes = o_dm + up16(d->dm_ids ? (size_t)ni * 4 : 0);
         const size_t tb = (size_t)cb * 8, out_bytes = (size_t)(3 + S) * tb + up16((size_t)ni * 4);
         if (int rc = pipe_grow(&sl.d_in, &sl.d_in_bytes, in_bytes, false)) return rc;
         if (int rc = pipe_grow(&sl.d_out, &sl.d_out_bytes, out_bytes, false)) return rc;
-        if (int rc = pipe_grow(&sl.p_in, &sl.p_in_bytes, in_pinned ? in_bytes - o_off + 16 : in_bytes, true)) return rc;
-        if (!out_pinned)
-            if (int rc = pipe_grow(&sl.p_out, &sl.p_out_bytes, out_bytes, true)) return rc;
-        // (the slot's previous chunk has been handed over: its device and staging buffers are free)
+        if (int rc = pipe_grow(&sl.p_small, &sl.p_small_bytes, in_bytes - o_off + 16, true)) return rc;
         const auto ti = tick();
-        double staged_here = 0.0;
-        char *small = in_pinned ? sl.p_in : sl.p_in + o_off;   // rebased offsets + model ids always go through staging
+        char *small = sl.p_small;   // the chunk's offsets, rebased to its first interval, and its model ids: made here
         if (ragged) {
             int64_t *ro = (int64_t *)small;
             for (int64_t i = 0; i <= ni; ++i) ro[i] = off[i0 + i] - off[i0];
         }
         if (d->dm_ids) memcpy(small + (o_dm - o_off), d->dm_ids + i0, (size_t)ni * 4);
-        if (in_pinned) {
-            HIP_TRY(hipMemcpyAsync(sl.d_in, d->counts_plus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
-            HIP_TRY(hipMemcpyAsync(sl.d_in + o_cm, d->counts_minus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
-            HIP_TRY(hipMemcpyAsync(sl.d_in + o_sq, d->seq + q0, (size_t)nq, hipMemcpyHostToDevice, P->s_in));
-            if (in_bytes > o_off)
-                HIP_TRY(hipMemcpyAsync(sl.d_in + o_off, small, in_bytes - o_off, hipMemcpyHostToDevice, P->s_in));
-        } else {
-            const auto ts = tick();
-            const copy_team::seg segs[3] = {{sl.p_in, d->counts_plus + c0, o_cm},
-                                            {sl.p_in + o_cm, d->counts_minus + c0, o_cm},
-                                            {sl.p_in + o_sq, d->seq + q0, (size_t)nq}};
-            P->team->copy_many(segs, 3);
-            staged_here = since(ts);
-            st.stage_seconds += staged_here;
-            HIP_TRY(hipMemcpyAsync(sl.d_in, sl.p_in, in_bytes, hipMemcpyHostToDevice, P->s_in));
-        }
+        HIP_TRY(hipMemcpyAsync(sl.d_in, d->counts_plus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
+        HIP_TRY(hipMemcpyAsync(sl.d_in + o_cm, d->counts_minus + c0, o_cm, hipMemcpyHostToDevice, P->s_in));
+        HIP_TRY(hipMemcpyAsync(sl.d_in + o_sq, d->seq + q0, (size_t)nq, hipMemcpyHostToDevice, P->s_in));
+        if (in_bytes > o_off) HIP_TRY(hipMemcpyAsync(sl.d_in + o_off, small, in_bytes - o_off, hipMemcpyHostToDevice, P->s_in));
         HIP_TRY(hipEventRecord(sl.ev_in, P->s_in));
         HIP_TRY(hipStreamWaitEvent(c->stream, sl.ev_in, 0));
         fpt_scan_desc cd = *d;
@@ -1719,27 +1636,25 @@ int fpt_scan_host(fpt_ctx *c, const fpt_scan_desc *d, int64_t chunk_bases) {
         HIP_TRY(hipMemsetAsync(cd.status_out, 0, (size_t)ni * 4, c->stream));
         if (int rc = fpt_scan_dev(c, &cd)) return rc;
         HIP_TRY(hipEventRecord(sl.ev_scan, c->stream));
-        HIP_TRY(hipStreamWaitEvent(P->s_out, sl.ev_scan, 0));
-        if (out_pinned) {
-            for (int t = 0; t < 3 + S; ++t)
-                if (outs[t]) HIP_TRY(hipMemcpyAsync(outs[t] + b0, sl.d_out + (size_t)t * tb, tb, hipMemcpyDeviceToHost, P->s_out));
-            if (d->status_out)
-                HIP_TRY(hipMemcpyAsync(d->status_out + i0, cd.status_out, (size_t)ni * 4, hipMemcpyDeviceToHost, P->s_out));
-        } else {
-            HIP_TRY(hipMemcpyAsync(sl.p_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, P->s_out));
-        }
-        HIP_TRY(hipEventRecord(sl.ev_out, P->s_out));
-        sl.busy = true;
         sl.base0 = b0, sl.bases = cb, sl.iv0 = i0, sl.n_iv = ni;
-        st.issue_seconds += since(ti) - staged_here;
+        {
+            std::lock_guard<std::mutex> g(dr.m);
+            dr.issued = k + 1;
+        }
+        dr.cv.notify_all();
+        st.issue_seconds += since(ti);
         st.chunks += 1;
         st.bytes_h2d += (int64_t)in_bytes;
         st.bytes_d2h += (int64_t)out_bytes;
         i0 = i1;
     }
-    // (in the order the chunks were issued: the slot after the last one used holds the oldest)
-    for (int j = 0; j < kPipeSlots; ++j)
-        if (int rc = finish(P->slot[(st.chunks + j) % kPipeSlots])) return rc;
+    {
+        const auto tw = tick();
+        std::unique_lock<std::mutex> g(dr.m);
+        dr.cv.wait(g, [&] { return dr.drained >= st.chunks; });
+        st.wait_seconds += since(tw);
+    }
+    if (dr.err != hipSuccess) return fail(FPT_ERR_HIP, "device-to-host copy failed: %s", hipGetErrorString(dr.err));
     HIP_TRY(hipStreamSynchronize(c->stream));
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     st.bases = total;

@@ -204,9 +204,9 @@ class FootprintScanner(object):
         """Host arrays in, dict of host arrays out (exp, obs, pval, winp[S], status): the per-call form a drop-in
         caller uses (the reference's prediction.compute / dm.p_values / windowing.stouffers_z take and return numpy
         arrays).  One fpt_scan_host call: the batch travels in chunks through a three-stage pipeline (host-to-device
-        copy, scan, device-to-host copy), the two directions of the link and the kernel overlapping.  Arrays made
-        by `ctx.pinned_empty` (inputs; outputs with pinned_out=True) are used by the copy engines directly, other
-        arrays go through pinned staging buffers the context keeps.
+        copy, scan, device-to-host copy; two threads), the two directions of the link and the kernel overlapping.
+        The arrays are used where they lie, pageable or page-locked (`ctx.pinned_empty`; outputs with
+        pinned_out=True): both move at the link's rate.
         dm_ids: optional per-interval index into the scanner's list of dispersion models.
         out: the dict an earlier call of the same shape returned -- its arrays are written again instead of new ones
         being made (a fresh numpy array costs a page fault per 4 KiB when first written, a fresh page-locked one

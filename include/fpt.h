@@ -214,12 +214,12 @@ int fpt_scan_dev(fpt_ctx *ctx, const fpt_scan_desc *desc);
  * modeling/predict.pyx:116-163, modeling/dispersion.pyx:291-316, stats/windowing.pyx:114-130).  EVERY
  * pointer of `desc` is a host pointer here (interval_off or interval_off_host: the host offsets of a ragged
  * batch, either field; status_out optional).  The batch is cut into chunks of about `chunk_bases` output bases
- * (0: 2^21) that travel through a three-stage pipeline -- host-to-device copy, fpt_scan_dev, device-to-host copy,
- * each on its own stream, three chunks in flight -- so that the two directions of the PCIe link and the kernel
- * overlap.  Arrays from fpt_host_alloc (or registered with hipHostRegister) are read and written by the copy
- * engines directly; any other (pageable) array goes through pinned staging buffers the context keeps, moved by
- * a small team of host threads.  Returns when every output is in place.  Results are those of fpt_scan_dev on
- * the whole batch, bit for bit (intervals are independent). */
+ * (0: 2^21) that travel through a three-stage pipeline, three chunks in flight: the calling thread copies a
+ * chunk's inputs to the device and launches fpt_scan_dev on it, a second thread (started per call) copies every
+ * chunk's results back in order -- each stage on its own stream, so that both directions of the PCIe link and the
+ * kernel overlap.  The caller's arrays are used where they lie, page-locked (fpt_host_alloc, hipHostRegister) or
+ * pageable: nothing is staged by the library.  Returns when every output is in place.  Results are those of
+ * fpt_scan_dev on the whole batch, bit for bit (intervals are independent). */
 int fpt_scan_host(fpt_ctx *ctx, const fpt_scan_desc *desc, int64_t chunk_bases);
 
 /* what the last fpt_scan_host of the context did */
@@ -228,9 +228,10 @@ typedef struct fpt_scan_host_stats {
     int64_t bases;            /* output bases */
     int64_t chunks;
     int64_t bytes_h2d, bytes_d2h;
-    int32_t inputs_pinned, outputs_pinned; /* 1: the caller's arrays were used by the copy engines directly */
-    /* where the calling thread spent the call: waiting for a chunk's results, moving bytes between the caller's
-     * pageable arrays and the staging buffers, and issuing copies and launches */
+    int32_t inputs_pinned, outputs_pinned; /* 1: the caller's arrays are page-locked (copies return at once; with
+                                            * pageable arrays a copy blocks the thread that issued it) */
+    /* where the calling thread spent the call: waiting for a slot or for the last results, (unused since the
+     * library stages nothing: 0), and issuing copies and launches -- with pageable inputs the copies themselves */
     double wait_seconds, stage_seconds, issue_seconds;
 } fpt_scan_host_stats;
 int fpt_scan_host_last(fpt_ctx *ctx, fpt_scan_host_stats *out);

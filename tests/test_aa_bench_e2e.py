@@ -75,7 +75,7 @@ def test_bench_default_line_carries_every_configuration():
     h = d["host_arrays"]
     assert "error" not in h, h
     assert h["parity"]["exp_bit_exact"] is True and h["parity"]["p_max_rel_err"] < 1e-6 and h["parity"]["pinned_equals_pageable_bitwise"] is True
-    assert h["pinned"]["arrays_used_directly"] is True and h["pageable"]["arrays_used_directly"] is False
+    assert h["pinned"]["arrays_page_locked"] is True and h["pageable"]["arrays_page_locked"] is False
     assert h["pinned"]["value"] > 1e8 and h["pageable"]["value"] > 1e8
     # the CPU baseline's figures as plain scalars are absent here (--no-cpu-baseline); the multi-GPU block is None at N = 1
     assert d["multi_gpu"] is None
