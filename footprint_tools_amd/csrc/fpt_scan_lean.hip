@@ -462,9 +462,15 @@ __global__ void __launch_bounds__(NT, BPL == 1 ? 8 : 6) k_scan_lean(const lean_a
     typedef const __attribute__((address_space(4))) lean_args kargs;
     kcoef *kc = &((kargs *)__builtin_amdgcn_kernarg_segment_ptr())->c;
     const int tid = threadIdx.x;
-    // (An XCD-contiguous order of the tiles -- workgroup b takes slot (b mod 8) n/8 + b/8, so that intervals that
-    // are neighbours in memory meet in one L2 -- was measured on the ragged shape: +1-2 %, dropped.)
-    const int64_t tile = a.tile_first + blockIdx.x;
+    // The 1,024-base tiles in an XCD-contiguous order (round 6): workgroups b, b + 8, b + 16, ... -- one XCD, one L2 --
+    // take NEIGHBOURING tiles, so the 128-byte line two neighbours' padded rows share (1 of the 70 a row spans) is
+    // fetched once: config 3 20.79 -> 20.54 ms (three alternating pairs, profiles/r06_lean_prio.txt).  Not for the
+    // smaller classes: config 2's 500-base tiles lose 7 % with it, the ragged shape 1-2 % (round 5).
+    int64_t tile = a.tile_first + blockIdx.x;
+    if (NP == 1024) {
+        const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+        tile = a.tile_first + (int64_t)(x * q + min(x, r) + idx);  // XCD x owns q (+ 1 for the first r) consecutive tiles
+    }
     // Wave priority (round 6): the SIMD's arbiter issues from its OLDEST wavefront first, and the oldest are deep in
     // the arithmetic of phases B - E -- a workgroup that has just arrived waits behind them for the few instructions
     // that send its loads off, and the 2.6 us of their latency start late.  Raised until the inputs are staged
