@@ -1017,7 +1017,9 @@ int fpt_fdr_dev(fpt_ctx *c, const fpt_fdr_desc *d) {
     fl.memo = d_memo;
     fl.alias = d_alias;
     fl.n_models = n_dm;
-    fl.light = c->fdr_light;
+    // (the light draw instances carry no test hooks -- caller's uniforms, null p-values out: a call with either takes
+    // the full instance, one workgroup per interval)
+    fl.light = c->fdr_light && !d->null_uniform && !d->null_winp_out;
     fl.light_dbuf = c->fdr_light_dbuf;
     fl.memo_exp = c->memo_exp;
     fl.memo_obs = c->fdr_memo_obs;

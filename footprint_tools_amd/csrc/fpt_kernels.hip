@@ -2089,8 +2089,10 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 
             uint32_t o[4] = {0u, 0u, 0u, 0u};  // the Philox block of this base and pass (words = samples)
             int ei = -1;
             // (the caller's uniforms are a test hook: whether there are any is a scalar condition, not a lane's pointer)
-            const bool has_up = a.null_uniform != nullptr;
-            const double *up = a.null_uniform + (size_t)(off + (t < L ? t : 0)) * a.times + s;
+            // (... and the light instance carries neither hook: fewer scalar registers live across the loop, where the
+            // compiler was spilling them into a vector register's lanes -- v_readlane_b32 in every pass)
+            const bool has_up = !LIGHT && a.null_uniform != nullptr;
+            const double *up = LIGHT ? nullptr : a.null_uniform + (size_t)(off + (t < L ? t : 0)) * a.times + s;
             if (t < L) {
                 if (ABL(32768)) {  // timing only: four well-mixed words for five multiplications instead of Philox's sixty instructions
                     uint32_t h = ((uint32_t)(a.base_index0 + off + t) * 2654435761u) ^ ((uint32_t)s * 0x9e3779b9u);
@@ -2214,7 +2216,7 @@ __global__ void __launch_bounds__(NT, MODE == 3 ? (NT > 256 ? 4 : 8) : (MODE == 
                 x0 = (sc & 0xffff) ? NAN : -s0;
                 x1 = (sc >> 16) ? NAN : -s1;
             }
-            if (a.null_out) {  // the p-values themselves only when somebody wants them
+            if (!LIGHT && a.null_out) {  // the p-values themselves only when somebody wants them
                 double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
 #pragma clang loop unroll(disable)
                 for (int w = 0; w < ns; ++w) {
@@ -2387,7 +2389,7 @@ __global__ void __launch_bounds__(NT, 8) k_fdr_slice(const fdr_slice_args sa) {
     const bool out = tid >= HS && tid < NT - HS && t < L;
     const bool inside = out && t >= HS && t < L - HS;  // its window fits the interval
     const int rl = valid ? alias_row_of(a.exp[off + t], a.memo_exp, row_lg) : -1;
-    const bool has_up = a.null_uniform != nullptr;
+    constexpr bool has_up = false;  // (no test hooks in the light instances: fpt_fdr_dev sends such calls to the full one)
     bool left_out = false;
     double2 *z01 = reinterpret_cast<double2 *>(zq), *z23 = z01 + NTMAX;
     for (int s = 0; s < a.times; s += 4) {
@@ -2430,14 +2432,6 @@ __global__ void __launch_bounds__(NT, 8) k_fdr_slice(const fdr_slice_args sa) {
                 x1 = (sm[1] - sm[1]) - sm[1];
                 x2 = (sm[2] - sm[2]) - sm[2];
                 x3 = (sm[3] - sm[3]) - sm[3];
-            }
-            if (a.null_out) {
-                double *np_ = a.null_out + (size_t)(off + t) * a.times + s;
-#pragma clang loop unroll(disable)
-                for (int w = 0; w < ns; ++w) {
-                    const double xw = w == 0 ? x0 : (w == 1 ? x1 : (w == 2 ? x2 : x3));
-                    np_[w] = xw == fptm::kInf ? 1.0 : fptm::ndtr(div_invariant(xw, a.sqrt_k, a.inv_sqrt_k));
-                }
             }
             auto rank_pair = [&](const double y0, const double y1, const bool second) {
                 const int b0 = slice_of(y0), b1 = slice_of(y1);
