@@ -27,7 +27,7 @@ EXPORTS = [
     "fpt_track_open", "fpt_track_close", "fpt_track_n_refs", "fpt_track_ref", "fpt_track_fetch", "fpt_track_fetch_rows", "fpt_track_writer_open", "fpt_track_writer_set_level", "fpt_track_writer_write", "fpt_track_writer_write_stats", "fpt_track_writer_close",
     "fpt_comm_unique_id", "fpt_comm_init", "fpt_comm_destroy", "fpt_allgather_track", "fpt_gather_track",
     "fpt_allgather_track_async", "fpt_gather_track_async", "fpt_comm_wait", "fpt_comm_synchronize", "fpt_comm_info",
-    "fpt_scan_host", "fpt_scan_host_last", "fpt_host_alloc", "fpt_host_free",
+    "fpt_scan_host", "fpt_scan_host_last", "fpt_host_alloc", "fpt_host_free", "fpt_host_prefault",
     "fpt_stream_pattern_dev", "fpt_set_memo_dims", "fpt_drop_kept_tables", "fpt_fdr_dev", "fpt_posterior_dev", "fpt_detect_columns_dev", "fpt_hist2d_dev", "fpt_segment_count_dev", "fpt_segment_fill_dev",
 ]
 
@@ -212,6 +212,7 @@ def load():
         L.fpt_scan_host_last.argtypes = [vp, vp]
         L.fpt_host_alloc.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
         L.fpt_host_free.argtypes = [vp, vp]
+        L.fpt_host_prefault.argtypes = [vp, i64]
         if hasattr(L, "fpt_stream_pattern_dev"):  # (absent from older builds loaded through FPT_LIB_PATH for A/B runs)
             L.fpt_stream_pattern_dev.argtypes = [vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, C.POINTER(C.c_float)]
         L.fpt_timing_read.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]

@@ -245,6 +245,8 @@ class FootprintScanner(object):
         else:
             flat = empty((3 + S) * total)
             status = empty(max(n_iv, 1), np.int32)[:n_iv]
+            if not pinned_out:  # a new numpy array: its pages touched by a team of threads before the copies land in it
+                _lib.check(ctx.L.fpt_host_prefault(flat.ctypes.data, flat.nbytes))
         status[:] = 0
         if n_iv and total:
             ctx.set_bias_table(self.table, self.dflt)

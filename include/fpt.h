@@ -236,6 +236,11 @@ typedef struct fpt_scan_host_stats {
 } fpt_scan_host_stats;
 int fpt_scan_host_last(fpt_ctx *ctx, fpt_scan_host_stats *out);
 
+/* Touches every page of a FRESH (never written) host array with a team of threads, so that the first copy into it
+ * does not pay a page fault per 4 KiB (a new 1.6 GB numpy array takes a device-to-host copy at 20 GB/s instead of 56).
+ * Writes one zero byte per page: only for arrays that hold nothing yet.  No context needed. */
+int fpt_host_prefault(void *host, int64_t bytes);
+
 /* page-locked host memory for the arrays of fpt_scan_host (hipHostMalloc / hipHostFree) */
 int fpt_host_alloc(fpt_ctx *ctx, int64_t bytes, void **host_out);
 int fpt_host_free(fpt_ctx *ctx, void *host);

@@ -438,3 +438,22 @@ def test_qvalues_golden():
     with pytest.raises(ValueError):
         fdr.bh_qvalue(np.array([0.1, 1.2]))
     assert fdr.bh_qvalue(np.zeros(0)).size == 0
+
+
+def test_host_prefault_touches_without_changing_length():
+    """fpt_host_prefault (no GPU, no context): a team of threads writes one zero byte per page of a fresh array so that
+    the first copy into it pays no page faults.  Bounds: nothing outside [host, host + bytes) is written; small and
+    empty arrays are left alone; bad arguments are refused."""
+    from footprint_tools_amd import _lib
+    L = _lib.load()
+    n = (1 << 23) + 12345                      # 8 MiB and a ragged tail
+    buf = np.full(n + 8192, 7, dtype=np.uint8)
+    view = buf[4096 + 3:4096 + 3 + n]          # unaligned start, guard bytes either side
+    assert L.fpt_host_prefault(view.ctypes.data, view.size) == 0
+    assert np.all(buf[:4096 + 3] == 7) and np.all(buf[4096 + 3 + n:] == 7)      # the guards are untouched
+    touched = np.flatnonzero(view == 0)
+    assert touched.size >= n // 4096 - 2 and np.all(np.diff(touched) == 4096)     # one byte per page, nothing else
+    small = np.full(1000, 7, dtype=np.uint8)
+    assert L.fpt_host_prefault(small.ctypes.data, small.size) == 0 and np.all(small == 7)
+    assert L.fpt_host_prefault(None, 0) == 0
+    assert L.fpt_host_prefault(None, 10) == _lib.FPT_ERR_INVALID and L.fpt_host_prefault(small.ctypes.data, -1) == _lib.FPT_ERR_INVALID

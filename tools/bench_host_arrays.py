@@ -20,5 +20,6 @@ for chunk in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0").split(
         v = d[k]
         print("chunk %9d %-8s %.3g bases/s  call %.1f ms  first %.1f ms  chunks %d  link %.1f + %.1f GB/s  thread %s" % (
             chunk, k, v["value"], v["ms_per_call"], v["first_call_ms"], v["chunks"], v["link_GBps_h2d"], v["link_GBps_d2h"],
-            json.dumps({a: round(b, 1) for a, b in v["calling_thread_ms"].items()})))
+            json.dumps({a: round(b, 1) for a, b in v["calling_thread_ms"].items()})) +
+              ("  new output arrays %.1f ms" % v["new_output_arrays_ms"] if "new_output_arrays_ms" in v else ""))
     print("   parity", d["parity"])
