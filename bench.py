@@ -1356,6 +1356,8 @@ def main():
         if host_leg and "error" not in host_leg:
             summ["host_arrays_bases_per_s"] = dict(pageable=float("%.4g" % host_leg["pageable"]["value"]),
                                                    pinned=float("%.4g" % host_leg["pinned"]["value"]),
+                                                   pageable_new_output_arrays=float("%.4g" % host_leg["pageable"].get(
+                                                       "new_output_arrays_value", 0.0)),
                                                    parity_ok=bool(host_leg["parity"]["exp_bit_exact"]
                                                                   and host_leg["parity"]["p_max_rel_err"] < 1e-6
                                                                   and host_leg["parity"]["pinned_equals_pageable_bitwise"]))
