@@ -437,6 +437,43 @@ def test_scan_host_pipeline_equals_one_call(fpt, orc, shape):
         assert rel_err(out["pval"][sl], p) < P_TOL and rel_err(out["winp"][:, sl], wp) < P_TOL
 
 
+def test_scan_host_edge_batches(fpt, orc):
+    """fpt_scan_host on the batches a driver can hand over: no interval at all, one interval, zero-length intervals
+    between others (their padded rows are still in the arrays), every chunk size -- against the oracle, interval by
+    interval; a batch whose arrays do not fit its layout is refused before anything is launched."""
+    from footprint_tools_amd.scan import FootprintScanner
+    lat = golden("nb_lattice.npz")
+    table = golden("kmer_probs.npz")["table"]
+    sc = FootprintScanner(table, _DM(lat["mu_A"], lat["r_A"]), 5, 50, 0.01, (3,), nb_mode="memo")
+    out = sc.scan(np.zeros(0), np.zeros(0), np.zeros(0, np.uint8), interval_off=np.zeros(1, np.int64))
+    assert out["exp"].size == 0 and out["winp"].shape == (1, 0) and out["status"].size == 0
+    lens = np.array([0, 40, 0, 0, 700, 1, 0, 1300, 0], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n_iv, total = lens.size, int(off[-1])
+    n_c, n_s = sc.input_sizes(n_iv, total)
+    cp, cm, sq = orc.synth_counts(4, 0, n_c, 0), orc.synth_counts(4, 0, n_c, 1), orc.synth_bases(4, 0, n_s)
+    ref = None
+    for chunk in (0, 1, 50, 701):
+        out = sc.scan(cp, cm, sq, interval_off=off, chunk_bases=chunk)
+        got = np.concatenate([out["exp"], out["obs"], out["pval"], out["winp"].ravel()])
+        if ref is None:
+            ref = got
+        assert np.array_equal(got, ref, equal_nan=True), chunk
+    for i in np.flatnonzero(lens):
+        Li = int(lens[i])
+        c0, s0 = int(off[i]) + i * 111, int(off[i]) + i * 117
+        e, o, p, wp = orc.detect_batch(cp[c0:c0 + Li + 111], cm[c0:c0 + Li + 111], sq[s0:s0 + Li + 117], 1, Li, 5, 50, 0.01,
+                                       table, lat["mu_A"], lat["r_A"], np.array((3,), np.int32))
+        sl = slice(int(off[i]), int(off[i + 1]))
+        assert np.array_equal(out["exp"][sl], e) and np.array_equal(out["obs"][sl], o), i
+        assert rel_err(out["pval"][sl], p) < P_TOL and rel_err(out["winp"][:, sl], wp) < P_TOL, i
+    # (interval 1 -- the first is empty -- on its own: its rows start behind the empty interval's padding)
+    one = sc.scan(cp[111:111 + 40 + 111], cm[111:111 + 40 + 111], sq[117:117 + 40 + 117], interval_len=40)
+    assert np.array_equal(one["exp"], out["exp"][:40]) and np.array_equal(one["pval"], out["pval"][:40], equal_nan=True)
+    with pytest.raises(ValueError):
+        sc.scan(cp[:-1], cm[:-1], sq, interval_off=off)
+
+
 @pytest.mark.parametrize("kind", ["float", "huge", "mixed"])
 def test_fused_scan_non_integer_counts(fpt, orc, kind):
     """the smoothing scans run on int32 when a tile's window sums are small integers and on
